@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the KGAT propagation hot path on MI355X (contract: see the task statement).
+
+A *step* is one pass of the whole hot path over the CKG, the sequence of the reference's
+``eval()`` (kgat.py:53-59): ``compute_attention`` (attention logits over relation-grouped
+edges + destination softmax, models.py:146-154) followed by ``gnn`` (3 x [u_mul_e -> sum
+aggregation + bi-interaction], normalize, concat, models.py:156-168), with inputs resident in
+HBM.  ``value`` = propagation-layer edge traversals per second = n_layers * E / step time (the
+attention refresh is inside the timed step but its edge pass is not counted).
+
+N = 1 workload: BASELINE.json configs[2] - the amazon-book-shaped CKG (N = 159,251,
+E = 3,663,302, R = 41; synthetic, the real files are not available offline), 3 layers,
+embed_dim = 64, fp32.  N > 1: the same graph partitioned by destination range, one RCCL
+all-reduce of each layer's output (strong scaling).
+
+Extra objects on the JSON line: ``roofline`` for the u_mul_e_sum SpMM at D = 64 (HBM bound;
+algorithmic bytes E*(4D+8) + N*(4D+4)), ``roofline_att`` for the attention-logit
+kernel (fp32-MFMA bound), ``cpu_baseline`` = the C/OpenMP oracle (a restatement, DGL itself is
+not installable) timed on this box's host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+FP32_MFMA_PEAK_TF = 157.3  # dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="amazon-book", choices=["amazon-book", "last-fm", "power-law"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spmm-algo", default="auto")
+    return ap.parse_args()
+
+
+def make_workload(args):
+    from dgl_kgat_amd import synth
+    if args.workload == "amazon-book":
+        n, trip, n_rel = synth.amazon_book_ckg(seed=1234, scale=args.scale)
+        name = "amazon-book-shaped CKG"
+    elif args.workload == "last-fm":
+        n, trip, n_rel = synth.last_fm_ckg(seed=1234, scale=args.scale)
+        name = "last-fm-shaped CKG"
+    else:
+        n, trip, n_rel = synth.power_law_ckg(int(10_000_000 * args.scale), int(200_000_000 * args.scale), 64)
+        name = "power-law CKG"
+    return name, n, trip, n_rel
+
+
+def cpu_baseline(n, trip, n_rel, params, n_layers, steps):
+    """The same step on the host cores with the C/OpenMP oracle (kind = "port")."""
+    from oracle import c_oracle as co
+    src, dst, et = trip[:, 2], trip[:, 0], trip[:, 1]
+    indptr, col, eid = co.csr_from_coo(n, src, dst)
+    ent, W_R, rel = params["entity_embed.weight"], params["W_R"], params["relation_embed.weight"]
+    W2 = [params["layers.%d.res_fc_2.weight" % i] for i in range(n_layers)]
+
+    def step():
+        logits = co.att_score(ent, W_R, rel, src, dst, et)
+        a = co.edge_softmax(n, indptr, eid, logits)
+        h = ent
+        cache = [h]
+        for W in W2:
+            hn = co.spmm(n, indptr, col, eid, h, a)
+            h = co.bi_interaction(h, hn, W)
+            cache.append(co.l2_normalize(h))
+        return np.concatenate(cache, 1), a
+
+    out, a = step()  # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / max(steps, 1)
+    return dt, co.threads(), out, a
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import ops, partition, synth
+
+    name, n, trip, n_rel = make_workload(args)
+    E = len(trip)
+    torch.manual_seed(1234)
+    model = K.KGATPropagation(n, n_rel, input_node_dim=args.dim, relation_dim=args.dim,
+                              num_gnn_layers=args.layers, n_hidden=args.dim, dropout=0.0)
+    params = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    g_full = synth.build_graph(n, trip, dev)
+    if world > 1:
+        g, _ = partition.shard_graph(g_full, rank, world)
+    else:
+        g = g_full
+
+    def step():
+        with torch.no_grad():
+            a = model.compute_attention(g)
+            g.edata["w"] = a
+            return model.gnn(g), a
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out, a = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, a = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # per-kernel HIP-event timing over an identical set of steps (events on the launch stream)
+    with ops.KernelTimer() as kt:
+        for _ in range(args.steps):
+            step()
+    sync()
+    ksum = kt.summary()
+
+    def avg_ms(name_, pred=lambda info: True):
+        v = [ms for info, ms in ksum.get(name_, []) if pred(info)]
+        return (float(np.mean(v)), float(np.min(v)), len(v)) if v else (None, None, 0)
+
+    D = args.dim
+    spmm_ms, spmm_min, spmm_cnt = avg_ms("spmm", lambda info: info[2] == D)
+    att_ms, att_min, _ = avg_ms("att_score")
+    sm_ms, _, _ = avg_ms("edge_softmax")
+    spmm_info = [info for info, _ in ksum.get("spmm", []) if info[2] == D]
+    e_loc, rows_loc = (spmm_info[0][0], spmm_info[0][1]) if spmm_info else (E, n)
+    # algorithmic bytes of one SpMM launch on this rank: E*(4D+8) + N_out*(4D+4)
+    b_spmm = e_loc * (4 * D + 8) + rows_loc * (4 * D + 4)
+    roofline = None
+    if spmm_ms:
+        ach = b_spmm / (spmm_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge_kernel + spmm_finish_kernel), D=%d" % D,
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "algorithmic_bytes": int(b_spmm), "avg_ms": round(spmm_ms, 4),
+                    "min_ms": round(spmm_min, 4), "launches": spmm_cnt,
+                    "edges_per_s": round(e_loc / (spmm_ms * 1e-3), 1),
+                    "note": "X (N*D*4 = %.1f MB) is Infinity-Cache resident: gathered bytes are largely cache-served, "
+                            "not HBM bytes; compulsory HBM traffic is 8E + N(8D+4) = %.1f MB"
+                            % (n * D * 4 / 1e6, (8 * e_loc + n * (8 * D + 4)) / 1e6)}
+    roofline_att = None
+    if att_ms:
+        att_info = ksum["att_score"][0][0]
+        flops = att_info[0] * (4 * D * D + 3 * D)
+        tf_ = flops / (att_ms * 1e-3) / 1e12
+        roofline_att = {"bound": "mfma", "kernel": "kgat_att_score_f32 (att_score_mfma_kernel)", "achieved": round(tf_, 2),
+                        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_ / FP32_MFMA_PEAK_TF, 4),
+                        "traffic": None, "avg_ms": round(att_ms, 4), "min_ms": round(att_min, 4)}
+
+    result = {
+        "metric": "propagation-layer edges/sec on amazon-book CKG; achieved HBM GB/s vs peak",
+        "value": round(args.layers * E / (dt / args.steps), 1),
+        "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s N=%d E=%d R=%d, %d layers, embed_dim=%d, fp32; step = compute_attention + "
+                               "edge_softmax + %dx(u_mul_e_sum + bi-interaction) + normalize/concat"
+                               % (name, n, E, n_rel, args.layers, D, args.layers),
+                   "partition": "none" if world == 1 else "dst-range x%d, all-reduce of layer outputs" % world,
+                   "edges_counted_per_step": args.layers * E},
+        "roofline": roofline,
+        "roofline_att": roofline_att,
+        "breakdown_ms": {"att_score": att_ms, "edge_softmax": sm_ms, "spmm_D%d" % D: spmm_ms,
+                         "spmm_all": avg_ms("spmm")[0]},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cdt, cores, c_out, c_a = cpu_baseline(n, trip, n_rel, params, args.layers, args.cpu_steps)
+        scale = float(np.abs(c_out).max())
+        err = float(np.max(np.abs(out.cpu().numpy() - c_out))) / scale
+        err_a = float(np.max(np.abs(a.cpu().numpy().reshape(-1) - c_a)))
+        result["cpu_baseline"] = {"value": round(args.layers * E / cdt, 1), "unit": "edges/s", "cores": cores,
+                                  "kind": "port", "ms_per_step": round(cdt * 1e3, 2),
+                                  "sample": "%d full steps of the same workload (same graph, same parameters) with the "
+                                            "C/OpenMP oracle (oracle/kgat_oracle.c), %d threads; DGL-CPU itself is not "
+                                            "installable here" % (args.cpu_steps, cores),
+                                  "gpu_vs_cpu_max_abs_diff": {"gnn_out_rel_to_max": err, "attention_abs": err_a}}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

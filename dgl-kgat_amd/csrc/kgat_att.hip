@@ -1,0 +1,251 @@
+// TransR-style attention logits for gfx950.  Rows A1 + A2 of SURVEY.md 8a.
+//
+// Replaces the per-relation loop of reference models.py:146-152
+//     for i in range(R): eids = g.filter_edges(type == i); g.apply_edges(_att_score, eids)
+// and the UDF models.py:135-144
+//     t_r = ent[src] @ W_r ; h_r = ent[dst] @ W_r ; att = sum_j t_r[j] * tanh(h_r[j] + rel_r[j])
+// by ONE launch over relation-grouped edges.
+//
+// Design: this is the only dense contraction on the path (4*d*k FLOP per edge against
+// ~8*d bytes of gathered rows, AI ~ 31 FLOP/B at d = k = 64 > the fp32 ridge), so it is
+// bound by the fp32 matrix pipe: v_mfma_f32_16x16x4_f32 (exact fp32, a k-ordered fma chain).
+//  * A workgroup (4 wavefronts) owns a chunk of one relation's edges; W_r (d x k) is staged
+//    once per chunk into LDS in MFMA B-fragment order, so every B fetch is one conflict-free
+//    ds_read_b32 per lane, shared by 2*TILES MFMAs (t and h projections of TILES 16-edge tiles).
+//  * A fragments come straight from global memory: lane (edge i = lane&15, slot q = lane>>4)
+//    loads float4 pieces of its edge's embedding row so that the 4 lanes of an edge read 64
+//    contiguous bytes per instruction; the contraction index is permuted consistently in A
+//    and B (k-step s, slot q -> element 16*(s>>2) + 4*q + (s&3)), which MFMA does not care about.
+//  * The 16 x k projection tiles stay in the accumulators; tanh, the product and the row sum
+//    run on the VALU from there (row sum = 4 DPP-width shuffles over the 16 lanes of a slot).
+//  * Relation-grouped src/dst arrays make the per-tile index reads coalesced; logits are
+//    scattered back to edge-id order (and optionally to CSR position order for the softmax).
+#include <math.h>
+
+#include "kgat_common.h"
+
+namespace kgat {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kAttThreads = 256;
+constexpr int kAttChunk = 1024;  // edges of one relation per workgroup
+
+// Locate (relation, chunk) for a block: blocks are laid out relation by relation,
+// ceil(E_r / kAttChunk) blocks each.  Returns false past the end.
+__device__ __forceinline__ bool att_locate(const int32_t* __restrict__ rel_ptr, int n_rel,
+                                           int block, int& r_out, int32_t& beg, int32_t& end) {
+  int acc = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    const int32_t b = rel_ptr[r], e = rel_ptr[r + 1];
+    const int nb = (e - b + kAttChunk - 1) / kAttChunk;
+    if (block < acc + nb) {
+      r_out = r;
+      beg = b + (block - acc) * kAttChunk;
+      end = (beg + kAttChunk < e) ? beg + kAttChunk : e;
+      return true;
+    }
+    acc += nb;
+  }
+  return false;
+}
+
+template <int D_, int K_, int TILES>
+__global__ __launch_bounds__(kAttThreads) void att_score_mfma_kernel(
+    int n_rel, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ src_g, const int32_t* __restrict__ dst_g,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ logits, float* __restrict__ logits_csr,
+    const int32_t* __restrict__ csr_pos) {
+  constexpr int KS = D_ / 4;   // k-steps (4 contraction elements each)
+  constexpr int KT = K_ / 16;  // 16-wide column tiles of the projection
+  constexpr int EPW = 16 * TILES;
+  __shared__ float s_w[KS * KT * kWave];
+
+  int r;
+  int32_t cbeg, cend;
+  if (!att_locate(rel_ptr, n_rel, blockIdx.x, r, cbeg, cend)) return;
+
+  const int tid = threadIdx.x;
+  // ---- stage W_r into LDS in B-fragment order: s_w[(s*KT + c)*64 + q*16 + n] =
+  //      W_r[16*(s>>2) + 4*q + (s&3)][16*c + n]
+  {
+    const float* W = W_R + (size_t)r * D_ * K_;
+    for (int idx = tid; idx < D_ * K_; idx += kAttThreads) {
+      const int row = idx / K_, colx = idx % K_;
+      const int s = (row >> 4) * 4 + (row & 3);
+      const int q = (row >> 2) & 3;
+      const int c = colx >> 4, n = colx & 15;
+      s_w[(s * KT + c) * kWave + q * 16 + n] = W[idx];
+    }
+  }
+  const int wave = tid / kWave, lane = tid % kWave;
+  const int i = lane & 15, q = lane >> 4;
+  float relv[KT];
+#pragma unroll
+  for (int c = 0; c < KT; ++c) relv[c] = rel[(size_t)r * K_ + 16 * c + i];
+  __syncthreads();
+
+  for (int32_t t0 = cbeg + wave * EPW; t0 < cend; t0 += (kAttThreads / kWave) * EPW) {
+    float aT[TILES][KS], aH[TILES][KS];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int32_t pe = t0 + t * 16 + i;
+      const bool valid = pe < cend;
+      const int32_t rs = valid ? src_g[pe] : 0;
+      const int32_t rd = valid ? dst_g[pe] : 0;
+      const float4* ps = reinterpret_cast<const float4*>(ent + (size_t)rs * D_) + q;
+      const float4* pd = reinterpret_cast<const float4*>(ent + (size_t)rd * D_) + q;
+#pragma unroll
+      for (int m = 0; m < D_ / 16; ++m) {
+        const float4 a = ps[m * 4];
+        const float4 b = pd[m * 4];
+        aT[t][4 * m + 0] = a.x; aT[t][4 * m + 1] = a.y; aT[t][4 * m + 2] = a.z; aT[t][4 * m + 3] = a.w;
+        aH[t][4 * m + 0] = b.x; aH[t][4 * m + 1] = b.y; aH[t][4 * m + 2] = b.z; aH[t][4 * m + 3] = b.w;
+      }
+    }
+    floatx4 accT[TILES][KT], accH[TILES][KT];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        accT[t][c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        accH[t][c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const float b = s_w[(s * KT + c) * kWave + lane];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          accT[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[t][s], b, accT[t][c], 0, 0, 0);
+          accH[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH[t][s], b, accH[t][c], 0, 0, 0);
+        }
+      }
+    }
+    // accX[t][c][j] = projection[edge 4*q + j of tile t][column 16*c + i]
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[j] = fmaf(accT[t][c][j], tanhf(accH[t][c][j] + relv[c]), part[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) part[j] += __shfl_xor(part[j], off, 16);
+      }
+      // lanes i = 0..3 of slot q write edges 4*q + i
+      const float v = i == 0 ? part[0] : (i == 1 ? part[1] : (i == 2 ? part[2] : part[3]));
+      const int32_t pe = t0 + t * 16 + 4 * q + i;
+      if (i < 4 && pe < cend) {
+        const int32_t e = perm[pe];
+        logits[e] = v;
+        if (logits_csr) logits_csr[csr_pos[e]] = v;
+      }
+    }
+  }
+}
+
+// Any (d, k): VALU kernel, one wavefront per 64-edge step, W_r column-sliced through LDS.
+// Correctness path for widths the MFMA kernel does not cover (e.g. the d = k = 8 config).
+__global__ __launch_bounds__(kAttThreads) void att_score_generic_kernel(
+    int d, int k, int n_rel, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ src_g, const int32_t* __restrict__ dst_g,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ logits, float* __restrict__ logits_csr,
+    const int32_t* __restrict__ csr_pos) {
+  extern __shared__ float s_wg[];  // d*k floats of W_r
+  int r;
+  int32_t cbeg, cend;
+  if (!att_locate(rel_ptr, n_rel, blockIdx.x, r, cbeg, cend)) return;
+  const float* W = W_R + (size_t)r * d * k;
+  for (int idx = threadIdx.x; idx < d * k; idx += kAttThreads) s_wg[idx] = W[idx];
+  __syncthreads();
+  const float* er = rel + (size_t)r * k;
+  for (int32_t pe = cbeg + threadIdx.x; pe < cend; pe += kAttThreads) {
+    const float* xt = ent + (size_t)src_g[pe] * d;
+    const float* xh = ent + (size_t)dst_g[pe] * d;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      float tr = 0.f, hr = 0.f;
+      for (int a = 0; a < d; ++a) {
+        const float wv = s_wg[a * k + j];
+        tr = fmaf(xt[a], wv, tr);
+        hr = fmaf(xh[a], wv, hr);
+      }
+      acc = fmaf(tr, tanhf(hr + er[j]), acc);
+    }
+    const int32_t e = perm[pe];
+    logits[e] = acc;
+    if (logits_csr) logits_csr[csr_pos[e]] = acc;
+  }
+}
+
+template <int D_, int K_, int TILES>
+static int launch_att_mfma(unsigned grid, hipStream_t st, int n_rel, const int32_t* rel_ptr,
+                           const int32_t* perm, const int32_t* src_g, const int32_t* dst_g,
+                           const float* ent, const float* W_R, const float* rel, float* logits,
+                           float* logits_csr, const int32_t* csr_pos) {
+  hipLaunchKernelGGL((att_score_mfma_kernel<D_, K_, TILES>), dim3(grid), dim3(kAttThreads), 0, st,
+                     n_rel, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+  KGAT_CHECK_LAUNCH("att_score_mfma");
+  return KGAT_OK;
+}
+
+}  // namespace kgat
+
+using namespace kgat;
+
+extern "C" {
+
+int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                       const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                       const int32_t* dst_g, const float* ent, const float* W_R, const float* rel,
+                       float* logits, float* logits_csr, const int32_t* csr_pos, int algo,
+                       kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && d > 0 && k > 0 && n_rel >= 0,
+                 "att_score: bad size");
+  KGAT_CHECK_ARG(n_edges < INT32_MAX, "att_score: size exceeds int32");
+  if (n_edges == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(logits != nullptr, "att_score: logits is null");
+  KGAT_CHECK_ARG(logits_csr == nullptr || csr_pos != nullptr, "att_score: logits_csr needs csr_pos");
+  KGAT_CHECK_ARG(algo >= KGAT_ATT_ALGO_AUTO && algo <= KGAT_ATT_ALGO_GENERIC, "att_score: bad algo");
+  hipStream_t st = as_stream(stream);
+  // edges whose type is outside [0, R) keep logit 0 (DGL zero-initialised column)
+  hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)n_edges, st);
+  if (e == hipSuccess && logits_csr) e = hipMemsetAsync(logits_csr, 0, sizeof(float) * (size_t)n_edges, st);
+  if (e != hipSuccess) {
+    set_error("att_score: memset failed: %s", hipGetErrorString(e));
+    return KGAT_E_HIP;
+  }
+  if (n_rel == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(rel_ptr && perm && src_g && dst_g && ent && W_R && rel, "att_score: null pointer");
+  const unsigned grid = (unsigned)((n_edges + kAttChunk - 1) / kAttChunk + n_rel);
+  const bool mfma_ok = (d == k) && (d == 16 || d == 32 || d == 64 || d == 128);
+  if (algo == KGAT_ATT_ALGO_MFMA && !mfma_ok) {
+    set_error("att_score: the MFMA kernel covers d == k in {16,32,64,128}, got d=%d k=%d", d, k);
+    return KGAT_E_UNSUPPORTED;
+  }
+  if (mfma_ok && algo != KGAT_ATT_ALGO_GENERIC) {
+    switch (d) {
+      case 16: return launch_att_mfma<16, 16, 2>(grid, st, n_rel, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+      case 32: return launch_att_mfma<32, 32, 2>(grid, st, n_rel, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+      case 64: return launch_att_mfma<64, 64, 2>(grid, st, n_rel, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+      default: return launch_att_mfma<128, 128, 1>(grid, st, n_rel, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+    }
+  }
+  const size_t lds = sizeof(float) * (size_t)d * k;
+  if (lds > 64 * 1024) {
+    set_error("att_score: d*k = %d exceeds the generic kernel's LDS tile", d * k);
+    return KGAT_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(att_score_generic_kernel, dim3(grid), dim3(kAttThreads), lds, st, d, k, n_rel,
+                     rel_ptr, perm, src_g, dst_g, ent, W_R, rel, logits, logits_csr, csr_pos);
+  KGAT_CHECK_LAUNCH("att_score_generic");
+  return KGAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// Graph-structure kernels for gfx950: stable radix sort, COO -> CSR-by-destination,
+// grouping of edges by relation, permutation helpers.  Row G0 / A1 of SURVEY.md 8a.
+//
+// Replaces (a) DGL 0.4.x's COO -> in-CSR conversion that runs on the first kernel call on a
+// graph built by reference dataset.py:112-120, and (b) the R full-graph filter_edges sweeps
+// of reference models.py:149-150.  One-off, integer, HBM-bound work: coalesced key reads,
+// wave-ballot ranking, no MFMA.
+#include <stdarg.h>
+
+#include "kgat_common.h"
+
+namespace kgat {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------ exclusive scan (int32)
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 4096 elements per block
+
+// Per-block exclusive scan; block totals go to sums[blockIdx] (if non-null).
+__global__ __launch_bounds__(kScanThreads) void scan_block_kernel(int32_t* __restrict__ data,
+                                                                    int64_t n,
+                                                                    int32_t* __restrict__ sums) {
+  __shared__ int32_t s_wave[kScanThreads / kWave];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
+  int32_t v[kScanItems];
+  int32_t tsum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    v[i] = (base + i < n) ? data[base + i] : 0;
+    tsum += v[i];
+  }
+  // inclusive scan of thread sums inside the wave
+  int32_t inc = tsum;
+  const int lane = tid & (kWave - 1), wv = tid / kWave;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    int32_t up = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += up;
+  }
+  if (lane == kWave - 1) s_wave[wv] = inc;
+  __syncthreads();
+  int32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < kScanThreads / kWave; ++i) {
+    if (i < wv) wbase += s_wave[i];
+    total += s_wave[i];
+  }
+  int32_t run = wbase + inc - tsum;  // exclusive prefix of this thread
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) data[base + i] = run;
+    run += v[i];
+  }
+  if (sums != nullptr && tid == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_add_kernel(int32_t* __restrict__ data,
+                                                                  int64_t n,
+                                                                  const int32_t* __restrict__ sums) {
+  const int32_t add = sums[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  for (int i = threadIdx.x; i < kScanTile; i += kScanThreads)
+    if (base + i < n) data[base + i] += add;
+}
+
+size_t scan_workspace_elems(int64_t n) {
+  size_t total = 0;
+  while (n > kScanTile) {
+    n = (n + kScanTile - 1) / kScanTile;
+    total += align_up((size_t)n, 64);
+  }
+  return total + 64;
+}
+
+int exclusive_scan_i32(int32_t* data, int64_t n, int32_t* ws, hipStream_t st) {
+  if (n <= 0) return KGAT_OK;
+  const int64_t nblk = (n + kScanTile - 1) / kScanTile;
+  if (nblk == 1) {
+    hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(kScanThreads), 0, st, data, n,
+                       (int32_t*)nullptr);
+    KGAT_CHECK_LAUNCH("scan_block");
+    return KGAT_OK;
+  }
+  int32_t* sums = ws;
+  hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, data, n,
+                     sums);
+  KGAT_CHECK_LAUNCH("scan_block");
+  int rc = exclusive_scan_i32(sums, nblk, ws + align_up((size_t)nblk, 64), st);
+  if (rc != KGAT_OK) return rc;
+  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, data, n,
+                     sums);
+  KGAT_CHECK_LAUNCH("scan_add");
+  return KGAT_OK;
+}
+
+// ------------------------------------------------------------------ stable LSD radix sort
+// One wavefront per block, kSortTile keys per block, 8-bit digits.  The scatter pass ranks
+// the 64 keys of a step with wave ballots (peers with the same digit and a lower lane), so
+// equal keys keep their input order: the sort is stable, which is what makes edge ids
+// ascend inside every CSR row.
+constexpr int kSortTile = 4096;
+constexpr int kDigits = 256;
+
+__global__ __launch_bounds__(kWave) void sort_hist_kernel(const int32_t* __restrict__ keys,
+                                                          int64_t n, int shift,
+                                                          int32_t* __restrict__ hist,
+                                                          int nblk) {
+  __shared__ int32_t cnt[kDigits];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < kDigits; i += kWave) cnt[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  for (int j = lane; j < kSortTile; j += kWave) {
+    const int64_t idx = base + j;
+    if (idx < n) atomicAdd(&cnt[((uint32_t)keys[idx] >> shift) & (kDigits - 1)], 1);
+  }
+  __syncthreads();
+  for (int i = lane; i < kDigits; i += kWave) hist[(size_t)i * nblk + blockIdx.x] = cnt[i];
+}
+
+__global__ __launch_bounds__(kWave) void sort_scatter_kernel(
+    const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int64_t n,
+    int shift, const int32_t* __restrict__ offs, int nblk, int32_t* __restrict__ keys_out,
+    int32_t* __restrict__ vals_out) {
+  __shared__ int32_t run[kDigits];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < kDigits; i += kWave) run[i] = offs[(size_t)i * nblk + blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int step = 0; step < kSortTile / kWave; ++step) {
+    const int64_t idx = base + (int64_t)step * kWave + lane;
+    const bool valid = idx < n;
+    const int32_t key = valid ? keys_in[idx] : 0;
+    const uint32_t dgt = ((uint32_t)key >> shift) & (kDigits - 1);
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (dgt >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(peers & lt_mask);
+    const int32_t basep = run[dgt];
+    __syncthreads();  // every lane has read its base before any leader bumps it
+    if (valid) {
+      const int32_t pos = basep + rank;
+      keys_out[pos] = key;
+      vals_out[pos] = vals_in ? vals_in[idx] : (int32_t)idx;
+      if (rank == 0) run[dgt] = basep + __popcll(peers);
+    }
+    __syncthreads();
+  }
+}
+
+struct SortPlan {
+  int nblk;
+  size_t hist_elems, scan_elems;
+};
+
+static SortPlan sort_plan(int64_t n) {
+  SortPlan p;
+  p.nblk = (int)((n + kSortTile - 1) / kSortTile);
+  if (p.nblk < 1) p.nblk = 1;
+  p.hist_elems = (size_t)kDigits * p.nblk;
+  p.scan_elems = scan_workspace_elems((int64_t)p.hist_elems);
+  return p;
+}
+
+size_t radix_sort_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  SortPlan p = sort_plan(n);
+  size_t b = 0;
+  b += 3 * align_up((size_t)n * 4, 256);  // keys ping, keys pong, vals pong
+  b += align_up(p.hist_elems * 4, 256);
+  b += align_up(p.scan_elems * 4, 256);
+  return b;
+}
+
+int radix_sort_index(const int32_t* keys_in, int64_t n, int key_bits, int32_t* vals_out,
+                     const int32_t** sorted_keys, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < radix_sort_workspace_bytes(n)) {
+    set_error("radix_sort: workspace too small (%zu < %zu)", ws_bytes,
+              radix_sort_workspace_bytes(n));
+    return KGAT_E_WORKSPACE;
+  }
+  Carver cv(ws);
+  int32_t* K[2] = {cv.take<int32_t>((size_t)(n > 0 ? n : 1)), cv.take<int32_t>((size_t)(n > 0 ? n : 1))};
+  int32_t* V1 = cv.take<int32_t>((size_t)(n > 0 ? n : 1));
+  SortPlan p = sort_plan(n);
+  int32_t* hist = cv.take<int32_t>(p.hist_elems);
+  int32_t* scan_ws = cv.take<int32_t>(p.scan_elems);
+  if (sorted_keys) *sorted_keys = K[0];
+  if (n <= 0) return KGAT_OK;
+  int passes = (key_bits + 7) / 8;
+  if (passes < 1) passes = 1;
+  int32_t* V[2] = {vals_out, V1};
+  const int32_t* kin = keys_in;
+  const int32_t* vin = nullptr;  // pass 0 emits the source index itself
+  for (int j = 0; j < passes; ++j) {
+    const int sel = (passes - 1 - j) & 1;  // the last pass lands in K[0] / vals_out
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(p.nblk), dim3(kWave), 0, st, kin, n, 8 * j, hist,
+                       p.nblk);
+    KGAT_CHECK_LAUNCH("sort_hist");
+    int rc = exclusive_scan_i32(hist, (int64_t)p.hist_elems, scan_ws, st);
+    if (rc != KGAT_OK) return rc;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.nblk), dim3(kWave), 0, st, kin, vin, n, 8 * j,
+                       (const int32_t*)hist, p.nblk, K[sel], V[sel]);
+    KGAT_CHECK_LAUNCH("sort_scatter");
+    kin = K[sel];
+    vin = V[sel];
+  }
+  return KGAT_OK;
+}
+
+// ------------------------------------------------------------------ small helpers
+__global__ void gather_i32_kernel(int64_t n, const int32_t* __restrict__ index,
+                                  const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[index[i]];
+}
+
+__global__ void gather_f32_kernel(int64_t n, const int32_t* __restrict__ index,
+                                  const float* __restrict__ in, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[index[i]];
+}
+
+__global__ void invert_perm_kernel(int64_t n, const int32_t* __restrict__ perm,
+                                   int32_t* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = (int32_t)i;
+}
+
+// offsets[v] = first sorted position whose key is >= v, for v in [0, n_keys]; keys sorted.
+// Thread p owns the boundary between sorted positions p-1 and p.
+__global__ void offsets_from_sorted_kernel(int64_t n, const int32_t* __restrict__ keys,
+                                           int32_t n_keys, int32_t* __restrict__ offsets) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n) return;
+  int32_t prev = (p == 0) ? -1 : keys[p - 1];
+  int32_t cur = (p == n) ? n_keys : keys[p];
+  if (cur > n_keys) cur = n_keys;
+  if (prev > n_keys) prev = n_keys;
+  for (int32_t v = prev + 1; v <= cur; ++v) offsets[v] = (int32_t)p;
+}
+
+__global__ void relation_key_kernel(int64_t n, int n_rel, const int32_t* __restrict__ etype,
+                                    int32_t* __restrict__ key) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int32_t t = etype[i];
+    key[i] = (t >= 0 && t < n_rel) ? t : n_rel;
+  }
+}
+
+constexpr int kDegClamp = 65535;
+__global__ void degree_key_kernel(int64_t n, const int32_t* __restrict__ indptr,
+                                  int32_t* __restrict__ key) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int32_t deg = indptr[i + 1] - indptr[i];
+    if (deg > kDegClamp) deg = kDegClamp;
+    key[i] = kDegClamp - deg;  // ascending key = descending degree
+  }
+}
+
+static inline unsigned blocks_for(int64_t n, int threads) {
+  return (unsigned)((n + threads - 1) / threads);
+}
+
+static int bits_for(int64_t max_key) {
+  int b = 1;
+  while (b < 31 && ((int64_t)1 << b) <= max_key) ++b;
+  return b;
+}
+
+}  // namespace kgat
+
+using namespace kgat;
+
+extern "C" {
+
+int kgat_version(void) { return KGAT_ABI_VERSION; }
+
+const char* kgat_last_error(void) { return kgat::g_err; }
+
+size_t kgat_csr_from_coo_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+  (void)n_nodes;
+  return radix_sort_workspace_bytes(n_edges);
+}
+
+int kgat_csr_from_coo(int64_t n_nodes, int64_t n_edges, const int32_t* src, const int32_t* dst,
+                      int32_t* indptr, int32_t* col, int32_t* eid, int32_t* row_of,
+                      void* workspace, size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0, "csr_from_coo: negative size");
+  KGAT_CHECK_ARG(n_nodes < INT32_MAX && n_edges < INT32_MAX, "csr_from_coo: size exceeds int32");
+  KGAT_CHECK_ARG(indptr != nullptr, "csr_from_coo: indptr is null");
+  KGAT_CHECK_ARG(n_edges == 0 || (src && dst && col && eid && workspace),
+                 "csr_from_coo: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int32_t* sorted = nullptr;
+  if (n_edges > 0) {
+    int rc = radix_sort_index(dst, n_edges, bits_for(n_nodes > 0 ? n_nodes - 1 : 0), eid, &sorted,
+                              workspace, workspace_bytes, st);
+    if (rc != KGAT_OK) return rc;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st,
+                       n_edges, (const int32_t*)eid, src, col);
+    KGAT_CHECK_LAUNCH("csr gather col");
+    if (row_of) {
+      hipError_t e = hipMemcpyAsync(row_of, sorted, sizeof(int32_t) * (size_t)n_edges,
+                                    hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) {
+        set_error("csr_from_coo: memcpy failed: %s", hipGetErrorString(e));
+        return KGAT_E_HIP;
+      }
+    }
+  }
+  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0,
+                     st, n_edges, sorted, (int32_t)n_nodes, indptr);
+  KGAT_CHECK_LAUNCH("csr offsets");
+  return KGAT_OK;
+}
+
+size_t kgat_group_by_relation_workspace_bytes(int64_t n_edges, int n_rel) {
+  (void)n_rel;
+  return radix_sort_workspace_bytes(n_edges) + align_up((size_t)(n_edges > 0 ? n_edges : 1) * 4, 256) +
+         align_up(((size_t)(n_rel > 0 ? n_rel : 0) + 2) * 4, 256);
+}
+
+int kgat_group_by_relation(int64_t n_edges, int n_rel, const int32_t* etype, int32_t* rel_ptr,
+                           int32_t* perm, void* workspace, size_t workspace_bytes,
+                           kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0 && n_rel >= 0, "group_by_relation: negative size");
+  KGAT_CHECK_ARG(n_edges < INT32_MAX, "group_by_relation: size exceeds int32");
+  KGAT_CHECK_ARG(rel_ptr != nullptr && workspace != nullptr, "group_by_relation: null pointer");
+  KGAT_CHECK_ARG(n_edges == 0 || (etype && perm), "group_by_relation: null pointer");
+  if (workspace_bytes < kgat_group_by_relation_workspace_bytes(n_edges, n_rel)) {
+    set_error("group_by_relation: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace);
+  int32_t* key = cv.take<int32_t>((size_t)(n_edges > 0 ? n_edges : 1));
+  int32_t* offs = cv.take<int32_t>((size_t)n_rel + 2);
+  void* sort_ws = cv.base + cv.off;
+  const int32_t* sorted = nullptr;
+  if (n_edges > 0) {
+    hipLaunchKernelGGL(relation_key_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st,
+                       n_edges, n_rel, etype, key);
+    KGAT_CHECK_LAUNCH("relation_key");
+    int rc = radix_sort_index(key, n_edges, bits_for(n_rel), perm, &sorted, sort_ws,
+                              workspace_bytes - cv.off, st);
+    if (rc != KGAT_OK) return rc;
+  }
+  // offs[v] for v in [0, n_rel+1]; rel_ptr is its first n_rel+1 entries
+  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0,
+                     st, n_edges, sorted, (int32_t)(n_rel + 1), offs);
+  KGAT_CHECK_LAUNCH("relation offsets");
+  hipError_t e = hipMemcpyAsync(rel_ptr, offs, sizeof(int32_t) * ((size_t)n_rel + 1),
+                                hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) {
+    set_error("group_by_relation: memcpy failed: %s", hipGetErrorString(e));
+    return KGAT_E_HIP;
+  }
+  return KGAT_OK;
+}
+
+int kgat_invert_permutation(int64_t n, const int32_t* perm, int32_t* inv, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n >= 0, "invert_permutation: negative size");
+  if (n == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(perm && inv, "invert_permutation: null pointer");
+  hipLaunchKernelGGL(invert_perm_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream),
+                     n, perm, inv);
+  KGAT_CHECK_LAUNCH("invert_perm");
+  return KGAT_OK;
+}
+
+size_t kgat_row_order_workspace_bytes(int64_t n_rows) {
+  return radix_sort_workspace_bytes(n_rows) + align_up((size_t)(n_rows > 0 ? n_rows : 1) * 4, 256);
+}
+
+int kgat_row_order_by_degree(int64_t n_rows, const int32_t* indptr, int32_t* order,
+                             void* workspace, size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX, "row_order: bad size");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(indptr && order && workspace, "row_order: null pointer");
+  if (workspace_bytes < kgat_row_order_workspace_bytes(n_rows)) {
+    set_error("row_order: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace);
+  int32_t* key = cv.take<int32_t>((size_t)n_rows);
+  hipLaunchKernelGGL(degree_key_kernel, dim3(blocks_for(n_rows, 256)), dim3(256), 0, st, n_rows,
+                     indptr, key);
+  KGAT_CHECK_LAUNCH("degree_key");
+  return radix_sort_index(key, n_rows, 16, order, nullptr, cv.base + cv.off,
+                          workspace_bytes - cv.off, st);
+}
+
+int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t* out,
+                    kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n >= 0, "gather: negative size");
+  if (n == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(index && in && out, "gather: null pointer");
+  hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream),
+                     n, index, in, out);
+  KGAT_CHECK_LAUNCH("gather_i32");
+  return KGAT_OK;
+}
+
+int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out,
+                    kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n >= 0, "gather: negative size");
+  if (n == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(index && in && out, "gather: null pointer");
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream),
+                     n, index, in, out);
+  KGAT_CHECK_LAUNCH("gather_f32");
+  return KGAT_OK;
+}
+
+}  // extern "C"

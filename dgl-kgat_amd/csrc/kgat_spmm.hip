@@ -1,0 +1,471 @@
+// u_mul_e -> sum aggregation (SpMM) for gfx950.  Row S1 / S1b of SURVEY.md 8a.
+//
+// Replaces g.update_all(fn.u_mul_e('h','w','m'), fn.sum('m','h_neighbor')) of reference
+// models.py:63 (DGL binary_reduce(sum, mul, SRC, EDGE), (N,D) x (E,1) broadcast):
+//   out[v,:] = sum_{p in row v} w_p * X[col[p],:]
+//
+// Design (HBM/Infinity-Cache gather bound, 0.5 FLOP/B - no MFMA):
+//  * Edge-balanced ("merge-path") decomposition over the destination-sorted edge array:
+//    every 256-thread workgroup owns a tile of TE consecutive CSR positions, whatever rows
+//    they belong to, so a power-law in-degree distribution cannot unbalance the launch.
+//  * A row of X is D floats; LPR = D/4 lanes read it with one 16-byte load each (a full
+//    256-B row per 16 lanes at D = 64, coalesced).  A wavefront therefore works on 64/LPR
+//    edges per load instruction; each lane group ("subgroup") walks its own run of C
+//    consecutive edges with U loads in flight, accumulating in registers and flushing when
+//    the destination row changes (the row id of every CSR position is a graph-static array).
+//  * col / w / row ids of a run are read coalesced (LPR consecutive entries per load) and
+//    handed around the subgroup with wavefront shuffles (ds_bpermute), not re-read.
+//  * Rows that end inside a run are stored straight to `out`.  A run's first and last row
+//    may continue in a neighbour run: those partial sums are combined through LDS in run
+//    order by the workgroup; only the first/last row of the whole tile goes to a small
+//    global partial buffer, which the finish kernel sums in tile order.  No float atomics:
+//    the summation order is fixed, results are bitwise reproducible.
+//  * The finish kernel also writes the zero rows (destinations without in-edges).
+#include "kgat_common.h"
+
+namespace kgat {
+
+__device__ __forceinline__ float4 fma4(float a, const float4& x, const float4& c) {
+  return make_float4(fmaf(a, x.x, c.x), fmaf(a, x.y, c.y), fmaf(a, x.z, c.z), fmaf(a, x.w, c.w));
+}
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 mul4(const float4& a, const float4& b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
+constexpr int kSpmmThreads = 256;
+
+template <int LPR>
+struct SpmmGeom {
+  static constexpr int NSUB = kSpmmThreads / LPR;  // subgroups per workgroup
+  static constexpr int U = LPR >= 4 ? 4 : LPR;     // X-row loads in flight per subgroup
+};
+
+// Final store of a complete row.
+template <int LPR, bool MUL_SELF>
+__device__ __forceinline__ void store_row(float4* __restrict__ out, const float4* __restrict__ X,
+                                          int32_t row, int32_t row0, int sl, float4 v) {
+  if (MUL_SELF) v = mul4(v, X[(size_t)row * LPR + sl]);
+  out[(size_t)(row - row0) * LPR + sl] = v;
+}
+
+template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_merge_kernel(
+    int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ row_of, const int32_t* __restrict__ eid,
+    const float4* __restrict__ X, const float* __restrict__ w, float4* __restrict__ out,
+    float4* __restrict__ bpart) {
+  constexpr int NSUB = SpmmGeom<LPR>::NSUB;
+  constexpr int U = SpmmGeom<LPR>::U;
+  constexpr int TE = NSUB * C;
+  __shared__ float4 s_part[NSUB][2][LPR];
+  __shared__ int32_t s_row[NSUB][2];
+
+  const int tid = threadIdx.x;
+  const int sub = tid / LPR, sl = tid % LPR;
+  const int64_t tile0 = e0 + (int64_t)blockIdx.x * TE;
+  const int64_t tile1 = (tile0 + TE < e1) ? tile0 + TE : e1;
+  const int64_t p0 = tile0 + (int64_t)sub * C;
+  const int64_t p1 = (p0 + C < tile1) ? p0 + C : tile1;
+
+  int32_t cur_row = -1;
+  bool head_done = false;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int64_t base = p0; base < p1; base += LPR) {
+    const int64_t my = base + sl;
+    const bool valid = my < p1;
+    const int32_t c = valid ? col[my] : 0;
+    const int32_t r = valid ? row_of[my] : -1;
+    float wv = 0.f;
+    if (valid) wv = HAS_EID ? w[eid[my]] : w[my];
+    const int n = (p1 - base < LPR) ? (int)(p1 - base) : LPR;
+    for (int j = 0; j < n; j += U) {
+      int32_t cj[U], rj[U];
+      float wj[U];
+      float4 x[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        cj[i] = __shfl(c, j + i, LPR);
+        rj[i] = __shfl(r, j + i, LPR);
+        wj[i] = __shfl(wv, j + i, LPR);
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) x[i] = X[(size_t)cj[i] * LPR + sl];  // padding lanes: row 0, w = 0
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        if (j + i < n) {
+          if (rj[i] != cur_row) {
+            if (cur_row >= 0) {
+              if (!head_done) {
+                s_part[sub][0][sl] = acc;
+                if (sl == 0) s_row[sub][0] = cur_row;
+                head_done = true;
+              } else {
+                store_row<LPR, MUL_SELF>(out, X, cur_row, row0, sl, acc);
+              }
+            }
+            cur_row = rj[i];
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          acc = fma4(wj[i], x[i], acc);
+        }
+      }
+    }
+  }
+  // the run's last open row: head slot if the run never changed row, else tail slot
+  if (!head_done) {
+    s_part[sub][0][sl] = acc;
+    if (sl == 0) {
+      s_row[sub][0] = cur_row;  // -1 for an empty run
+      s_row[sub][1] = -1;
+    }
+  } else {
+    s_part[sub][1][sl] = acc;
+    if (sl == 0) s_row[sub][1] = cur_row;
+  }
+  __syncthreads();
+
+  // In-order combine of the run-boundary partials by subgroup 0.
+  if (sub == 0) {
+    const int32_t first_row = s_row[0][0];
+    const int32_t last_row = row_of[tile1 - 1];
+    float4* bp = bpart + (size_t)blockIdx.x * 2 * LPR;
+    int32_t crow = -1;
+    float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto emit = [&](int32_t rr, const float4& v) {
+      if (rr < 0) return;
+      if (rr == first_row) bp[sl] = v;
+      else if (rr == last_row) bp[LPR + sl] = v;
+      else store_row<LPR, MUL_SELF>(out, X, rr, row0, sl, v);
+    };
+    for (int s = 0; s < NSUB; ++s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int32_t rr = s_row[s][t];
+        if (rr < 0) continue;
+        const float4 v = s_part[s][t][sl];
+        if (rr == crow) {
+          cacc = add4(cacc, v);
+        } else {
+          emit(crow, cacc);
+          crow = rr;
+          cacc = v;
+        }
+      }
+    }
+    emit(crow, cacc);
+  }
+}
+
+// Finish: (a) rows that are first/last in some tile: sum their tile partials in tile order;
+// (b) rows without in-edges: write zeros.  One wavefront per (tile, slot) item for (a).
+template <int LPR, int C, bool MUL_SELF>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
+    int64_t e0, int64_t e1, int32_t row0, int32_t n_rows, int32_t n_tiles,
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
+    const float4* __restrict__ X, float4* __restrict__ out, const float4* __restrict__ bpart,
+    int32_t fix_blocks) {
+  constexpr int NSUB = SpmmGeom<LPR>::NSUB;
+  constexpr int TE = NSUB * C;
+  constexpr int SPW = kWave / LPR >= 1 ? kWave / LPR : 1;  // subgroups per wave
+  constexpr int WPB = kSpmmThreads / kWave;
+  const int tid = threadIdx.x;
+  if ((int32_t)blockIdx.x < fix_blocks) {
+    if (LPR > kWave) return;  // not instantiated
+    const int wave = tid / kWave, lane = tid % kWave;
+    const int q = lane / LPR, sl = lane % LPR;
+    const int64_t item = (int64_t)blockIdx.x * WPB + wave;
+    const int32_t b = (int32_t)(item >> 1);
+    const int s = (int)(item & 1);
+    if (b >= n_tiles) return;
+    const int64_t t0 = e0 + (int64_t)b * TE;
+    const int64_t t1 = (t0 + TE < e1) ? t0 + TE : e1;
+    const int32_t fr = row_of[t0], lr = row_of[t1 - 1];
+    if (s == 1 && lr == fr) return;
+    const int32_t r = s == 0 ? fr : lr;
+    const int64_t rb = indptr[r], re = indptr[r + 1];
+    const int32_t bf = (int32_t)((rb - e0) / TE);
+    if (bf != b) return;  // another tile owns this row's fix-up
+    const int32_t bl = (int32_t)((re - 1 - e0) / TE);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int32_t bb = b + q; bb <= bl; bb += SPW) {
+      const int slot = (bb == b) ? s : 0;
+      acc = add4(acc, bpart[((size_t)bb * 2 + slot) * LPR + sl]);
+    }
+    // fixed-order reduction across the wave's subgroups
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+      float4 o;
+      o.x = __shfl_xor(acc.x, off, kWave);
+      o.y = __shfl_xor(acc.y, off, kWave);
+      o.z = __shfl_xor(acc.z, off, kWave);
+      o.w = __shfl_xor(acc.w, off, kWave);
+      acc = add4(acc, o);
+    }
+    if (q == 0) store_row<LPR, MUL_SELF>(out, X, r, row0, sl, acc);
+  } else {
+    const int sub = tid / LPR, sl = tid % LPR;
+    const int32_t nz_blocks = gridDim.x - fix_blocks;
+    for (int64_t v = (int64_t)(blockIdx.x - fix_blocks) * NSUB + sub; v < n_rows;
+         v += (int64_t)nz_blocks * NSUB) {
+      const int32_t row = row0 + (int32_t)v;
+      if (indptr[row] == indptr[row + 1])
+        out[(size_t)v * LPR + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// Row-per-subgroup kernel (optionally in a degree-sorted order).  Kept as the simple
+// reference formulation on the device and as an A/B arm for the merge kernel; long rows
+// serialise on one subgroup.
+template <int LPR, bool MUL_SELF, bool HAS_EID>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_rows_kernel(
+    int32_t n_rows, int32_t row0, const int32_t* __restrict__ indptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+    const int32_t* __restrict__ order, const float4* __restrict__ X, const float* __restrict__ w,
+    float4* __restrict__ out) {
+  constexpr int NSUB = SpmmGeom<LPR>::NSUB;
+  constexpr int U = SpmmGeom<LPR>::U;
+  const int tid = threadIdx.x;
+  const int sub = tid / LPR, sl = tid % LPR;
+  const int64_t g = (int64_t)blockIdx.x * NSUB + sub;
+  if (g >= n_rows) return;
+  const int32_t v = order ? order[g] : (int32_t)g;
+  const int32_t row = row0 + v;
+  const int32_t beg = indptr[row], end = indptr[row + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t base = beg; base < end; base += LPR) {
+    const int32_t my = base + sl;
+    const bool valid = my < end;
+    const int32_t c = valid ? col[my] : 0;
+    float wv = 0.f;
+    if (valid) wv = HAS_EID ? w[eid[my]] : w[my];
+    const int n = (end - base < LPR) ? (end - base) : LPR;
+    for (int j = 0; j < n; j += U) {
+      int32_t cj[U];
+      float wj[U];
+      float4 x[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        cj[i] = __shfl(c, j + i, LPR);
+        wj[i] = __shfl(wv, j + i, LPR);
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) x[i] = X[(size_t)cj[i] * LPR + sl];
+#pragma unroll
+      for (int i = 0; i < U; ++i)
+        if (j + i < n) acc = fma4(wj[i], x[i], acc);
+    }
+  }
+  store_row<LPR, MUL_SELF>(out, X, row, row0, sl, acc);
+}
+
+// Any feature width: one wavefront per row, lane j covers columns j, j+64, ...
+template <bool MUL_SELF, bool HAS_EID>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_rows_generic_kernel(
+    int32_t n_rows, int32_t row0, int D, const int32_t* __restrict__ indptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+    const float* __restrict__ X, const float* __restrict__ w, float* __restrict__ out) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int64_t v = (int64_t)blockIdx.x * (kSpmmThreads / kWave) + wave;
+  if (v >= n_rows) return;
+  const int32_t row = row0 + (int32_t)v;
+  const int32_t beg = indptr[row], end = indptr[row + 1];
+  for (int d0 = 0; d0 < D; d0 += kWave) {
+    const int d = d0 + lane;
+    float acc = 0.f;
+    if (d < D) {
+      for (int32_t p = beg; p < end; ++p) {
+        const float wv = HAS_EID ? w[eid[p]] : w[p];
+        acc = fmaf(wv, X[(size_t)col[p] * D + d], acc);
+      }
+      if (MUL_SELF) acc *= X[(size_t)row * D + d];
+      out[(size_t)v * D + d] = acc;
+    }
+  }
+}
+
+struct SpmmArgs {
+  int64_t n_rows, row0;
+  int D;
+  const int32_t *indptr, *col, *row_of, *eid, *order;
+  const float *X, *w;
+  float* out;
+  void* ws;
+  size_t ws_bytes;
+  unsigned flags;
+  int algo;
+  int32_t e0_host, e1_host;  // CSR position range of the row range
+  hipStream_t st;
+};
+
+constexpr int kRunLen = 64;  // C: edges per subgroup run in the merge kernel
+
+template <int LPR>
+static int64_t merge_tiles(int64_t n_edges) {
+  constexpr int TE = SpmmGeom<LPR>::NSUB * kRunLen;
+  return (n_edges + TE - 1) / TE;
+}
+
+template <int LPR, bool MUL_SELF, bool HAS_EID>
+static int launch_merge(const SpmmArgs& a) {
+  const int64_t e0 = a.e0_host, e1 = a.e1_host;
+  const int64_t tiles = merge_tiles<LPR>(e1 - e0);
+  const size_t need = (size_t)tiles * 2 * LPR * sizeof(float4);
+  if (tiles > 0 && (a.ws == nullptr || a.ws_bytes < need)) {
+    set_error("spmm: workspace too small (%zu < %zu)", a.ws_bytes, need);
+    return KGAT_E_WORKSPACE;
+  }
+  float4* bpart = static_cast<float4*>(a.ws);
+  if (tiles > 0) {
+    hipLaunchKernelGGL((spmm_merge_kernel<LPR, kRunLen, MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
+                       dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
+                       a.eid, (const float4*)a.X, a.w, (float4*)a.out, bpart);
+    KGAT_CHECK_LAUNCH("spmm_merge");
+  }
+  const int32_t fix_blocks = (int32_t)((tiles * 2 + 3) / 4);
+  int64_t nz_blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
+  if (nz_blocks > 2048) nz_blocks = 2048;
+  if (nz_blocks < 1) nz_blocks = 1;
+  hipLaunchKernelGGL((spmm_finish_kernel<LPR, kRunLen, MUL_SELF>),
+                     dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kSpmmThreads), 0, a.st, e0, e1,
+                     (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
+                     (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks);
+  KGAT_CHECK_LAUNCH("spmm_finish");
+  return KGAT_OK;
+}
+
+template <int LPR, bool MUL_SELF, bool HAS_EID>
+static int launch_rows(const SpmmArgs& a) {
+  const int64_t blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
+  hipLaunchKernelGGL((spmm_rows_kernel<LPR, MUL_SELF, HAS_EID>), dim3((unsigned)blocks),
+                     dim3(kSpmmThreads), 0, a.st, (int32_t)a.n_rows, (int32_t)a.row0, a.indptr,
+                     a.col, a.eid, a.order, (const float4*)a.X, a.w, (float4*)a.out);
+  KGAT_CHECK_LAUNCH("spmm_rows");
+  return KGAT_OK;
+}
+
+template <bool MUL_SELF, bool HAS_EID>
+static int launch_generic(const SpmmArgs& a) {
+  const int64_t blocks = (a.n_rows + 3) / 4;
+  hipLaunchKernelGGL((spmm_rows_generic_kernel<MUL_SELF, HAS_EID>), dim3((unsigned)blocks),
+                     dim3(kSpmmThreads), 0, a.st, (int32_t)a.n_rows, (int32_t)a.row0, a.D,
+                     a.indptr, a.col, a.eid, a.X, a.w, a.out);
+  KGAT_CHECK_LAUNCH("spmm_generic");
+  return KGAT_OK;
+}
+
+template <int LPR, bool MUL_SELF, bool HAS_EID>
+static int dispatch_algo(const SpmmArgs& a) {
+  if (a.algo == KGAT_SPMM_ALGO_ROWS) return launch_rows<LPR, MUL_SELF, HAS_EID>(a);
+  return launch_merge<LPR, MUL_SELF, HAS_EID>(a);
+}
+
+template <bool MUL_SELF, bool HAS_EID>
+static int dispatch_width(const SpmmArgs& a) {
+  if (a.algo == KGAT_SPMM_ALGO_GENERIC) return launch_generic<MUL_SELF, HAS_EID>(a);
+  switch (a.D) {
+    case 4: return dispatch_algo<1, MUL_SELF, HAS_EID>(a);
+    case 8: return dispatch_algo<2, MUL_SELF, HAS_EID>(a);
+    case 16: return dispatch_algo<4, MUL_SELF, HAS_EID>(a);
+    case 32: return dispatch_algo<8, MUL_SELF, HAS_EID>(a);
+    case 64: return dispatch_algo<16, MUL_SELF, HAS_EID>(a);
+    case 128: return dispatch_algo<32, MUL_SELF, HAS_EID>(a);
+    case 256: return dispatch_algo<64, MUL_SELF, HAS_EID>(a);
+    default: return launch_generic<MUL_SELF, HAS_EID>(a);
+  }
+}
+
+static int lpr_for(int D) {
+  switch (D) {
+    case 4: case 8: case 16: case 32: case 64: case 128: case 256: return D / 4;
+    default: return 0;
+  }
+}
+
+// SDDMM: grad_w[e] = <X[src e], G[dst e]>.  One subgroup of 16 lanes per edge.
+__global__ __launch_bounds__(256) void sddmm_dot_kernel(int64_t n_edges, int D,
+                                                        const int32_t* __restrict__ src,
+                                                        const int32_t* __restrict__ dst,
+                                                        const float* __restrict__ X,
+                                                        const float* __restrict__ G,
+                                                        float* __restrict__ out) {
+  constexpr int L = 16;
+  const int sub = threadIdx.x / L, sl = threadIdx.x % L;
+  const int64_t e = (int64_t)blockIdx.x * (256 / L) + sub;
+  if (e >= n_edges) return;
+  const float* x = X + (size_t)src[e] * D;
+  const float* g = G + (size_t)dst[e] * D;
+  float acc = 0.f;
+  for (int d = sl; d < D; d += L) acc = fmaf(x[d], g[d], acc);
+#pragma unroll
+  for (int off = L / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, L);
+  if (sl == 0) out[e] = acc;
+}
+
+}  // namespace kgat
+
+using namespace kgat;
+
+extern "C" {
+
+size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
+  const int lpr = lpr_for(D);
+  if (lpr == 0 || n_edges <= 0) return 256;
+  const int nsub = kSpmmThreads / lpr;
+  const int64_t te = (int64_t)nsub * kRunLen;
+  const int64_t tiles = (n_edges + te - 1) / te;
+  return align_up((size_t)tiles * 2 * lpr * sizeof(float4), 256) + 256;
+}
+
+int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64_t e_end, int D,
+                            const int32_t* indptr, const int32_t* col, const int32_t* row_of,
+                            const int32_t* eid, const float* X, const float* w, float* out,
+                            const int32_t* order, void* workspace, size_t workspace_bytes,
+                            unsigned flags, int algo, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && row0 >= 0 && D > 0, "spmm: bad size (n_rows=%lld row0=%lld D=%d)",
+                 (long long)n_rows, (long long)row0, D);
+  KGAT_CHECK_ARG(row0 + n_rows < INT32_MAX, "spmm: row range exceeds int32");
+  KGAT_CHECK_ARG(e_begin >= 0 && e_end >= e_begin && e_end < INT32_MAX, "spmm: bad edge range");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(indptr && X && out, "spmm: null pointer");
+  KGAT_CHECK_ARG(e_end == e_begin || (col && w), "spmm: null col/w");
+  KGAT_CHECK_ARG((flags & ~(unsigned)KGAT_SPMM_MUL_SELF) == 0, "spmm: unknown flags 0x%x", flags);
+  KGAT_CHECK_ARG(algo >= KGAT_SPMM_ALGO_AUTO && algo <= KGAT_SPMM_ALGO_GENERIC,
+                 "spmm: unknown algo %d", algo);
+  if (algo == KGAT_SPMM_ALGO_AUTO)
+    algo = (lpr_for(D) && row_of) ? KGAT_SPMM_ALGO_MERGE
+                                  : (lpr_for(D) ? KGAT_SPMM_ALGO_ROWS : KGAT_SPMM_ALGO_GENERIC);
+  if (lpr_for(D) == 0) algo = KGAT_SPMM_ALGO_GENERIC;
+  KGAT_CHECK_ARG(algo != KGAT_SPMM_ALGO_MERGE || row_of != nullptr,
+                 "spmm: merge algorithm needs row_of");
+  KGAT_CHECK_ARG(order == nullptr || algo == KGAT_SPMM_ALGO_ROWS,
+                 "spmm: a row order only applies to the rows algorithm");
+  SpmmArgs a;
+  a.n_rows = n_rows; a.row0 = row0; a.D = D;
+  a.indptr = indptr; a.col = col; a.row_of = row_of; a.eid = eid; a.order = order;
+  a.X = X; a.w = w; a.out = out; a.ws = workspace; a.ws_bytes = workspace_bytes;
+  a.flags = flags; a.algo = algo;
+  a.e0_host = (int32_t)e_begin; a.e1_host = (int32_t)e_end;
+  a.st = as_stream(stream);
+  const bool mul = flags & KGAT_SPMM_MUL_SELF;
+  if (mul) return eid ? dispatch_width<true, true>(a) : dispatch_width<true, false>(a);
+  return eid ? dispatch_width<false, true>(a) : dispatch_width<false, false>(a);
+}
+
+int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t* dst,
+                       const float* X, const float* grad_out, float* grad_w,
+                       kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0 && D > 0, "sddmm: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(src && dst && X && grad_out && grad_w, "sddmm: null pointer");
+  hipLaunchKernelGGL(sddmm_dot_kernel, dim3((unsigned)((n_edges + 15) / 16)), dim3(256), 0,
+                     as_stream(stream), n_edges, D, src, dst, X, grad_out, grad_w);
+  KGAT_CHECK_LAUNCH("sddmm_dot");
+  return KGAT_OK;
+}
+
+}  // extern "C"

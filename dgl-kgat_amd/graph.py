@@ -1,0 +1,420 @@
+"""DGLGraph operator surface for the KGAT propagation path, backed by the gfx950 kernels.
+
+Mirrors, with the same names, argument meaning and error behaviour, exactly the DGL 0.4.x
+calls the reference makes:
+
+* construction ``DGLGraph()``, ``add_nodes``, ``add_edges``, ``readonly``   (dataset.py:114-117)
+* frames ``g.ndata[k]`` / ``g.edata[k]`` get / set / ``pop``            (models.py:62,64,153; kgat.py:58,100-101,144)
+* ``g.local_var()``                                                     (models.py:61,148,157)
+* ``g.filter_edges(pred)`` / ``g.apply_edges(func, eids)`` + EdgeBatch  (models.py:140-143,150,152)
+* ``g.update_all(fn.u_mul_e(..), fn.sum(..))``                          (models.py:63)
+
+Structure (COO, destination-major CSR, relation grouping) is built on the device by
+``libkgat_hip.so`` the first time a kernel needs it and is shared by every ``local_var`` view.
+The sparse arithmetic has no CPU implementation: calling ``update_all`` / ``edge_softmax`` on
+CPU tensors raises.  On top of the surface the graph offers a fused fast path,
+``kgat_attention`` (one launch instead of the per-relation ``filter_edges``/``apply_edges``
+loop), which the generic surface does not require.
+"""
+from collections import namedtuple
+from collections.abc import MutableMapping
+
+import numpy as np
+import torch
+
+from . import ops
+from .function import BuiltinMessage, BuiltinReduce
+
+ALL = "__ALL__"
+
+
+class DGLError(Exception):
+    """Same role as dgl.DGLError: misuse of the graph API."""
+
+
+def _as_id_array(x, name):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    x = np.asarray(x)
+    if x.ndim == 0:
+        x = x.reshape(1)
+    if x.ndim != 1:
+        raise DGLError("%s must be a 1-D array of node ids" % name)
+    if x.size and not np.issubdtype(x.dtype, np.integer):
+        raise DGLError("%s must hold integers" % name)
+    return x.astype(np.int64, copy=False)
+
+
+class Frame(MutableMapping):
+    """Column store for node or edge features (``g.ndata`` / ``g.edata``)."""
+
+    def __init__(self, num_rows_fn, what, cols=None):
+        self._n = num_rows_fn
+        self._what = what
+        self._cols = dict(cols) if cols else {}
+
+    def __getitem__(self, key):
+        return self._cols[key]
+
+    def __setitem__(self, key, val):
+        if not isinstance(val, torch.Tensor):
+            raise DGLError("feature data must be a tensor")
+        if val.dim() == 0 or val.shape[0] != self._n():
+            raise DGLError("Expect number of features to match number of %s (len(%s)). Got %d and %d "
+                           "instead." % (self._what, self._what,
+                                         val.shape[0] if val.dim() else 0, self._n()))
+        self._cols[key] = val
+
+    def __delitem__(self, key):
+        del self._cols[key]
+
+    def __iter__(self):
+        return iter(self._cols)
+
+    def __len__(self):
+        return len(self._cols)
+
+    def clone(self):
+        return Frame(self._n, self._what, self._cols)
+
+
+CSR = namedtuple("CSR", "indptr col eid row_of")
+RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g")
+
+
+class _Structure:
+    """Edge list + per-device derived structure, shared by a graph and its local_var views."""
+
+    def __init__(self):
+        self.n_nodes = 0
+        self._src = np.zeros(0, np.int64)
+        self._dst = np.zeros(0, np.int64)
+        self.readonly = False
+        self._dev = {}
+
+    # ---- mutation
+    def add_nodes(self, num):
+        if self.readonly:
+            raise DGLError("readonly graph. Mutation is not allowed.")
+        self.n_nodes += int(num)
+        self._dev.clear()
+
+    def add_edges(self, u, v):
+        if self.readonly:
+            raise DGLError("readonly graph. Mutation is not allowed.")
+        u, v = _as_id_array(u, "u"), _as_id_array(v, "v")
+        if len(u) != len(v):
+            if len(u) == 1:
+                u = np.repeat(u, len(v))
+            elif len(v) == 1:
+                v = np.repeat(v, len(u))
+            else:
+                raise DGLError("Expect number of source and destination ids to match")
+        if len(u) and (u.min() < 0 or v.min() < 0 or u.max() >= self.n_nodes or v.max() >= self.n_nodes):
+            raise DGLError("Node id out of range (number of nodes: %d)" % self.n_nodes)
+        self._src = np.concatenate([self._src, u])
+        self._dst = np.concatenate([self._dst, v])
+        self._dev.clear()
+
+    @property
+    def n_edges(self):
+        return len(self._src)
+
+    # ---- per-device caches
+    def _cache(self, device):
+        device = torch.device(device)
+        c = self._dev.get(device)
+        if c is None:
+            c = self._dev[device] = {}
+        return c
+
+    def coo(self, device, dtype=torch.int32):
+        c = self._cache(device)
+        key = ("coo", dtype)
+        if key not in c:
+            c[key] = (torch.as_tensor(self._src, dtype=dtype).to(device),
+                      torch.as_tensor(self._dst, dtype=dtype).to(device))
+        return c[key]
+
+    def csr(self, device):
+        """Destination-major CSR (kgat_csr_from_coo)."""
+        c = self._cache(device)
+        if "csr" not in c:
+            src, dst = self.coo(device)
+            c["csr"] = CSR(*ops.csr_from_coo(self.n_nodes, src, dst))
+        return c["csr"]
+
+    def csr_pos(self, device):
+        """CSR position of every edge id (inverse of csr.eid)."""
+        c = self._cache(device)
+        if "csr_pos" not in c:
+            c["csr_pos"] = ops.invert_permutation(self.csr(device).eid)
+        return c["csr_pos"]
+
+    def csr_rev(self, device):
+        """CSR of the reversed graph (rows = sources): used by the SpMM backward (S1b)."""
+        c = self._cache(device)
+        if "csr_rev" not in c:
+            src, dst = self.coo(device)
+            c["csr_rev"] = CSR(*ops.csr_from_coo(self.n_nodes, dst, src))
+        return c["csr_rev"]
+
+    def row_order(self, device):
+        c = self._cache(device)
+        if "order" not in c:
+            c["order"] = ops.row_order_by_degree(self.csr(device).indptr)
+        return c["order"]
+
+    def rel_groups(self, etype, n_rel):
+        """Edges grouped by relation (kgat_group_by_relation) + grouped endpoint arrays."""
+        c = self._cache(etype.device)
+        key = ("rel", etype.data_ptr(), etype._version, int(n_rel))
+        hit = c.get("rel_groups")
+        if hit is None or hit[0] != key:
+            et32 = etype if etype.dtype == torch.int32 else etype.to(torch.int32)
+            rel_ptr, perm = ops.group_by_relation(et32.contiguous(), int(n_rel))
+            src, dst = self.coo(etype.device)
+            hit = (key, RelGroups(rel_ptr, perm, ops.gather(perm, src), ops.gather(perm, dst)), etype)
+            c["rel_groups"] = hit
+        return hit[1]
+
+    def weight_in_csr_order(self, w_flat):
+        """Per-edge weights permuted to CSR order once per distinct weight tensor; the SpMM
+        then streams them coalesced (kgat.py:144 sets 'w' once per epoch, models.py:63 uses
+        it in every layer of every batch)."""
+        c = self._cache(w_flat.device)
+        key = (w_flat.data_ptr(), w_flat._version, w_flat.numel())
+        hit = c.get("w_csr")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.gather(self.csr(w_flat.device).eid, w_flat), w_flat)
+            c["w_csr"] = hit
+        return hit[1]
+
+    def remember_weight(self, w_flat, w_csr):
+        self._cache(w_flat.device)["w_csr"] = ((w_flat.data_ptr(), w_flat._version, w_flat.numel()),
+                                               w_csr, w_flat)
+
+
+class EdgeBatch:
+    """What a UDF passed to filter_edges / apply_edges sees: lazily gathered src / dst /
+    edge features of the selected edges (reference models.py:140-143)."""
+
+    class _Lazy(MutableMapping):
+        def __init__(self, frame, index):
+            self._frame, self._index, self._got = frame, index, {}
+
+        def __getitem__(self, key):
+            if key not in self._got:
+                col = self._frame[key]
+                idx = self._index(col.device)
+                self._got[key] = col if idx is None else col.index_select(0, idx)
+            return self._got[key]
+
+        def __setitem__(self, key, val):
+            self._got[key] = val
+
+        def __delitem__(self, key):
+            del self._got[key]
+
+        def __iter__(self):
+            return iter(self._frame)
+
+        def __len__(self):
+            return len(self._frame)
+
+    def __init__(self, g, eids):
+        self._g, self._eids = g, eids
+        st = g._st
+
+        def edge_index(device):
+            return None if eids is None else eids.to(device)
+
+        def end_index(which):
+            def fn(device):
+                ends = st.coo(device, torch.int64)[which]
+                return ends if eids is None else ends.index_select(0, eids.to(device))
+            return fn
+
+        self.src = EdgeBatch._Lazy(g._node_frame, end_index(0))
+        self.dst = EdgeBatch._Lazy(g._node_frame, end_index(1))
+        self.data = EdgeBatch._Lazy(g._edge_frame, edge_index)
+
+    def batch_size(self):
+        return self._g.number_of_edges() if self._eids is None else len(self._eids)
+
+    def __len__(self):
+        return self.batch_size()
+
+
+class DGLGraph:
+    def __init__(self, _structure=None, _nframe=None, _eframe=None):
+        self._st = _structure if _structure is not None else _Structure()
+        self._node_frame = _nframe if _nframe is not None else Frame(self.number_of_nodes, "nodes")
+        self._edge_frame = _eframe if _eframe is not None else Frame(self.number_of_edges, "edges")
+        self.partition = None  # set by partition.shard_graph for multi-GPU runs
+
+    # ---- construction (reference dataset.py:114-117)
+    def add_nodes(self, num, data=None):
+        if len(self._node_frame):
+            raise DGLError("adding nodes after node features were set is not supported")
+        self._st.add_nodes(num)
+        if data:
+            for k, v in data.items():
+                self.ndata[k] = v
+
+    def add_edges(self, u, v, data=None):
+        if len(self._edge_frame):
+            raise DGLError("adding edges after edge features were set is not supported")
+        self._st.add_edges(u, v)
+        if data:
+            for k, val in data.items():
+                self.edata[k] = val
+
+    def readonly(self, readonly_state=True):
+        self._st.readonly = bool(readonly_state)
+        return self
+
+    # ---- queries
+    def number_of_nodes(self):
+        return self._st.n_nodes
+
+    def number_of_edges(self):
+        return self._st.n_edges
+
+    def __len__(self):
+        return self.number_of_nodes()
+
+    @property
+    def is_readonly(self):
+        return self._st.readonly
+
+    def edges(self, form="uv"):
+        src = torch.as_tensor(self._st._src)
+        dst = torch.as_tensor(self._st._dst)
+        eid = torch.arange(len(src))
+        return {"uv": (src, dst), "eid": eid, "all": (src, dst, eid)}[form]
+
+    all_edges = edges
+
+    def in_degrees(self):
+        return torch.as_tensor(np.bincount(self._st._dst, minlength=self._st.n_nodes))
+
+    def out_degrees(self):
+        return torch.as_tensor(np.bincount(self._st._src, minlength=self._st.n_nodes))
+
+    # ---- frames
+    @property
+    def ndata(self):
+        return self._node_frame
+
+    @property
+    def edata(self):
+        return self._edge_frame
+
+    def local_var(self):
+        """A view whose feature writes do not leak to this graph (models.py:61,148,157)."""
+        g = DGLGraph(self._st, self._node_frame.clone(), self._edge_frame.clone())
+        g.partition = self.partition
+        return g
+
+    class _LocalScope:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            g = self.g
+            self.saved = (g._node_frame, g._edge_frame)
+            g._node_frame, g._edge_frame = g._node_frame.clone(), g._edge_frame.clone()
+            return g
+
+        def __exit__(self, *exc):
+            self.g._node_frame, self.g._edge_frame = self.saved
+            return False
+
+    def local_scope(self):
+        return DGLGraph._LocalScope(self)
+
+    # ---- UDF plumbing
+    def _edge_ids(self, edges):
+        if isinstance(edges, str) and edges == ALL:
+            return None
+        if isinstance(edges, torch.Tensor):
+            eids = edges.to(torch.int64).reshape(-1)
+        else:
+            eids = torch.as_tensor(np.asarray(edges, dtype=np.int64)).reshape(-1)
+        return eids
+
+    def filter_edges(self, predicate, edges=ALL):
+        """Ids (int64) of the edges for which ``predicate(EdgeBatch)`` is true (models.py:150)."""
+        eids = self._edge_ids(edges)
+        mask = predicate(EdgeBatch(self, eids))
+        if mask.dtype != torch.bool:
+            mask = mask != 0
+        hit = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1)
+        return hit if eids is None else eids.to(hit.device).index_select(0, hit)
+
+    def apply_edges(self, func, edges=ALL):
+        """Run a UDF on an edge batch and write its outputs into ``edata`` (models.py:152).  A
+        column that does not exist yet is zero-initialised before a partial write."""
+        if isinstance(func, BuiltinMessage):
+            raise NotImplementedError("apply_edges with a builtin is outside the KGAT path")
+        eids = self._edge_ids(edges)
+        out = func(EdgeBatch(self, eids))
+        if not isinstance(out, dict):
+            raise DGLError("edge UDF must return a dict of tensors")
+        n_sel = self.number_of_edges() if eids is None else len(eids)
+        for key, val in out.items():
+            if val.shape[0] != n_sel:
+                raise DGLError("Expect number of features to match number of edges in the batch")
+            if eids is None:
+                self._edge_frame[key] = val
+                continue
+            if key in self._edge_frame:
+                col = self._edge_frame[key].clone()
+            else:
+                col = torch.zeros((self.number_of_edges(),) + tuple(val.shape[1:]), dtype=val.dtype,
+                                  device=val.device)
+            col.index_copy_(0, eids.to(val.device), val)
+            self._edge_frame[key] = col
+
+    # ---- the aggregation (models.py:63)
+    def update_all(self, message_func, reduce_func, apply_node_func=None):
+        if not (isinstance(message_func, BuiltinMessage) and isinstance(reduce_func, BuiltinReduce)):
+            raise NotImplementedError("only builtin message/reduce pairs run on the HIP kernels; "
+                                      "python UDF message passing is outside the KGAT path")
+        if message_func.name != "u_mul_e" or reduce_func.name != "sum":
+            raise NotImplementedError("the KGAT path uses update_all(fn.u_mul_e, fn.sum); got %s/%s"
+                                      % (message_func.name, reduce_func.name))
+        if message_func.out_field != reduce_func.msg_field:
+            raise DGLError("reduce reads message field %r but the message function writes %r"
+                           % (reduce_func.msg_field, message_func.out_field))
+        if message_func.src_field not in self._node_frame:
+            raise KeyError(message_func.src_field)
+        if message_func.edge_field not in self._edge_frame:
+            raise KeyError(message_func.edge_field)
+        from .autograd import u_mul_e_sum
+        x = self._node_frame[message_func.src_field]
+        w = self._edge_frame[message_func.edge_field]
+        self._node_frame[reduce_func.out_field] = u_mul_e_sum(self, x, w)
+        if apply_node_func is not None:
+            raise NotImplementedError("apply_node_func is outside the KGAT path")
+
+    # ---- fused fast path (not part of the DGL surface)
+    def kgat_attention(self, ent, W_R, rel, etype=None, algo="auto"):
+        """compute_attention (models.py:146-154) in two launches: relation-grouped attention
+        logits + destination softmax.  Returns (E,1) weights in edge-id order and remembers
+        their CSR-ordered copy so that a following ``edata['w'] = result`` +
+        ``update_all`` streams them without a permutation pass."""
+        if etype is None:
+            etype = self._edge_frame["type"]
+        st = self._st
+        dev = ent.device
+        csr = st.csr(dev)
+        groups = st.rel_groups(etype.to(dev), W_R.shape[0])
+        _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
+                                      ent.detach().contiguous(), W_R.detach().contiguous(),
+                                      rel.detach().contiguous(), csr_pos=st.csr_pos(dev), algo=algo)
+        a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
+                                    want_out=True, want_csr=True)
+        st.remember_weight(a, a_csr)
+        return a.unsqueeze(1)

@@ -1,0 +1,115 @@
+"""KGAT's attentive embedding-propagation layer on the DGLGraph surface of this package.
+
+A from-scratch restatement of the reference's model glue for the hot path (SURVEY.md 8a rows
+A1, B1, B2): ``KGATConv`` follows reference models.py:49-70, ``KGATPropagation.compute_attention``
+models.py:146-154 and ``KGATPropagation.gnn`` models.py:156-168.  Parameter names and shapes
+match the reference's ``Model`` (``entity_embed.weight`` (N,d), ``relation_embed.weight`` (R,k),
+``W_R`` (R,d,k), ``layers.i.res_fc_2.weight`` (D_out,D_in)) so its state_dict loads unchanged.
+
+Two ways through every step:
+* the *surface* way - the very call sequence of the reference (``filter_edges`` /
+  ``apply_edges`` per relation, ``edge_softmax``, ``update_all``), exercising the drop-in
+  boundary; and
+* the *fused* way - ``g.kgat_attention`` (one attention launch over relation-grouped edges)
+  and the SpMM with the ``h * h_N`` product in its epilogue.  Same results, fewer passes.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import function as fn
+from .autograd import edge_softmax, u_mul_e_sum
+
+
+class KGATConv(nn.Module):
+    """Bi-interaction propagation layer: LeakyReLU_{0.01}(W2 (h * h_N)), dropout
+    (reference models.py:49-70; only the ``Bi`` branch with ``res_fc_2`` exists there)."""
+
+    def __init__(self, entity_in_feats, out_feats, dropout, res_type="Bi"):
+        super().__init__()
+        if res_type != "Bi":
+            raise NotImplementedError(res_type)
+        self.mess_drop = nn.Dropout(dropout)
+        self._res_type = res_type
+        self.res_fc_2 = nn.Linear(entity_in_feats, out_feats, bias=False)
+
+    def forward(self, g, nfeat, fused=None):
+        part = g.partition
+        if fused is None:
+            fused = not (torch.is_grad_enabled() and nfeat.requires_grad)
+        if part is not None:
+            out = part.propagate(g, nfeat, self.res_fc_2.weight)
+        elif fused:
+            # h * h_N formed in the SpMM epilogue (models.py:63 + the th.mul of :66)
+            prod = u_mul_e_sum(g, nfeat, g.edata["w"], mul_self=True)
+            out = F.leaky_relu(self.res_fc_2(prod))
+        else:
+            g = g.local_var()
+            g.ndata["h"] = nfeat
+            g.update_all(fn.u_mul_e("h", "w", "m"), fn.sum("m", "h_neighbor"))
+            h_neighbor = g.ndata["h_neighbor"]
+            out = F.leaky_relu(self.res_fc_2(torch.mul(g.ndata["h"], h_neighbor)))
+        return self.mess_drop(out)
+
+
+class KGATPropagation(nn.Module):
+    """The hot-path part of the reference's ``Model`` (models.py:72-111,135-168): embeddings,
+    W_R, the KGATConv stack, ``compute_attention`` and ``gnn``.  The TransR / BPR losses of the
+    reference (models.py:114-133,170-178) are outside this path; ``get_loss`` is kept because the
+    training-step test needs a scalar to differentiate."""
+
+    def __init__(self, n_entities, n_relations, input_node_dim=64, relation_dim=64, num_gnn_layers=3,
+                 n_hidden=64, dropout=0.1, reg_lambda_gnn=0.01):
+        super().__init__()
+        self._n_entities, self._n_relations = n_entities, n_relations
+        self._reg_lambda_gnn = reg_lambda_gnn
+        self.entity_embed = nn.Embedding(n_entities, input_node_dim)
+        self.relation_embed = nn.Embedding(n_relations, relation_dim)
+        self.W_R = nn.Parameter(torch.empty(n_relations, input_node_dim, relation_dim))
+        nn.init.xavier_uniform_(self.W_R, gain=nn.init.calculate_gain("relu"))
+        self.layers = nn.ModuleList()
+        for i in range(num_gnn_layers):  # widths: models.py:91-111
+            d_in = input_node_dim if i == 0 else n_hidden // int(math.pow(2, i - 1))
+            self.layers.append(KGATConv(d_in, n_hidden // int(math.pow(2, i)), dropout))
+
+    # -- attention (models.py:135-154)
+    def _att_score(self, edges):
+        t_r = torch.matmul(self.entity_embed(edges.src["id"]), self.W_r)
+        h_r = torch.matmul(self.entity_embed(edges.dst["id"]), self.W_r)
+        att_w = torch.bmm(t_r.unsqueeze(1),
+                          torch.tanh(h_r + self.relation_embed(edges.data["type"])).unsqueeze(2)).squeeze(-1)
+        return {"att_w": att_w}
+
+    def compute_attention_surface(self, g):
+        """The reference's own call sequence over the drop-in surface."""
+        g = g.local_var()
+        for i in range(self._n_relations):
+            e_idxs = g.filter_edges(lambda edges: edges.data["type"] == i)
+            self.W_r = self.W_R[i]
+            g.apply_edges(self._att_score, e_idxs)
+        return edge_softmax(g, g.edata.pop("att_w"))
+
+    def compute_attention(self, g, algo="auto"):
+        """Fused: one attention-logit launch over relation-grouped edges + destination softmax."""
+        return g.kgat_attention(self.entity_embed.weight, self.W_R, self.relation_embed.weight, algo=algo)
+
+    # -- propagation (models.py:156-168)
+    def gnn(self, g, x=None, fused=None):
+        g = g.local_var()
+        h = self.entity_embed(g.ndata["id"])
+        node_embed_cache = [h]
+        for layer in self.layers:
+            h = layer(g, h, fused=fused)
+            node_embed_cache.append(F.normalize(h, p=2, dim=1))
+        return torch.cat(node_embed_cache, 1)
+
+    def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids):
+        """BPR loss of reference models.py:170-178 (harness only)."""
+        s, p, n = embedding[src_ids], embedding[pos_dst_ids], embedding[neg_dst_ids]
+        pos = (s * p).sum(1)
+        neg = (s * n).sum(1)
+        cf = -F.logsigmoid(pos - neg).mean()
+        reg = sum((v.pow(2).sum(1) / 2.0).mean() for v in (s, p, n))
+        return cf + self._reg_lambda_gnn * reg

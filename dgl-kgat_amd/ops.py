@@ -1,0 +1,265 @@
+"""Tensor-level wrappers around the C ABI (include/kgat_hip.h).
+
+torch is used here for what it is good at on ROCm - device memory, the current HIP stream -
+and nothing else: every arithmetic step of the path happens inside libkgat_hip.so.  All
+functions validate device / dtype / contiguity before the call and turn a non-zero return
+code into KGATLibraryError.  CPU tensors are rejected: this path has no CPU implementation.
+"""
+import torch
+
+from . import _lib
+from ._lib import KGATLibraryError, check
+
+SPMM_MUL_SELF = 1
+SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3}
+ATT_ALGO = {"auto": 0, "mfma": 1, "generic": 2}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class KernelTimer:
+    """Optional per-op HIP-event timing (bench.py): while active, every wrapped C-ABI op
+    records an event pair on the stream it launches on.  Costs nothing when inactive."""
+    active = None
+
+    def __init__(self):
+        self.records = []  # (name, info, start_event, end_event)
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def summary(self):
+        """name -> list of (info, milliseconds); call after a device synchronize."""
+        out = {}
+        for name, info, a, b in self.records:
+            out.setdefault(name, []).append((info, a.elapsed_time(b)))
+        return out
+
+
+class _timed:
+    def __init__(self, name, info=None):
+        self.t = KernelTimer.active
+        self.name, self.info = name, info
+
+    def __enter__(self):
+        if self.t is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.b.record()
+            self.t.records.append((self.name, self.info, self.a, self.b))
+        return False
+
+
+def _need(t, dtype, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise KGATLibraryError("%s is on %s: the KGAT propagation path only runs on a HIP device "
+                               "(no CPU implementation exists in this package)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def csr_from_coo(n_nodes, src, dst):
+    """(indptr, col, eid, row_of) of the destination-major CSR; stable in edge id."""
+    src = _need(src, torch.int32, "src")
+    dst = _need(dst, torch.int32, "dst", src.shape)
+    lib = _lib.load()
+    e, dev = src.numel(), src.device
+    indptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(e, dtype=torch.int32, device=dev)
+    eid = torch.empty(e, dtype=torch.int32, device=dev)
+    row_of = torch.empty(e, dtype=torch.int32, device=dev)
+    nb = lib.kgat_csr_from_coo_workspace_bytes(n_nodes, e)
+    ws = _workspace(nb, dev)
+    check(lib.kgat_csr_from_coo(n_nodes, e, _ptr(src), _ptr(dst), _ptr(indptr), _ptr(col), _ptr(eid),
+                                _ptr(row_of), _ptr(ws), ws.numel(), _stream(src)), "kgat_csr_from_coo")
+    return indptr, col, eid, row_of
+
+
+def group_by_relation(etype, n_rel):
+    etype = _need(etype, torch.int32, "etype")
+    lib = _lib.load()
+    e, dev = etype.numel(), etype.device
+    rel_ptr = torch.empty(n_rel + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.kgat_group_by_relation_workspace_bytes(e, n_rel), dev)
+    check(lib.kgat_group_by_relation(e, n_rel, _ptr(etype), _ptr(rel_ptr), _ptr(perm), _ptr(ws),
+                                     ws.numel(), _stream(etype)), "kgat_group_by_relation")
+    return rel_ptr, perm
+
+
+def invert_permutation(perm):
+    perm = _need(perm, torch.int32, "perm")
+    inv = torch.empty_like(perm)
+    check(_lib.load().kgat_invert_permutation(perm.numel(), _ptr(perm), _ptr(inv), _stream(perm)),
+          "kgat_invert_permutation")
+    return inv
+
+
+def row_order_by_degree(indptr):
+    indptr = _need(indptr, torch.int32, "indptr")
+    lib = _lib.load()
+    n = indptr.numel() - 1
+    order = torch.empty(n, dtype=torch.int32, device=indptr.device)
+    ws = _workspace(lib.kgat_row_order_workspace_bytes(n), indptr.device)
+    check(lib.kgat_row_order_by_degree(n, _ptr(indptr), _ptr(order), _ptr(ws), ws.numel(),
+                                       _stream(indptr)), "kgat_row_order_by_degree")
+    return order
+
+
+def gather(index, values):
+    index = _need(index, torch.int32, "index")
+    if values.dtype == torch.float32:
+        values = _need(values, torch.float32, "values")
+        out = torch.empty(index.numel(), dtype=torch.float32, device=index.device)
+        check(_lib.load().kgat_gather_f32(index.numel(), _ptr(index), _ptr(values), _ptr(out),
+                                          _stream(index)), "kgat_gather_f32")
+    else:
+        values = _need(values, torch.int32, "values")
+        out = torch.empty(index.numel(), dtype=torch.int32, device=index.device)
+        check(_lib.load().kgat_gather_i32(index.numel(), _ptr(index), _ptr(values), _ptr(out),
+                                          _stream(index)), "kgat_gather_i32")
+    return out
+
+
+def att_score(n_nodes, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, csr_pos=None, algo="auto"):
+    """Attention logits (E,) in edge-id order; with csr_pos also in CSR order."""
+    ent = _need(ent, torch.float32, "ent")
+    n_rel, d, k = W_R.shape
+    W_R = _need(W_R, torch.float32, "W_R")
+    rel = _need(rel, torch.float32, "rel", (n_rel, k))
+    if ent.shape != (n_nodes, d):
+        raise ValueError("ent has shape %s, expected %s" % (tuple(ent.shape), (n_nodes, d)))
+    perm = _need(perm, torch.int32, "perm")
+    e = perm.numel()
+    rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
+    src_g = _need(src_g, torch.int32, "src_g", (e,))
+    dst_g = _need(dst_g, torch.int32, "dst_g", (e,))
+    logits = torch.empty(e, dtype=torch.float32, device=ent.device)
+    logits_csr = None
+    if csr_pos is not None:
+        csr_pos = _need(csr_pos, torch.int32, "csr_pos", (e,))
+        logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device)
+    with _timed("att_score", (e, d, k)):
+        check(_lib.load().kgat_att_score_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
+                                             _ptr(dst_g), _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits),
+                                             _ptr(logits_csr), _ptr(csr_pos), ATT_ALGO[algo], _stream(ent)),
+              "kgat_att_score_f32")
+    return logits, logits_csr
+
+
+def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
+                 want_csr=False):
+    """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
+    CSR order with in_csr_order=True.  Returns (out in edge-id order, out_csr in CSR order);
+    unrequested ones are None."""
+    logits = _need(logits, torch.float32, "logits")
+    row_of = _need(row_of, torch.int32, "row_of", logits.shape)
+    eid = _need(eid, torch.int32, "eid", logits.shape)
+    lib = _lib.load()
+    e0, e1 = (0, logits.numel()) if e_range is None else e_range
+    out = torch.empty_like(logits) if want_out else None
+    out_csr = torch.empty_like(logits) if want_csr else None
+    ws = _workspace(lib.kgat_edge_softmax_workspace_bytes(n_nodes), logits.device)
+    with _timed("edge_softmax", (e1 - e0,)):
+        check(lib.kgat_edge_softmax_f32(n_nodes, e0, e1, _ptr(row_of), _ptr(eid), _ptr(logits),
+                                        1 if in_csr_order else 0, _ptr(out), _ptr(out_csr), _ptr(ws),
+                                        ws.numel(), _stream(logits)), "kgat_edge_softmax_f32")
+    return out, out_csr
+
+
+def edge_softmax_bwd(indptr, eid, a, grad_a, row_range=None):
+    a = _need(a, torch.float32, "a")
+    grad_a = _need(grad_a, torch.float32, "grad_a", a.shape)
+    indptr = _need(indptr, torch.int32, "indptr")
+    if eid is not None:
+        eid = _need(eid, torch.int32, "eid", a.shape)
+    row0, n_rows = (0, indptr.numel() - 1) if row_range is None else row_range
+    out = torch.zeros_like(a)
+    check(_lib.load().kgat_edge_softmax_bwd_f32(n_rows, row0, _ptr(indptr), _ptr(eid), _ptr(a),
+                                                _ptr(grad_a), _ptr(out), _stream(a)),
+          "kgat_edge_softmax_bwd_f32")
+    return out
+
+
+def spmm_workspace(n_edges, D, device):
+    return _workspace(_lib.load().kgat_spmm_workspace_bytes(n_edges, D), device)
+
+
+def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=False, algo="auto",
+         rows=None, e_range=None, workspace=None):
+    """out[v - row0] = sum_p w_p X[col[p]] over the CSR rows `rows` = (row0, n_rows) whose CSR
+    positions are `e_range` (defaults: the whole graph).  w is in CSR order, or in edge-id
+    order when `eid` is given."""
+    X = _need(X, torch.float32, "X")
+    if X.dim() != 2:
+        raise ValueError("X must be (N, D)")
+    D = X.shape[1]
+    indptr = _need(indptr, torch.int32, "indptr")
+    col = _need(col, torch.int32, "col")
+    w = _need(w, torch.float32, "w", col.shape)
+    if row_of is not None:
+        row_of = _need(row_of, torch.int32, "row_of", col.shape)
+    if eid is not None:
+        eid = _need(eid, torch.int32, "eid", col.shape)
+    if order is not None:
+        order = _need(order, torch.int32, "order")
+    row0, n_rows = (0, indptr.numel() - 1) if rows is None else rows
+    e0, e1 = (0, col.numel()) if e_range is None else e_range
+    if out is None:
+        out = torch.empty((n_rows, D), dtype=torch.float32, device=X.device)
+    else:
+        out = _need(out, torch.float32, "out", (n_rows, D))
+    if workspace is None:
+        workspace = spmm_workspace(e1 - e0, D, X.device)
+    with _timed("spmm", (e1 - e0, n_rows, D)):
+        check(_lib.load().kgat_spmm_umule_sum_f32(n_rows, row0, e0, e1, D, _ptr(indptr), _ptr(col), _ptr(row_of),
+                                                  _ptr(eid), _ptr(X), _ptr(w), _ptr(out), _ptr(order),
+                                                  _ptr(workspace), workspace.numel(),
+                                                  SPMM_MUL_SELF if mul_self else 0, SPMM_ALGO[algo], _stream(X)),
+              "kgat_spmm_umule_sum_f32")
+    return out
+
+
+def sddmm_dot(src, dst, X, G):
+    X = _need(X, torch.float32, "X")
+    G = _need(G, torch.float32, "grad_out")
+    src = _need(src, torch.int32, "src")
+    dst = _need(dst, torch.int32, "dst", src.shape)
+    if X.shape[1] != G.shape[1]:
+        raise ValueError("feature widths differ")
+    out = torch.empty(src.numel(), dtype=torch.float32, device=X.device)
+    check(_lib.load().kgat_sddmm_dot_f32(src.numel(), X.shape[1], _ptr(src), _ptr(dst), _ptr(X), _ptr(G),
+                                         _ptr(out), _stream(X)), "kgat_sddmm_dot_f32")
+    return out
+
+
+__all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
+           "att_score", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "KGATLibraryError"]

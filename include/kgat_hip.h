@@ -1,0 +1,167 @@
+/* kgat_hip.h - C ABI of libkgat_hip.so: KGAT's attentive embedding-propagation path on
+ * MI355X (gfx950).  This is the drop-in boundary: every entry point below
+ * replaces one DGL 0.4.x kernel family that the reference reaches from models.py, and is
+ * exactly what a binding for that call site would bind (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every pointer is a DEVICE pointer (hipMalloc'd or
+ *    torch-allocated) unless the parameter name ends in `_host`.  Buffers are borrowed for
+ *    the duration of the call; the library allocates nothing persistent and frees nothing
+ *    it did not allocate.  Scratch memory is passed in by the caller (`*_workspace_bytes`).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *    enqueued asynchronously on it; no entry point synchronises the host.
+ *  - Return value: 0 on success, negative KGAT_E_* on failure; the message is available
+ *    from kgat_last_error() (thread-local).  Nothing throws or aborts across the ABI.
+ *  - Indices are int32 (E, N < 2^31); byte offsets are formed in 64 bit.  Feature matrices
+ *    are row-major contiguous fp32.  Per-edge arrays are in EDGE-ID order (the order edges
+ *    were added, reference dataset.py:116) unless the name says `_csr` (destination-major
+ *    CSR position order) - outputs are always fully overwritten.
+ *  - Edge direction (reference dataset.py:116, add_edges(t, h)): src = tail t, dst = head h.
+ */
+#ifndef KGAT_HIP_H_
+#define KGAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGAT_ABI_VERSION 1
+
+enum {
+  KGAT_OK = 0,
+  KGAT_E_BADARG = -1,      /* null pointer, negative size, inconsistent sizes */
+  KGAT_E_UNSUPPORTED = -2, /* e.g. feature width the kernels do not cover */
+  KGAT_E_WORKSPACE = -3,   /* workspace too small */
+  KGAT_E_HIP = -4          /* a HIP runtime call or launch failed */
+};
+
+/* flags for kgat_spmm_umule_sum_f32 */
+enum {
+  KGAT_SPMM_MUL_SELF = 1 /* out[v,:] *= X[row0+v,:]  (the h * h_neighbor of models.py:66) */
+};
+
+/* algorithm selectors (AUTO picks the tuned kernel; the others exist for A/B and tests) */
+enum {
+  KGAT_SPMM_ALGO_AUTO = 0,
+  KGAT_SPMM_ALGO_MERGE = 1,  /* edge-balanced tiles over the destination-sorted edge array */
+  KGAT_SPMM_ALGO_ROWS = 2,   /* one lane group per destination row (optionally degree ordered) */
+  KGAT_SPMM_ALGO_GENERIC = 3 /* any feature width, one wavefront per row */
+};
+enum {
+  KGAT_ATT_ALGO_AUTO = 0,
+  KGAT_ATT_ALGO_MFMA = 1,   /* v_mfma_f32_16x16x4_f32; d == k in {16,32,64,128} */
+  KGAT_ATT_ALGO_GENERIC = 2 /* VALU, any (d,k) with d*k*4 <= 64 KiB */
+};
+
+typedef void* kgat_stream_t; /* hipStream_t */
+
+int kgat_version(void);
+const char* kgat_last_error(void);
+
+/* ---------------------------------------------------------------- graph structure (G0)
+ * Replaces DGL's COO -> in-CSR conversion that runs on the first kernel call on a graph
+ * built by reference dataset.py:112-120.  Stable: within a destination row, edge ids
+ * ascend.  indptr[N+1], col[E] (source ids), eid[E] (original edge id per CSR position),
+ * row_of[E] (destination id per CSR position; may be NULL).
+ * Ids outside [0,N) are a caller error (checked by the host wrapper, not on device). */
+size_t kgat_csr_from_coo_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int kgat_csr_from_coo(int64_t n_nodes, int64_t n_edges, const int32_t* src, const int32_t* dst,
+                      int32_t* indptr, int32_t* col, int32_t* eid, int32_t* row_of,
+                      void* workspace, size_t workspace_bytes, kgat_stream_t stream);
+
+/* Replaces the R full-graph g.filter_edges(lambda e: e.data['type'] == i) sweeps of
+ * reference models.py:149-150 by one stable grouping: perm[rel_ptr[r] .. rel_ptr[r+1]) are
+ * the edge ids of relation r, ascending.  Types outside [0,R) are placed after rel_ptr[R]
+ * (the reference loop never visits them). */
+size_t kgat_group_by_relation_workspace_bytes(int64_t n_edges, int n_rel);
+int kgat_group_by_relation(int64_t n_edges, int n_rel, const int32_t* etype, int32_t* rel_ptr,
+                           int32_t* perm, void* workspace, size_t workspace_bytes,
+                           kgat_stream_t stream);
+
+/* Inverse of a permutation: inv[perm[i]] = i  (CSR position of each edge id). */
+int kgat_invert_permutation(int64_t n, const int32_t* perm, int32_t* inv, kgat_stream_t stream);
+
+/* Row schedule for the row-parallel kernels: a permutation of the CSR rows by descending
+ * in-degree (stable), so that the row groups that share a wavefront carry similar work and
+ * the heaviest rows start first.  order[N]. */
+size_t kgat_row_order_workspace_bytes(int64_t n_rows);
+int kgat_row_order_by_degree(int64_t n_rows, const int32_t* indptr, int32_t* order,
+                             void* workspace, size_t workspace_bytes, kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- attention score (A1+A2)
+ * Replaces the per-relation g.apply_edges(self._att_score, e_idxs) loop of reference
+ * models.py:135-152 by one launch over relation-grouped edges:
+ *   logits[e] = sum_j (ent[src e] W_R[r])_j * tanh((ent[dst e] W_R[r])_j + rel[r]_j), r = type(e)
+ * ent (N,d), W_R (R,d,k), rel (R,k).  rel_ptr/perm come from kgat_group_by_relation;
+ * src_g[i] = src[perm[i]], dst_g[i] = dst[perm[i]] (relation-grouped endpoint arrays, built
+ * once per graph with kgat_gather_i32).  Edges whose type is outside [0,R) get logit 0 (DGL
+ * zero-initialises the column on the first partial write).  logits[E] in edge-id order; if
+ * logits_csr is non-NULL the same value is also written to logits_csr[csr_pos[e]]. */
+int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                       const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                       const int32_t* dst_g, const float* ent, const float* W_R, const float* rel,
+                       float* logits, float* logits_csr, const int32_t* csr_pos, int algo,
+                       kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- edge softmax (A3)
+ * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
+ *   a[e] = exp(s[e] - max_{e'->dst e} s[e']) / sum_{e'->dst e} exp(s[e'] - max)
+ * over the incoming edges of each destination, all relations together, for the CSR
+ * positions [e_begin, e_end) (the whole graph: 0, E; a destination-range shard: its
+ * indptr range).  row_of = destination id per CSR position.
+ * Input: logits in edge-id order (logits_in_csr_order = 0; read through eid) or in CSR
+ * position order (1).  Outputs (either may be NULL, not both): out in edge-id order (written
+ * through eid) and out_csr in CSR order.  eid = original edge id per CSR position.
+ * Bitwise reproducible (integer-ordered max, fixed-point sum). */
+size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes);
+int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
+                          const int32_t* row_of, const int32_t* eid, const float* logits,
+                          int logits_in_csr_order, float* out, float* out_csr, void* workspace,
+                          size_t workspace_bytes, kgat_stream_t stream);
+
+/* Backward of the above (DGL 0.4.x EdgeSoftmax.backward), rows [row0, row0 + n_rows):
+ *   grad_s[e] = a[e]*g[e] - a[e] * sum_{e'->dst e} a[e']*g[e'];  arrays in edge-id order
+ * (eid != NULL) or CSR order (eid == NULL). */
+int kgat_edge_softmax_bwd_f32(int64_t n_rows, int64_t row0, const int32_t* indptr,
+                              const int32_t* eid, const float* a, const float* grad_a,
+                              float* grad_logits, kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- aggregation (S1, S1b)
+ * Replaces g.update_all(fn.u_mul_e('h','w','m'), fn.sum('m','h_neighbor')) of reference
+ * models.py:63 (DGL binary_reduce(sum, mul, SRC, EDGE) with (E,1) broadcast):
+ *   out[v - row0, :] = sum_{p in [indptr[v], indptr[v+1])} w_p * X[col[p], :]
+ * for rows v in [row0, row0 + n_rows), whose CSR positions are [e_begin, e_end) =
+ * [indptr[row0], indptr[row0 + n_rows]) (passed by value so the call needs no device read).
+ * w_p = w[eid[p]] if eid != NULL (w in edge-id order) else w[p] (w in CSR order).
+ * Rows with no in-edge are written as 0.  Summation order is fixed, no float atomics:
+ * results are bitwise reproducible.  X has D columns, fp32 row-major, 16-byte aligned.
+ * row_of (destination per CSR position) is required by the MERGE algorithm; `order` (a row
+ * schedule from kgat_row_order_by_degree over the same row range, entries relative to
+ * row0) only applies to ROWS.  workspace: kgat_spmm_workspace_bytes(e_end - e_begin, D).
+ * Backward w.r.t. X (S1b) is this same call on the CSR of the reversed graph. */
+size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D);
+int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64_t e_end, int D,
+                            const int32_t* indptr, const int32_t* col, const int32_t* row_of,
+                            const int32_t* eid, const float* X, const float* w, float* out,
+                            const int32_t* order, void* workspace, size_t workspace_bytes,
+                            unsigned flags, int algo, kgat_stream_t stream);
+
+/* Gradient of the aggregation w.r.t. the edge weight (DGL backward_rhs of the same op):
+ *   grad_w[e] = < X[src e, :], grad_out[dst e, :] >,  edge-id order. */
+int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t* dst,
+                       const float* X, const float* grad_out, float* grad_w,
+                       kgat_stream_t stream);
+
+/* Permute a per-edge array: out[i] = in[index[i]]. */
+int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out,
+                    kgat_stream_t stream);
+int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t* out,
+                    kgat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGAT_HIP_H_ */

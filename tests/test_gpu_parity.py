@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the CPU oracle on the
+same seeded inputs, the committed golden fixtures, edge cases, and size-independent
+properties at the benchmark's full size.  Tolerance for fp32 device results vs the fp64
+oracle: 1e-4 relative (conftest.rel_err, the form stated in SURVEY 8c); integer / index
+outputs are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, load_golden, rel_err
+from oracle import c_oracle as co
+from oracle import kgat_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def K():
+    import dgl_kgat_amd
+    return dgl_kgat_amd
+
+
+def t32(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32), device=dev)
+
+
+def tf(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def random_graph(seed, n, e, hub=0, isolated_tail=0):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e)
+    dst = rng.integers(0, max(n - isolated_tail, 1), e)
+    if hub:
+        dst[rng.choice(e, min(hub, e), replace=False)] = min(3, n - 1)
+    return src.astype(np.int32), dst.astype(np.int32)
+
+
+GRAPHS = [
+    ("empty", 5, 0, 0, 0),
+    ("single_edge", 3, 1, 0, 0),
+    ("tiny", 7, 20, 0, 2),
+    ("ragged", 300, 5000, 0, 40),
+    ("hub", 500, 20000, 9000, 100),
+    ("all_one_row", 64, 7000, 7000, 0),
+    ("wide", 5000, 60000, 3000, 0),
+]
+
+
+@pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
+def test_csr_from_coo_bit_exact(K, dev, name, n, e, hub, iso):
+    from dgl_kgat_amd import ops
+    src, dst = random_graph(1, n, e, hub, iso)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    oi, oc, oe = orc.csr_from_coo(n, src, dst)
+    assert np.array_equal(indptr.cpu().numpy(), oi)
+    assert np.array_equal(col.cpu().numpy(), oc)
+    assert np.array_equal(eid.cpu().numpy(), oe)
+    assert np.array_equal(row_of.cpu().numpy(), dst[oe])
+    if e:
+        pos = ops.invert_permutation(eid).cpu().numpy()
+        assert np.array_equal(pos[oe], np.arange(e))
+        order = ops.row_order_by_degree(indptr).cpu().numpy()
+        deg = np.diff(oi)
+        assert sorted(order.tolist()) == list(range(n))
+        assert np.all(np.diff(deg[order]) <= 0)
+        assert np.array_equal(order, np.argsort(-deg.astype(np.int64), kind="stable"))
+
+
+def test_csr_large_ids_three_radix_passes(K, dev):
+    from dgl_kgat_amd import ops
+    n, e = 200_000, 300_000  # 18-bit node ids -> three 8-bit passes
+    src, dst = random_graph(2, n, e, hub=50_000)
+    indptr, col, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    oi, oc, oe = co.csr_from_coo(n, src, dst)
+    assert np.array_equal(indptr.cpu().numpy(), oi) and np.array_equal(eid.cpu().numpy(), oe)
+    assert np.array_equal(col.cpu().numpy(), oc)
+
+
+@pytest.mark.parametrize("n_rel,e", [(1, 10), (5, 5000), (41, 70000), (300, 9000)])
+def test_group_by_relation_bit_exact(K, dev, n_rel, e):
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(n_rel)
+    et = rng.integers(-2, n_rel + 3, e).astype(np.int32)  # includes types outside [0, R)
+    rel_ptr, perm = ops.group_by_relation(t32(et, dev), n_rel)
+    orp, operm = orc.group_by_relation(et, n_rel)
+    assert np.array_equal(rel_ptr.cpu().numpy(), orp)
+    assert np.array_equal(perm.cpu().numpy(), operm)
+
+
+@pytest.mark.parametrize("D", [1, 4, 8, 12, 16, 32, 64, 128, 256, 100])
+@pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
+def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
+    from dgl_kgat_amd import ops
+    src, dst = random_graph(3, n, e, hub, iso)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(e).astype(np.float32)
+    ref = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
+    ref_self = ref * X
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    Xd, wd = tf(X, dev), tf(w, dev)
+    w_csr = ops.gather(eid, wd) if e else wd
+    algos = ["generic"] + (["merge", "rows"] if D in (4, 8, 16, 32, 64, 128, 256) else [])
+    for algo in algos:
+        out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo).cpu().numpy()
+        assert out.shape == (n, D)
+        assert rel_err(out, ref) < TOL, (algo, "csr-order w")
+        out = ops.spmm(indptr, col, row_of, Xd, wd, eid=eid, algo=algo).cpu().numpy()
+        assert rel_err(out, ref) < TOL, (algo, "edge-id-order w")
+        out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo, mul_self=True).cpu().numpy()
+        assert rel_err(out, ref_self) < TOL, (algo, "mul_self")
+        # destinations without in-edges are written as exact zeros, on a dirty output buffer
+        dirty = torch.full((n, D), 7.0, device=dev)
+        ops.spmm(indptr, col, row_of, Xd, w_csr, out=dirty, algo=algo)
+        assert np.all(dirty.cpu().numpy()[np.diff(indptr.cpu().numpy()) == 0] == 0)
+    if "rows" in algos and e:
+        order = ops.row_order_by_degree(indptr)
+        out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo="rows", order=order).cpu().numpy()
+        assert rel_err(out, ref) < TOL
+        # the rows kernel adds in CSR order with one fma per edge: bit-exact vs the C restatement
+        cref = co.spmm(n, indptr.cpu().numpy(), col.cpu().numpy(), None, X, w_csr.cpu().numpy())
+        assert np.array_equal(out, cref)
+        # reproducible: two launches of the merge kernel give identical bits
+        a = ops.spmm(indptr, col, row_of, Xd, w_csr, algo="merge")
+        b = ops.spmm(indptr, col, row_of, Xd, w_csr, algo="merge")
+        assert torch.equal(a, b)
+
+
+def test_spmm_row_range_shard(K, dev):
+    """Destination-range shard: rows [lo, hi) with their CSR position range (multi-GPU layout)."""
+    from dgl_kgat_amd import ops
+    n, e, D = 700, 30000, 64
+    src, dst = random_graph(5, n, e, hub=8000, isolated_tail=30)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(e).astype(np.float32)
+    ref = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    ip = indptr.cpu().numpy()
+    w_csr = ops.gather(eid, tf(w, dev))
+    for lo, hi in [(0, 3), (3, 4), (4, 250), (250, 700), (690, 700)]:
+        for algo in ["merge", "rows", "generic"]:
+            out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, rows=(lo, hi - lo),
+                           e_range=(int(ip[lo]), int(ip[hi])), algo=algo).cpu().numpy()
+            assert out.shape == (hi - lo, D)
+            assert rel_err(out, ref[lo:hi]) < TOL, (lo, hi, algo)
+
+
+@pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
+def test_edge_softmax_vs_oracle(K, dev, name, n, e, hub, iso):
+    from dgl_kgat_amd import ops
+    if e == 0:
+        pytest.skip("no edges")
+    src, dst = random_graph(7, n, e, hub, iso)
+    rng = np.random.default_rng(8)
+    s = (rng.standard_normal(e) * 4).astype(np.float32)
+    s[: min(e, 4)] = [80.0, -80.0, 0.0, -0.0][: min(e, 4)]
+    ref = orc.edge_softmax(n, dst, s)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    out, out_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
+    out, out_csr = out.cpu().numpy(), out_csr.cpu().numpy()
+    assert np.all(np.isfinite(out))
+    assert rel_err(out, ref) < TOL
+    assert np.array_equal(out_csr, out[eid.cpu().numpy()])
+    # CSR-ordered input gives the same bits
+    s_csr = ops.gather(eid, tf(s, dev))
+    out2, _ = ops.edge_softmax(n, row_of, eid, s_csr, in_csr_order=True, want_out=True)
+    assert np.array_equal(out2.cpu().numpy(), out)
+    # every non-empty destination's weights sum to one; shift invariance per destination
+    sums = np.zeros(n)
+    np.add.at(sums, dst, out.astype(np.float64))
+    assert np.allclose(sums[np.bincount(dst, minlength=n) > 0], 1.0, atol=1e-5)
+    shift = rng.standard_normal(n).astype(np.float32)[dst] * 3
+    out3, _ = ops.edge_softmax(n, row_of, eid, tf(s + shift, dev))
+    assert rel_err(out3.cpu().numpy(), ref) < 5e-4  # the shifted fp32 logits round differently
+    # reproducible bit for bit
+    out4, _ = ops.edge_softmax(n, row_of, eid, tf(s, dev))
+    assert np.array_equal(out4.cpu().numpy(), out)
+
+
+def test_edge_softmax_known_answers(K, dev):
+    from dgl_kgat_amd import ops
+    src = np.array([1, 2, 3, 0], np.int32)
+    dst = np.array([0, 0, 2, 3], np.int32)
+    indptr, col, eid, row_of = ops.csr_from_coo(5, t32(src, dev), t32(dst, dev))
+    a, _ = ops.edge_softmax(5, row_of, eid, tf([0.3, 0.3, -7.0, 80.0], dev))
+    assert np.array_equal(a.cpu().numpy(), np.array([0.5, 0.5, 1.0, 1.0], np.float32))
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_att_score_golden(K, dev, case):
+    """Attention logits against the outputs of the reference's own _att_score (F1)."""
+    from dgl_kgat_amd import ops
+    g = load_golden(case)
+    n, R = g["n"], g["R"]
+    src, dst, et = t32(g["src"], dev), t32(g["dst"], dev), t32(g["etype"], dev)
+    rel_ptr, perm = ops.group_by_relation(et, R)
+    sg, dg = ops.gather(perm, src), ops.gather(perm, dst)
+    _, _, eid, _ = ops.csr_from_coo(n, src, dst)
+    pos = ops.invert_permutation(eid)
+    d = g["entity_embed"].shape[1]
+    algos = ["generic"] + (["mfma"] if d == g["W_R"].shape[2] and d in (16, 32, 64, 128) else [])
+    for algo in algos:
+        logits, logits_csr = ops.att_score(n, rel_ptr, perm, sg, dg, tf(g["entity_embed"], dev),
+                                           tf(g["W_R"], dev), tf(g["relation_embed"], dev), csr_pos=pos,
+                                           algo=algo)
+        logits = logits.cpu().numpy()
+        for r in range(R):
+            assert rel_err(logits[g["att_eids_%d" % r]], g["att_score_%d" % r].reshape(-1)) < TOL, (algo, r)
+        assert np.array_equal(logits_csr.cpu().numpy(), logits[eid.cpu().numpy()])
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+def test_att_score_mfma_vs_oracle(K, dev, d):
+    from dgl_kgat_amd import ops
+    n, e, R = 900, 40000, 7
+    src, dst = random_graph(9, n, e, hub=3000)
+    rng = np.random.default_rng(10)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)  # some edges outside [0, R): logit 0
+    et[rng.choice(e, e // 2, replace=False)] = 2     # one large relation (> one 1024-edge chunk)
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = (rng.random((R, d, d)).astype(np.float32) - 0.5) * (2.0 / np.sqrt(d))
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    rel_ptr, perm = ops.group_by_relation(t32(et, dev), R)
+    sg, dg = ops.gather(perm, t32(src, dev)), ops.gather(perm, t32(dst, dev))
+    for algo in ["mfma", "generic"]:
+        logits, _ = ops.att_score(n, rel_ptr, perm, sg, dg, tf(ent, dev), tf(W, dev), tf(rel, dev), algo=algo)
+        logits = logits.cpu().numpy()
+        assert np.all(logits[(et < 0) | (et >= R)] == 0)
+        assert rel_err(logits, ref) < TOL, algo
+
+
+def _model_from_golden(K, g, dev):
+    d, k = g["entity_embed"].shape[1], g["W_R"].shape[2]
+    hidden = g["W2"][0].shape[0]
+    m = K.KGATPropagation(g["n"], g["R"], input_node_dim=d, relation_dim=k, num_gnn_layers=len(g["W2"]),
+                          n_hidden=hidden, dropout=0.0)
+    sd = {"entity_embed.weight": g["entity_embed"], "relation_embed.weight": g["relation_embed"], "W_R": g["W_R"]}
+    for i, W2 in enumerate(g["W2"]):
+        sd["layers.%d.res_fc_2.weight" % i] = W2
+    m.load_state_dict({k_: torch.as_tensor(v) for k_, v in sd.items()})
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
+    """The reference's call sequence over the drop-in surface, and the fused path, against the
+    outputs of the reference's own compute_attention / gnn glue (F2)."""
+    from dgl_kgat_amd import synth
+    g = load_golden(case)
+    model = _model_from_golden(K, g, dev)
+    graph = synth.build_graph(g["n"], g["triplets"], dev)
+    with torch.no_grad():
+        a_surface = model.compute_attention_surface(graph)
+        a_fused = model.compute_attention(graph)
+        assert a_surface.shape == a_fused.shape == (len(g["src"]), 1)
+        assert rel_err(a_surface.cpu().numpy(), g["attention"]) < TOL
+        assert rel_err(a_fused.cpu().numpy(), g["attention"]) < TOL
+        graph.edata["w"] = a_fused
+        for fused in (False, True):
+            out = model.gnn(graph, fused=fused)
+            assert out.shape == g["gnn_out"].shape
+            assert rel_err(out.cpu().numpy(), g["gnn_out"]) < TOL, fused
+        h = model.entity_embed(graph.ndata["id"])
+        for i, layer in enumerate(model.layers):
+            h = layer(graph, h, fused=False)
+            assert rel_err(h.cpu().numpy(), g["layer_out_%d" % i]) < TOL
+    assert "att_w" not in graph.edata and "h_neighbor" not in graph.ndata  # local_var did not leak
+
+
+def test_autograd_matches_oracle(K, dev):
+    from dgl_kgat_amd import synth
+    from dgl_kgat_amd.autograd import edge_softmax, u_mul_e_sum
+    n, trip, R = synth.collaborative_kg(30, 40, 30, 3, 900, 400, seed=3)
+    src, dst = trip[:, 2], trip[:, 0]
+    g = synth.build_graph(n, trip, dev)
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, 32)).astype(np.float32)
+    s = rng.standard_normal(len(trip)).astype(np.float32)
+    go = rng.standard_normal((n, 32)).astype(np.float32)
+    Xd = tf(X, dev).requires_grad_(True)
+    sd = tf(s, dev).reshape(-1, 1).requires_grad_(True)
+    a = edge_softmax(g, sd)
+    out = u_mul_e_sum(g, Xd, a)
+    out.backward(tf(go, dev))
+    a_ref = orc.edge_softmax(n, dst, s)
+    assert rel_err(out.detach().cpu().numpy(), orc.spmm_u_mul_e_sum(n, src, dst, X, a_ref)) < TOL
+    assert rel_err(Xd.grad.cpu().numpy(), orc.spmm_backward_x(n, src, dst, go, a_ref)) < TOL
+    gw = orc.sddmm_dot(src, dst, X, go)
+    gs = orc.edge_softmax_backward(n, dst, a_ref, gw).reshape(-1)
+    assert rel_err(sd.grad.cpu().numpy().reshape(-1), gs) < 5e-4
+
+
+def test_training_step_runs(K, dev):
+    """gnn -> BPR loss -> backward -> Adam, the CF step of kgat.py:146-168, over the kernels."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.collaborative_kg(30, 40, 30, 3, 900, 400, seed=5)
+    g = synth.build_graph(n, trip, dev)
+    torch.manual_seed(0)
+    model = K.KGATPropagation(n, R, 16, 16, 2, 16, dropout=0.0).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    with torch.no_grad():
+        g.edata["w"] = model.compute_attention(g)
+    u = torch.randint(0, 30, (64,), device=dev)
+    p = torch.randint(30, 70, (64,), device=dev)
+    q = torch.randint(30, 70, (64,), device=dev)
+    losses = []
+    for _ in range(5):
+        loss = model.get_loss(model.gnn(g), u, p, q)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_full_size_properties(K, dev):
+    """amazon-book-sized CKG (BASELINE configs[2]): properties that need no oracle run -
+    partition of unity of the attention, merge == rows kernel, linearity, reproducibility -
+    plus an oracle spot check on a sample of destination rows."""
+    from dgl_kgat_amd import ops, synth
+    n, trip, R = synth.amazon_book_ckg()
+    src, dst = trip[:, 2], trip[:, 0]
+    e = len(trip)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    ip = indptr.cpu().numpy().astype(np.int64)
+    assert ip[-1] == e and np.array_equal(np.diff(ip), np.bincount(dst, minlength=n))
+    eid_h = eid.cpu().numpy()
+    assert np.array_equal(np.sort(eid_h), np.arange(e)) and np.array_equal(dst[eid_h], row_of.cpu().numpy())
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    s = torch.randn(e, generator=gen).to(dev) * 3
+    a, a_csr = ops.edge_softmax(n, row_of, eid, s, want_out=True, want_csr=True)
+    ones = torch.ones((n, 64), device=dev)
+    unity = ops.spmm(indptr, col, row_of, ones, a_csr, algo="merge")
+    nonempty = torch.as_tensor(np.diff(ip) > 0, device=dev)
+    assert torch.all(unity[~nonempty] == 0)
+    assert float((unity[nonempty] - 1).abs().max()) < 1e-4
+    X = torch.randn((n, 64), generator=gen).to(dev)
+    Y = torch.randn((n, 64), generator=gen).to(dev)
+    m = ops.spmm(indptr, col, row_of, X, a_csr, algo="merge")
+    r = ops.spmm(indptr, col, row_of, X, a_csr, algo="rows")
+    scale = float(r.abs().max())
+    assert float((m - r).abs().max()) < 1e-5 * scale
+    assert torch.equal(m, ops.spmm(indptr, col, row_of, X, a_csr, algo="merge"))
+    lin = ops.spmm(indptr, col, row_of, X + Y, a_csr) - m - ops.spmm(indptr, col, row_of, Y, a_csr)
+    assert float(lin.abs().max()) < 1e-4 * scale
+    # oracle spot check: 200 rows incl. the heaviest hub
+    rows = np.unique(np.concatenate([np.random.default_rng(2).integers(0, n, 199), [int(np.argmax(np.diff(ip)))]]))
+    Xh, ah, mh = X.cpu().numpy().astype(np.float64), a.cpu().numpy().astype(np.float64), m.cpu().numpy()
+    for v in rows:
+        seg = eid_h[ip[v]:ip[v + 1]]
+        ref = (ah[seg, None] * Xh[src[seg]]).sum(0) if len(seg) else np.zeros(64)
+        assert np.max(np.abs(mh[v] - ref)) < 1e-4 * max(np.abs(ref).max(), 1e-3 * scale)
