@@ -437,10 +437,10 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
   KGAT_CHECK_ARG(algo >= KGAT_SPMM_ALGO_AUTO && algo <= KGAT_SPMM_ALGO_GENERIC,
                  "spmm: unknown algo %d", algo);
   if (algo == KGAT_SPMM_ALGO_AUTO)
-    algo = (lpr_for(D) && row_of) ? KGAT_SPMM_ALGO_MERGE
+    algo = (lpr_for(D) && (row_of || e_end == e_begin)) ? KGAT_SPMM_ALGO_MERGE
                                   : (lpr_for(D) ? KGAT_SPMM_ALGO_ROWS : KGAT_SPMM_ALGO_GENERIC);
   if (lpr_for(D) == 0) algo = KGAT_SPMM_ALGO_GENERIC;
-  KGAT_CHECK_ARG(algo != KGAT_SPMM_ALGO_MERGE || row_of != nullptr,
+  KGAT_CHECK_ARG(algo != KGAT_SPMM_ALGO_MERGE || row_of != nullptr || e_end == e_begin,
                  "spmm: merge algorithm needs row_of");
   KGAT_CHECK_ARG(order == nullptr || algo == KGAT_SPMM_ALGO_ROWS,
                  "spmm: a row order only applies to the rows algorithm");

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, load_golden, rel_err
+from conftest import GOLDEN_CASES, blocks_rel_err_inf, load_golden, rel_err, rel_err_inf, rel_err_rows
 from oracle import c_oracle as co
 from oracle import kgat_oracle as orc
 
@@ -114,11 +114,11 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     for algo in algos:
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo).cpu().numpy()
         assert out.shape == (n, D)
-        assert rel_err(out, ref) < TOL, (algo, "csr-order w")
+        assert rel_err_rows(out, ref) < TOL, (algo, "csr-order w")
         out = ops.spmm(indptr, col, row_of, Xd, wd, eid=eid, algo=algo).cpu().numpy()
-        assert rel_err(out, ref) < TOL, (algo, "edge-id-order w")
+        assert rel_err_rows(out, ref) < TOL, (algo, "edge-id-order w")
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo, mul_self=True).cpu().numpy()
-        assert rel_err(out, ref_self) < TOL, (algo, "mul_self")
+        assert rel_err_rows(out, ref_self) < TOL, (algo, "mul_self")
         # destinations without in-edges are written as exact zeros, on a dirty output buffer
         dirty = torch.full((n, D), 7.0, device=dev)
         ops.spmm(indptr, col, row_of, Xd, w_csr, out=dirty, algo=algo)
@@ -126,7 +126,7 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     if "rows" in algos and e:
         order = ops.row_order_by_degree(indptr)
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo="rows", order=order).cpu().numpy()
-        assert rel_err(out, ref) < TOL
+        assert rel_err_rows(out, ref) < TOL
         # the rows kernel adds in CSR order with one fma per edge: bit-exact vs the C restatement
         cref = co.spmm(n, indptr.cpu().numpy(), col.cpu().numpy(), None, X, w_csr.cpu().numpy())
         assert np.array_equal(out, cref)
@@ -153,7 +153,7 @@ def test_spmm_row_range_shard(K, dev):
             out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, rows=(lo, hi - lo),
                            e_range=(int(ip[lo]), int(ip[hi])), algo=algo).cpu().numpy()
             assert out.shape == (hi - lo, D)
-            assert rel_err(out, ref[lo:hi]) < TOL, (lo, hi, algo)
+            assert rel_err_rows(out, ref[lo:hi]) < TOL, (lo, hi, algo)
 
 
 @pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
@@ -268,14 +268,15 @@ def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
         assert rel_err(a_surface.cpu().numpy(), g["attention"]) < TOL
         assert rel_err(a_fused.cpu().numpy(), g["attention"]) < TOL
         graph.edata["w"] = a_fused
+        widths = [g["entity_embed"].shape[1]] + [W2.shape[0] for W2 in g["W2"]]
         for fused in (False, True):
             out = model.gnn(graph, fused=fused)
             assert out.shape == g["gnn_out"].shape
-            assert rel_err(out.cpu().numpy(), g["gnn_out"]) < TOL, fused
+            assert blocks_rel_err_inf(out.cpu().numpy(), g["gnn_out"], widths) < TOL, fused
         h = model.entity_embed(graph.ndata["id"])
         for i, layer in enumerate(model.layers):
             h = layer(graph, h, fused=False)
-            assert rel_err(h.cpu().numpy(), g["layer_out_%d" % i]) < TOL
+            assert rel_err_inf(h.cpu().numpy(), g["layer_out_%d" % i]) < TOL
     assert "att_w" not in graph.edata and "h_neighbor" not in graph.ndata  # local_var did not leak
 
 
