@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libkgat_hip.so")
-SOURCES = ["kgat_graph.hip", "kgat_spmm.hip", "kgat_softmax.hip", "kgat_att.hip"]
+SOURCES = ["kgat_graph.hip", "kgat_spmm.hip", "kgat_softmax.hip", "kgat_att.hip", "kgat_dense.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "kgat_hip.h")
 
 _i64, _i32, _u32, _sz, _p = C.c_int64, C.c_int, C.c_uint, C.c_size_t, C.c_void_p
@@ -32,6 +32,8 @@ SIGNATURES = {
     "kgat_spmm_workspace_bytes": (_sz, [_i64, _i32]),
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _p, _sz, _u32, _i32, _p]),
+    "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
+    "kgat_bi_interaction_f32": (_i32, [_i64, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64, _p]),
     "kgat_sddmm_dot_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
     "kgat_gather_f32": (_i32, [_i64, _p, _p, _p, _p]),
     "kgat_gather_i32": (_i32, [_i64, _p, _p, _p, _p]),

@@ -79,7 +79,7 @@ class Frame(MutableMapping):
 
 
 CSR = namedtuple("CSR", "indptr col eid row_of")
-RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g")
+RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g pos_g")
 
 
 class _Structure:
@@ -174,7 +174,8 @@ class _Structure:
             et32 = etype if etype.dtype == torch.int32 else etype.to(torch.int32)
             rel_ptr, perm = ops.group_by_relation(et32.contiguous(), int(n_rel))
             src, dst = self.coo(etype.device)
-            hit = (key, RelGroups(rel_ptr, perm, ops.gather(perm, src), ops.gather(perm, dst)), etype)
+            hit = (key, RelGroups(rel_ptr, perm, ops.gather(perm, src), ops.gather(perm, dst),
+                                   ops.gather(perm, self.csr_pos(etype.device))), etype)
             c["rel_groups"] = hit
         return hit[1]
 
@@ -413,7 +414,7 @@ class DGLGraph:
         groups = st.rel_groups(etype.to(dev), W_R.shape[0])
         _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                       ent.detach().contiguous(), W_R.detach().contiguous(),
-                                      rel.detach().contiguous(), csr_pos=st.csr_pos(dev), algo=algo)
+                                      rel.detach().contiguous(), pos_g=groups.pos_g, algo=algo)
         a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
                                     want_out=True, want_csr=True)
         st.remember_weight(a, a_csr)

@@ -12,7 +12,7 @@ from ._lib import KGATLibraryError, check
 
 SPMM_MUL_SELF = 1
 SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3}
-ATT_ALGO = {"auto": 0, "mfma": 1, "generic": 2}
+ATT_ALGO = dict({"auto": 0, "mfma": 1, "generic": 2}, **{"mfma_v%d" % v: 16 + v for v in range(16)})
 
 
 def _stream(t):
@@ -148,8 +148,9 @@ def gather(index, values):
     return out
 
 
-def att_score(n_nodes, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, csr_pos=None, algo="auto"):
-    """Attention logits (E,) in edge-id order; with csr_pos also in CSR order."""
+def att_score(n_nodes, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, pos_g=None, algo="auto"):
+    """Attention logits (E,) in edge-id order; with pos_g (CSR position of edge perm[i]) also
+    in CSR order."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
@@ -163,13 +164,13 @@ def att_score(n_nodes, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, csr_pos=None,
     dst_g = _need(dst_g, torch.int32, "dst_g", (e,))
     logits = torch.empty(e, dtype=torch.float32, device=ent.device)
     logits_csr = None
-    if csr_pos is not None:
-        csr_pos = _need(csr_pos, torch.int32, "csr_pos", (e,))
+    if pos_g is not None:
+        pos_g = _need(pos_g, torch.int32, "pos_g", (e,))
         logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device)
     with _timed("att_score", (e, d, k)):
         check(_lib.load().kgat_att_score_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
                                              _ptr(dst_g), _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits),
-                                             _ptr(logits_csr), _ptr(csr_pos), ATT_ALGO[algo], _stream(ent)),
+                                             _ptr(logits_csr), _ptr(pos_g), ATT_ALGO[algo], _stream(ent)),
               "kgat_att_score_f32")
     return logits, logits_csr
 
@@ -247,6 +248,36 @@ def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=Fal
     return out
 
 
+def bi_interaction_supported(d_in, d_out):
+    return bool(_lib.load().kgat_bi_interaction_supported(int(d_in), int(d_out)))
+
+
+def bi_interaction(P, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h=True):
+    """Z = leaky_relu(P @ W2^T); returns Z (next layer's input) and writes Z / ||Z_row|| into
+    `norm_out`, which may be a column slice of a wider row-major buffer."""
+    P = _need(P, torch.float32, "P")
+    W2 = _need(W2, torch.float32, "W2")
+    n, d_in = P.shape
+    d_out = W2.shape[0]
+    if W2.shape[1] != d_in:
+        raise ValueError("W2 has shape %s, expected (*, %d)" % (tuple(W2.shape), d_in))
+    if want_h and h_out is None:
+        h_out = torch.empty((n, d_out), dtype=torch.float32, device=P.device)
+    if h_out is not None:
+        h_out = _need(h_out, torch.float32, "h_out", (n, d_out))
+    stride = 0
+    if norm_out is not None:
+        if (not norm_out.is_cuda or norm_out.dtype != torch.float32 or tuple(norm_out.shape) != (n, d_out)
+                or norm_out.stride(1) != 1):
+            raise ValueError("norm_out must be an (n, d_out) float32 device view with unit column stride")
+        stride = norm_out.stride(0)
+    with _timed("bi_interaction", (n, d_in, d_out)):
+        check(_lib.load().kgat_bi_interaction_f32(n, d_in, d_out, _ptr(P), _ptr(W2), float(negative_slope),
+                                                  _ptr(h_out), _ptr(norm_out), stride, _stream(P)),
+              "kgat_bi_interaction_f32")
+    return h_out
+
+
 def sddmm_dot(src, dst, X, G):
     X = _need(X, torch.float32, "X")
     G = _need(G, torch.float32, "grad_out")
@@ -262,4 +293,5 @@ def sddmm_dot(src, dst, X, G):
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
            "att_score", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "bi_interaction", "bi_interaction_supported",
            "KGATLibraryError"]

@@ -53,7 +53,11 @@ enum {
 enum {
   KGAT_ATT_ALGO_AUTO = 0,
   KGAT_ATT_ALGO_MFMA = 1,   /* v_mfma_f32_16x16x4_f32; d == k in {16,32,64,128} */
-  KGAT_ATT_ALGO_GENERIC = 2 /* VALU, any (d,k) with d*k*4 <= 64 KiB */
+  KGAT_ATT_ALGO_GENERIC = 2, /* VALU, any (d,k) with d*k*4 <= 64 KiB */
+  /* MFMA tuning variants for A/B runs: BASE + bits (1: one 16-edge tile per wave step of the
+   * chunk kernel, 2: device-library tanhf instead of the exp2/rcp form, 4: workgroup-chunk
+   * kernel instead of the persistent-wavefront kernel, 8: 3 persistent waves per SIMD) */
+  KGAT_ATT_ALGO_VARIANT_BASE = 16
 };
 
 typedef void* kgat_stream_t; /* hipStream_t */
@@ -99,11 +103,12 @@ int kgat_row_order_by_degree(int64_t n_rows, const int32_t* indptr, int32_t* ord
  * src_g[i] = src[perm[i]], dst_g[i] = dst[perm[i]] (relation-grouped endpoint arrays, built
  * once per graph with kgat_gather_i32).  Edges whose type is outside [0,R) get logit 0 (DGL
  * zero-initialises the column on the first partial write).  logits[E] in edge-id order; if
- * logits_csr is non-NULL the same value is also written to logits_csr[csr_pos[e]]. */
+ * logits_csr is non-NULL the same value is also written in CSR position order through
+ * pos_g[i] = CSR position of edge perm[i] (= kgat_gather_i32(perm, csr_pos)). */
 int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                        const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                        const int32_t* dst_g, const float* ent, const float* W_R, const float* rel,
-                       float* logits, float* logits_csr, const int32_t* csr_pos, int algo,
+                       float* logits, float* logits_csr, const int32_t* pos_g, int algo,
                        kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- edge softmax (A3)
@@ -154,6 +159,18 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
 int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t* dst,
                        const float* X, const float* grad_out, float* grad_w,
                        kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- bi-interaction (B1 + B2)
+ * Forward of the dense part of KGATConv (reference models.py:66) fused with the readout
+ * normalisation (models.py:165-167):  Z = LeakyReLU_slope(P @ W2^T), P = h * h_N (n_rows x d_in,
+ * produced by the aggregation with KGAT_SPMM_MUL_SELF), W2 = res_fc_2.weight (d_out x d_in).
+ * h_out (n_rows x d_out, may be NULL) receives Z (the input of the next layer); norm_out (may
+ * be NULL) receives Z / max(||Z_row||_2, 1e-12) with row stride norm_stride floats (a column
+ * slice of the concatenated output).  Widths: see kgat_bi_interaction_supported. */
+int kgat_bi_interaction_supported(int d_in, int d_out);
+int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P, const float* W2,
+                            float negative_slope, float* h_out, float* norm_out,
+                            int64_t norm_stride, kgat_stream_t stream);
 
 /* Permute a per-edge array: out[i] = in[index[i]]. */
 int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out,

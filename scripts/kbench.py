@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the benchmark graph (developer tool; not part of the product
+path or of bench.py's contract).  Interleaved rounds in one process, HIP events per launch.
+
+  python scripts/kbench.py att   [--algos mfma_v0,mfma_v1,...] [--dim 64]
+  python scripts/kbench.py spmm  [--algos merge,rows,rows_ordered] [--dim 64]
+  python scripts/kbench.py softmax
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(fns, rounds, warm=3):
+    names = list(fns)
+    for _ in range(warm):
+        for n in names:
+            fns[n]()
+    ts = {n: [] for n in names}
+    for _ in range(rounds):
+        for n in names:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fns[n]()
+            b.record()
+            ts[n].append((a, b))
+    torch.cuda.synchronize()
+    return {n: np.array([a.elapsed_time(b) for a, b in v]) for n, v in ts.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kernel", choices=["att", "spmm", "softmax"])
+    ap.add_argument("--algos", default=None)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--workload", default="amazon-book")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    from dgl_kgat_amd import ops, synth
+    dev = torch.device("cuda:0")
+    if args.workload == "amazon-book":
+        n, trip, R = synth.amazon_book_ckg(scale=args.scale)
+    elif args.workload == "last-fm":
+        n, trip, R = synth.last_fm_ckg(scale=args.scale)
+    else:
+        n, trip, R = synth.power_law_ckg(int(1e7 * args.scale), int(2e8 * args.scale), 64)
+    E, D = len(trip), args.dim
+    src = torch.as_tensor(trip[:, 2].copy(), device=dev)
+    dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
+    et = torch.as_tensor(trip[:, 1].copy(), device=dev)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
+    g = torch.Generator().manual_seed(0)
+    print("N=%d E=%d R=%d D=%d" % (n, E, R, D))
+    if args.kernel == "att":
+        rel_ptr, perm = ops.group_by_relation(et, R)
+        sg, dg = ops.gather(perm, src), ops.gather(perm, dst)
+        pos = ops.gather(perm, ops.invert_permutation(eid))
+        ent = torch.randn(n, D, generator=g).to(dev)
+        W = ((torch.rand(R, D, D, generator=g) - 0.5) * (2 * 1.414 * (6 / (D * D + R * D)) ** 0.5)).to(dev)
+        rel = torch.randn(R, D, generator=g).to(dev)
+        algos = (args.algos or "mfma_v0,mfma_v2,mfma_v4,mfma_v5,mfma_v8").split(",")
+        fns = {a: (lambda a=a: ops.att_score(n, rel_ptr, perm, sg, dg, ent, W, rel, pos_g=pos, algo=a)) for a in algos}
+        res = timeit(fns, args.rounds)
+        flops = E * (4 * D * D + 3 * D)
+        for a, t in res.items():
+            print("att %-10s median %.4f ms  min %.4f ms  -> %.1f TFLOP/s (%.1f%% of 157.3), %.2f G edges/s"
+                  % (a, np.median(t), t.min(), flops / np.median(t) / 1e9, flops / np.median(t) / 1e9 / 157.3 * 100,
+                     E / np.median(t) / 1e6))
+        if args.check:
+            from oracle import kgat_oracle as orc
+            idx = np.random.default_rng(0).choice(E, 20000, replace=False)
+            ref = orc.att_score(ent.cpu().numpy(), W.cpu().numpy(), rel.cpu().numpy(), trip[idx, 2], trip[idx, 0], trip[idx, 1])
+            for a in algos:
+                out = fns[a]()[0].cpu().numpy()[idx]
+                print("  %-10s max abs err %.3e (max |ref| %.3f), rel-to-max %.2e" % (a, np.abs(out - ref).max(), np.abs(ref).max(),
+                                                                                 np.abs(out - ref).max() / np.abs(ref).max()))
+    elif args.kernel == "spmm":
+        X = torch.randn(n, D, generator=g).to(dev)
+        logits = torch.randn(E, generator=g).to(dev)
+        _, w_csr = ops.edge_softmax(n, row_of, eid, logits, want_out=False, want_csr=True)
+        order = ops.row_order_by_degree(indptr)
+        out = torch.empty(n, D, device=dev)
+        ws = ops.spmm_workspace(E, D, dev)
+        algos = (args.algos or "merge,rows,rows_ordered").split(",")
+        fns = {}
+        for a in algos:
+            if a == "rows_ordered":
+                fns[a] = lambda: ops.spmm(indptr, col, row_of, X, w_csr, out=out, order=order, algo="rows", workspace=ws)
+            else:
+                fns[a] = lambda a=a: ops.spmm(indptr, col, row_of, X, w_csr, out=out, algo=a, workspace=ws, mul_self=True)
+        res = timeit(fns, args.rounds)
+        b = E * (4 * D + 8) + n * (4 * D + 4)
+        for a, t in res.items():
+            print("spmm %-13s median %.4f ms  min %.4f ms -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), %.2f G edges/s"
+                  % (a, np.median(t), t.min(), b / np.median(t) / 1e6, b / np.median(t) / 1e6 / 80, E / np.median(t) / 1e6))
+    else:
+        logits = torch.randn(E, generator=g).to(dev)
+        fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
+               "softmax_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True)}
+        res = timeit(fns, args.rounds)
+        b = 12 * E + 4 * n
+        for a, t in res.items():
+            print("%-12s median %.4f ms min %.4f ms -> %.0f GB/s algorithmic" % (a, np.median(t), t.min(), b / np.median(t) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -74,3 +74,20 @@ def rel_err_rows(x, y):
         return float("inf")
     nz = scale > 0
     return float(np.max(err[nz] / scale[nz])) if nz.any() else 0.0
+
+
+def sum_err(x, y, abs_sum):
+    """Forward-error metric for a sum of products: max |x - y| / sum_p |w_p * X_p| per output
+    element (`abs_sum` = the same aggregation on |w|, |X|).  This is the quantity fp32
+    summation bounds (<= n*eps in the worst case, ~sqrt(n)*eps typically); an element whose
+    terms cancel cannot be held to a tolerance relative to its own (tiny) value.  Elements
+    with no terms must be exactly zero."""
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    a = np.asarray(abs_sum, np.float64)
+    if y.size == 0:
+        return 0.0
+    if np.any(x[a == 0] != 0):
+        return float("inf")
+    nz = a > 0
+    return float(np.max(np.abs(x - y)[nz] / a[nz])) if nz.any() else 0.0

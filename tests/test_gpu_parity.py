@@ -1,13 +1,15 @@
 """GPU parity tests: the HIP path (through the C ABI / ctypes) against the CPU oracle on the
 same seeded inputs, the committed golden fixtures, edge cases, and size-independent
 properties at the benchmark's full size.  Tolerance for fp32 device results vs the fp64
-oracle: 1e-4 relative (conftest.rel_err, the form stated in SURVEY 8c); integer / index
-outputs are bit-exact."""
+oracle: 1e-4 relative - elementwise with SURVEY 8c's floor (conftest.rel_err) for the softmax,
+relative to the sum of |terms| for the aggregation (conftest.sum_err: hub rows add thousands
+of fp32 products), relative to the tensor's scale for logits and multi-layer outputs
+(conftest.rel_err_inf); integer / index outputs are bit-exact."""
 import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, blocks_rel_err_inf, load_golden, rel_err, rel_err_inf, rel_err_rows
+from conftest import GOLDEN_CASES, blocks_rel_err_inf, load_golden, rel_err, rel_err_inf, sum_err
 from oracle import c_oracle as co
 from oracle import kgat_oracle as orc
 
@@ -106,7 +108,8 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     X = rng.standard_normal((n, D)).astype(np.float32)
     w = rng.random(e).astype(np.float32)
     ref = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
-    ref_self = ref * X
+    ref_abs = orc.spmm_u_mul_e_sum(n, src, dst, np.abs(X), w)  # w >= 0: sum of |terms|
+    ref_self, ref_self_abs = ref * X, ref_abs * np.abs(X)
     indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
     Xd, wd = tf(X, dev), tf(w, dev)
     w_csr = ops.gather(eid, wd) if e else wd
@@ -114,11 +117,11 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     for algo in algos:
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo).cpu().numpy()
         assert out.shape == (n, D)
-        assert rel_err_rows(out, ref) < TOL, (algo, "csr-order w")
+        assert sum_err(out, ref, ref_abs) < TOL, (algo, "csr-order w")
         out = ops.spmm(indptr, col, row_of, Xd, wd, eid=eid, algo=algo).cpu().numpy()
-        assert rel_err_rows(out, ref) < TOL, (algo, "edge-id-order w")
+        assert sum_err(out, ref, ref_abs) < TOL, (algo, "edge-id-order w")
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo, mul_self=True).cpu().numpy()
-        assert rel_err_rows(out, ref_self) < TOL, (algo, "mul_self")
+        assert sum_err(out, ref_self, ref_self_abs) < TOL, (algo, "mul_self")
         # destinations without in-edges are written as exact zeros, on a dirty output buffer
         dirty = torch.full((n, D), 7.0, device=dev)
         ops.spmm(indptr, col, row_of, Xd, w_csr, out=dirty, algo=algo)
@@ -126,7 +129,7 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     if "rows" in algos and e:
         order = ops.row_order_by_degree(indptr)
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo="rows", order=order).cpu().numpy()
-        assert rel_err_rows(out, ref) < TOL
+        assert sum_err(out, ref, ref_abs) < TOL
         # the rows kernel adds in CSR order with one fma per edge: bit-exact vs the C restatement
         cref = co.spmm(n, indptr.cpu().numpy(), col.cpu().numpy(), None, X, w_csr.cpu().numpy())
         assert np.array_equal(out, cref)
@@ -145,6 +148,7 @@ def test_spmm_row_range_shard(K, dev):
     X = rng.standard_normal((n, D)).astype(np.float32)
     w = rng.random(e).astype(np.float32)
     ref = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
+    ref_abs = orc.spmm_u_mul_e_sum(n, src, dst, np.abs(X), w)
     indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
     ip = indptr.cpu().numpy()
     w_csr = ops.gather(eid, tf(w, dev))
@@ -153,7 +157,7 @@ def test_spmm_row_range_shard(K, dev):
             out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, rows=(lo, hi - lo),
                            e_range=(int(ip[lo]), int(ip[hi])), algo=algo).cpu().numpy()
             assert out.shape == (hi - lo, D)
-            assert rel_err_rows(out, ref[lo:hi]) < TOL, (lo, hi, algo)
+            assert sum_err(out, ref[lo:hi], ref_abs[lo:hi]) < TOL, (lo, hi, algo)
 
 
 @pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
@@ -207,12 +211,13 @@ def test_att_score_golden(K, dev, case):
     rel_ptr, perm = ops.group_by_relation(et, R)
     sg, dg = ops.gather(perm, src), ops.gather(perm, dst)
     _, _, eid, _ = ops.csr_from_coo(n, src, dst)
-    pos = ops.invert_permutation(eid)
+    pos = ops.gather(perm, ops.invert_permutation(eid))
     d = g["entity_embed"].shape[1]
-    algos = ["generic"] + (["mfma"] if d == g["W_R"].shape[2] and d in (16, 32, 64, 128) else [])
+    algos = ["generic"] + (["mfma", "mfma_v2", "mfma_v4", "mfma_v5"]
+                           if d == g["W_R"].shape[2] and d in (16, 32, 64, 128) else [])
     for algo in algos:
         logits, logits_csr = ops.att_score(n, rel_ptr, perm, sg, dg, tf(g["entity_embed"], dev),
-                                           tf(g["W_R"], dev), tf(g["relation_embed"], dev), csr_pos=pos,
+                                           tf(g["W_R"], dev), tf(g["relation_embed"], dev), pos_g=pos,
                                            algo=algo)
         logits = logits.cpu().numpy()
         for r in range(R):
@@ -234,11 +239,14 @@ def test_att_score_mfma_vs_oracle(K, dev, d):
     ref = orc.att_score(ent, W, rel, src, dst, et)
     rel_ptr, perm = ops.group_by_relation(t32(et, dev), R)
     sg, dg = ops.gather(perm, t32(src, dev)), ops.gather(perm, t32(dst, dev))
-    for algo in ["mfma", "generic"]:
+    # mfma = persistent-wavefront kernel (d <= 64) / chunk kernel (d = 128); v2 = library tanhf;
+    # v4 / v5 = workgroup-chunk kernel with two / one tile per wave step
+    for algo in ["mfma", "mfma_v2", "mfma_v4", "mfma_v5", "generic"]:
         logits, _ = ops.att_score(n, rel_ptr, perm, sg, dg, tf(ent, dev), tf(W, dev), tf(rel, dev), algo=algo)
         logits = logits.cpu().numpy()
         assert np.all(logits[(et < 0) | (et >= R)] == 0)
-        assert rel_err(logits, ref) < TOL, algo
+        # the softmax that consumes the logits is sensitive to their ABSOLUTE error
+        assert rel_err_inf(logits, ref) < 1e-5, algo
 
 
 def _model_from_golden(K, g, dev):
@@ -278,6 +286,24 @@ def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
             h = layer(graph, h, fused=False)
             assert rel_err_inf(h.cpu().numpy(), g["layer_out_%d" % i]) < TOL
     assert "att_w" not in graph.edata and "h_neighbor" not in graph.ndata  # local_var did not leak
+
+
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (16, 16), (128, 64), (16, 128)])
+def test_bi_interaction_vs_oracle(K, dev, d_in, d_out):
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(d_in + d_out)
+    for n in (1, 15, 16, 17, 1000, 40001):
+        P = rng.standard_normal((n, d_in)).astype(np.float32)
+        P[n // 2] = 0  # an all-zero row must normalise to zeros (eps clamp), not NaN
+        W2 = (rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+        ref = orc.bi_interaction(np.ones_like(P), P, W2)
+        wide = torch.full((n, d_out + 24), 9.0, device=dev)
+        h = ops.bi_interaction(tf(P, dev), tf(W2, dev), 0.01, norm_out=wide[:, 8:8 + d_out])
+        assert rel_err_inf(h.cpu().numpy(), ref) < 1e-5
+        assert rel_err_inf(wide[:, 8:8 + d_out].cpu().numpy(), orc.l2_normalize(ref)) < 1e-5
+        assert torch.all(wide[:, :8] == 9.0) and torch.all(wide[:, 8 + d_out:] == 9.0)
+        assert np.all(np.isfinite(wide.cpu().numpy()))
+    assert not ops.bi_interaction_supported(128, 128) and not ops.bi_interaction_supported(8, 8)
 
 
 def test_autograd_matches_oracle(K, dev):
