@@ -32,11 +32,9 @@ class _UMulESum(torch.autograd.Function):
         w_flat = _flat_weight(w, st.n_edges).contiguous()
         csr = st.csr(dev)
         w_csr = st.weight_in_csr_order(w_flat.detach())
-        part = g.partition
-        if part is None:
-            out = ops.spmm(csr.indptr, csr.col, csr.row_of, x2.detach(), w_csr, mul_self=mul_self)
-        else:
-            out = part.aggregate(csr, x2.detach(), w_csr, mul_self=mul_self)
+        # (a destination-range shard is an ordinary graph holding only its local edges: rows it
+        # does not own come out as zeros and the caller exchanges them, partition.py)
+        out = ops.spmm(csr.indptr, csr.col, csr.row_of, x2.detach(), w_csr, mul_self=mul_self)
         ctx.g, ctx.mul_self, ctx.squeeze = g, mul_self, x.dim() == 1
         ctx.w_shape = w.shape
         ctx.save_for_backward(x2, w_flat, out if mul_self else None)
@@ -47,8 +45,6 @@ class _UMulESum(torch.autograd.Function):
         x2, w_flat, _ = ctx.saved_tensors
         st = ctx.g._st
         dev = grad_out.device
-        if ctx.g.partition is not None:
-            raise NotImplementedError("backward through a destination-partitioned aggregation")
         if ctx.mul_self:
             raise NotImplementedError("backward of the fused h*h_N epilogue: use the unfused op")
         go = (grad_out.unsqueeze(1) if ctx.squeeze else grad_out).contiguous()
@@ -85,14 +81,8 @@ class _EdgeSoftmax(torch.autograd.Function):
         if flat.dtype != torch.float32:
             raise TypeError("logits must be float32, got %s" % flat.dtype)
         csr = st.csr(flat.device)
-        part = g.partition
-        e_range = None if part is None else part.e_range
-        a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, flat, e_range=e_range, want_out=True,
-                                    want_csr=True)
-        if part is not None:
-            a = part.assemble_edge_values(csr, a, a_csr)
-        else:
-            st.remember_weight(a, a_csr)
+        a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, flat, want_out=True, want_csr=True)
+        st.remember_weight(a, a_csr)
         ctx.g = g
         ctx.save_for_backward(a)
         return a.reshape(logits.shape)

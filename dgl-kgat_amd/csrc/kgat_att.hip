@@ -60,6 +60,12 @@ __device__ __forceinline__ float att_tanh(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
+// tanh(x) given y = x * 2*log2(e) (the scale is folded into the caller's fma)
+__device__ __forceinline__ float att_tanh_scaled(float y) {
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 1.0f);
+}
+constexpr float kTwoLog2e = 2.8853900817779268f;
+
 // Sum over the 16 lanes of a DPP row (= one slot q of the MFMA layout); every lane gets the
 // total.  Four v_add_f32 with DPP operands, no LDS round trip.
 __device__ __forceinline__ float row16_sum(float v) {
@@ -268,7 +274,10 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
         for (int c = 0; c < KT; ++c) wreg[s][c] = W[krow * K_ + 16 * c + i];
       }
 #pragma unroll
-      for (int c = 0; c < KT; ++c) relv[c] = rel[(size_t)r * K_ + 16 * c + i];
+      for (int c = 0; c < KT; ++c) {
+        relv[c] = rel[(size_t)r * K_ + 16 * c + i];
+        if (!ACC_TANH) relv[c] *= kTwoLog2e;  // tanh argument scale folded into one fma
+      }
     }
 
     // Tile n of the segment covers edges pe0 + 16 n ...; indices past the segment are clamped
@@ -290,9 +299,19 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
       x.oe = perm[po];
       x.op = logits_csr ? pos_g[po] : 0;
     };
+    // 32-bit byte offsets from the table base (the launcher guarantees N*d*4 < 4 GiB): one
+    // scalar base + one VGPR offset per row instead of 64-bit address arithmetic per load
     auto load_a = [&](AFrag<D_, 1>& f, int32_t rs, int32_t rd) {
-      const int32_t rs1[1] = {rs}, rd1[1] = {rd};
-      att_load_a<D_, 1>(f, ent, rs1, rd1, q);
+      const char* base = reinterpret_cast<const char*>(ent);
+      const uint32_t os = (uint32_t)rs * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+      const uint32_t od = (uint32_t)rd * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+      for (int m = 0; m < D_ / 16; ++m) {
+        const float4 a = *reinterpret_cast<const float4*>(base + os + m * 64);
+        const float4 b = *reinterpret_cast<const float4*>(base + od + m * 64);
+        f.t[0][4 * m + 0] = a.x; f.t[0][4 * m + 1] = a.y; f.t[0][4 * m + 2] = a.z; f.t[0][4 * m + 3] = a.w;
+        f.h[0][4 * m + 0] = b.x; f.h[0][4 * m + 1] = b.y; f.h[0][4 * m + 2] = b.z; f.h[0][4 * m + 3] = b.w;
+      }
     };
     auto tile = [&](int32_t n, AFrag<D_, 1>& fa, const Idx& x) {
       floatx4 accT[KT], accH[KT];
@@ -314,7 +333,10 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
       for (int cc = 0; cc < KT; ++cc)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          part[j] = fmaf(accT[cc][j], att_tanh<ACC_TANH>(accH[cc][j] + relv[cc]), part[j]);
+          part[j] = fmaf(accT[cc][j],
+                         ACC_TANH ? tanhf(accH[cc][j] + relv[cc])
+                                  : att_tanh_scaled(fmaf(accH[cc][j], kTwoLog2e, relv[cc])),
+                         part[j]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) part[j] = row16_sum(part[j]);
       const float v = i == 0 ? part[0] : (i == 1 ? part[1] : (i == 2 ? part[2] : part[3]));
@@ -395,7 +417,8 @@ struct AttArgs {
   const float *ent, *W_R, *rel;
   float *logits, *logits_csr;
   const int32_t* pos_g;
-  int waves_per_simd = 2;
+  int waves_per_simd = 0;
+  unsigned long long table_bytes = 0;
 };
 
 template <int D_, int K_, int TILES, int ACC_TANH>
@@ -409,12 +432,23 @@ static int launch_att_mfma(const AttArgs& a) {
 
 template <int D_, int ACC_TANH>
 static int launch_att_persistent(const AttArgs& a) {
+  // one resident workgroup per CU slot the kernel's register budget admits: the tile ranges
+  // are split evenly over exactly the wavefronts that run concurrently
+  static int blocks_per_cu = 0;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  const unsigned grid = (unsigned)(cus * a.waves_per_simd);  // 4 waves per block, one per SIMD
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_score_persistent_kernel<D_, ACC_TANH>,
+                                                     kAttThreads, 0) != hipSuccess || nb < 1)
+      nb = 1;
+    blocks_per_cu = nb > 8 ? 8 : nb;
+  }
+  const int per_cu = a.waves_per_simd > 0 ? a.waves_per_simd : blocks_per_cu;
+  const unsigned grid = (unsigned)(cus * per_cu);  // 4 waves per block, one per SIMD
   hipLaunchKernelGGL((att_score_persistent_kernel<D_, ACC_TANH>), dim3(grid), dim3(kAttThreads), 0, a.st,
                      a.n_rel, a.rel_ptr, a.perm, a.src_g, a.dst_g, a.ent, a.W_R, a.rel, a.logits,
                      a.logits_csr, a.pos_g);
@@ -425,13 +459,13 @@ static int launch_att_persistent(const AttArgs& a) {
 // variant bits (A/B tuning): bit 0 = one 16-edge tile per wave step of the chunk kernel
 // (default two, except d = 128), bit 1 = device-library tanhf instead of the exp2/rcp form,
 // bit 2 = workgroup-chunk kernel (W_r in LDS) instead of the persistent-wavefront kernel,
-// bit 3 = three instead of two persistent waves per SIMD.
+// bit 3 = force one persistent wave per SIMD (default: what the occupancy query admits).
 template <int D_>
 static int dispatch_att_variant(AttArgs a, int variant) {
   const bool one_tile = (variant & 1) || D_ >= 128;
   const bool acc = variant & 2;
-  const bool chunk = (variant & 4) || D_ >= 128 || a.n_rel > kAttMaxRelLds;
-  a.waves_per_simd = (variant & 8) ? 3 : 2;
+  const bool chunk = (variant & 4) || D_ >= 128 || a.n_rel > kAttMaxRelLds || a.table_bytes >= (1ull << 32);
+  a.waves_per_simd = (variant & 8) ? 1 : 0;  // 0 = as many as are resident
   if constexpr (D_ <= 64) {
     if (!chunk) return acc ? launch_att_persistent<D_, 1>(a) : launch_att_persistent<D_, 0>(a);
   }
@@ -475,6 +509,7 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
   a.st = st; a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = dst_g;
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
   a.pos_g = pos_g;
+  a.table_bytes = (unsigned long long)n_nodes * (unsigned long long)d * 4ull;
   const unsigned grid = a.grid;
   const bool mfma_ok = (d == k) && (d == 16 || d == 32 || d == 64 || d == 128);
   int variant = 0;

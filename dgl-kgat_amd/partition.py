@@ -38,21 +38,30 @@ class Partition:
         self.rank, self.world, self.bounds, self.n_nodes, self.group = rank, world, list(bounds), n_nodes, group
         self.lo, self.hi = bounds[rank], bounds[rank + 1]
 
-    def exchange(self, local_rows, width):
-        """Zero-padded N x width buffer holding this rank's rows, all-reduced (sum)."""
+    def pad(self, local_rows, width):
+        """This rank's rows inside a zeroed N x width buffer."""
         full = torch.zeros((self.n_nodes, width), dtype=local_rows.dtype, device=local_rows.device)
         full[self.lo:self.hi] = local_rows
+        return full
+
+    def exchange(self, local_rows, width):
+        """Zero-padded N x width buffer holding this rank's rows, all-reduced (sum): every row
+        has exactly one non-zero contributor, so the result is exact and order independent."""
+        full = self.pad(local_rows, width)
         if self.world > 1:
             dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
         return full
 
-    def propagate(self, g, h, weight):
-        """One KGATConv on a shard: local aggregation (+ h*h_N epilogue), local dense part on
-        the owned rows only, then the all-reduce of the D_out-wide result."""
+    def propagate_local(self, g, h, weight):
+        """The owned rows of one KGATConv output: local aggregation (+ h*h_N epilogue) over the
+        shard's edges, dense part on the owned rows only."""
         from .autograd import u_mul_e_sum
         prod = u_mul_e_sum(g, h, g.edata["w"], mul_self=True)
-        out = torch.nn.functional.leaky_relu(torch.nn.functional.linear(prod[self.lo:self.hi], weight))
-        return self.exchange(out, weight.shape[0])
+        return torch.nn.functional.leaky_relu(torch.nn.functional.linear(prod[self.lo:self.hi], weight))
+
+    def propagate(self, g, h, weight):
+        """One KGATConv on a shard + the all-reduce of its D_out-wide result."""
+        return self.exchange(self.propagate_local(g, h, weight), weight.shape[0])
 
 
 def shard_graph(g, rank, world, group=None, bounds=None):

@@ -56,7 +56,7 @@ enum {
   KGAT_ATT_ALGO_GENERIC = 2, /* VALU, any (d,k) with d*k*4 <= 64 KiB */
   /* MFMA tuning variants for A/B runs: BASE + bits (1: one 16-edge tile per wave step of the
    * chunk kernel, 2: device-library tanhf instead of the exp2/rcp form, 4: workgroup-chunk
-   * kernel instead of the persistent-wavefront kernel, 8: 3 persistent waves per SIMD) */
+   * kernel instead of the persistent-wavefront kernel, 8: one persistent wave per SIMD) */
   KGAT_ATT_ALGO_VARIANT_BASE = 16
 };
 

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--workload", default="amazon-book")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--same-rows", action="store_true")
     args = ap.parse_args()
     from dgl_kgat_amd import ops, synth
     dev = torch.device("cuda:0")
@@ -68,6 +69,10 @@ def main():
         rel = torch.randn(R, D, generator=g).to(dev)
         algos = (args.algos or "mfma_v0,mfma_v2,mfma_v4,mfma_v5,mfma_v8").split(",")
         fns = {a: (lambda a=a: ops.att_score(n, rel_ptr, perm, sg, dg, ent, W, rel, pos_g=pos, algo=a)) for a in algos}
+        if args.same_rows:  # diagnostic: every edge reads rows 0..15 (cache resident): isolates gather latency
+            sz, dz = sg % 16, dg % 16
+            for a in algos:
+                fns[a + "_samerows"] = (lambda a=a: ops.att_score(n, rel_ptr, perm, sz, dz, ent, W, rel, pos_g=pos, algo=a))
         res = timeit(fns, args.rounds)
         flops = E * (4 * D * D + 3 * D)
         for a, t in res.items():

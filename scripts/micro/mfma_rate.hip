@@ -1,0 +1,61 @@
+// Micro-benchmark (developer tool): issue rate of v_mfma_f32_16x16x4_f32 in the access pattern
+// of the attention kernel (8 independent accumulator chains, operands in VGPRs), with and
+// without VALU filler between the MFMAs.  hipcc --offload-arch=gfx950 -O3 mfma_rate.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int FILL>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+  floatx4 acc[8];
+  for (int c = 0; c < 8; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  float a[16], b[16];
+  for (int s = 0; s < 16; ++s) { a[s] = seed + s + threadIdx.x; b[s] = seed * 2 + s; }
+  float f = seed;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[(s + c) & 15], acc[c], 0, 0, 0);
+      if (FILL) {
+#pragma unroll
+        for (int j = 0; j < FILL; ++j) f = fmaf(f, 1.0001f, 0.5f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float r = f;
+  for (int c = 0; c < 8; ++c) r += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int FILL>
+void run(const char* name, int blocks) {
+  float* out;
+  hipMalloc(&out, sizeof(float) * blocks * 256);
+  const int iters = 2000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  k<FILL><<<blocks, 256>>>(out, 10, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k<FILL><<<blocks, 256>>>(out, iters, 1.0f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  double flop = (double)blocks * 4 * iters * 128 * (16 * 16 * 4 * 2);
+  double cyc_per_mfma = ms * 1e-3 * 2.4e9 / (iters * 128.0) / ((double)blocks / 256.0 > 1 ? (double)blocks / 256.0 : 1);
+  printf("%-28s blocks=%d  %.3f ms  %.1f TFLOP/s  (~%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", name, blocks, ms, flop / ms / 1e9, cyc_per_mfma);
+  hipFree(out);
+}
+
+int main() {
+  run<0>("mfma only, 1 wave/SIMD", 256);
+  run<0>("mfma only, 2 waves/SIMD", 512);
+  run<4>("mfma + 4 fma/kstep, 1 w/SIMD", 256);
+  run<8>("mfma + 8 fma/kstep, 1 w/SIMD", 256);
+  run<16>("mfma + 16 fma/kstep, 1 w/SIMD", 256);
+  run<8>("mfma + 8 fma/kstep, 2 w/SIMD", 512);
+  return 0;
+}
