@@ -168,23 +168,38 @@ def main():
     e_loc, rows_loc = (spmm_info[0][0], spmm_info[0][1]) if spmm_info else (E, n)
     # algorithmic bytes of one SpMM launch on this rank: E*(4D+8) + N_out*(4D+4)
     b_spmm = e_loc * (4 * D + 8) + rows_loc * (4 * D + 4)
+    # HBM-side traffic of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/*_pmc_spmm_traffic.json).
+    # Counters cannot be collected from inside this process, so the figure is the committed
+    # measurement of the identical launch (same graph, D, kernel), or null when none matches.
+    traffic = None
+    try:
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_spmm_traffic.json"))
+        if pmc_files and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
+            with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as f:
+                traffic = int(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = None
     if spmm_ms:
         ach = b_spmm / (spmm_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge_kernel + spmm_finish_kernel), D=%d" % D,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "algorithmic_bytes": int(b_spmm), "avg_ms": round(spmm_ms, 4),
+                    "traffic": traffic, "algorithmic_bytes": int(b_spmm), "avg_ms": round(spmm_ms, 4),
                     "min_ms": round(spmm_min, 4), "launches": spmm_cnt,
                     "edges_per_s": round(e_loc / (spmm_ms * 1e-3), 1),
-                    "note": "X (N*D*4 = %.1f MB) is Infinity-Cache resident: gathered bytes are largely cache-served, "
-                            "not HBM bytes; compulsory HBM traffic is 8E + N(8D+4) = %.1f MB"
-                            % (n * D * 4 / 1e6, (8 * e_loc + n * (8 * D + 4)) / 1e6)}
+                    "note": ("X (N*D*4 = %.1f MB) fits the 256 MiB Infinity Cache: gathered bytes are largely cache-served, "
+                             "not HBM bytes (a fraction above 1.0 means exactly that, not >peak HBM); "
+                             if n * D * 4 < 200e6 else
+                             "X (N*D*4 = %.1f MB) exceeds the 256 MiB Infinity Cache: gathers are HBM-served; ")
+                            % (n * D * 4 / 1e6) +
+                            "compulsory HBM traffic is 8E + N(8D+4) = %.1f MB" % ((8 * e_loc + n * (8 * D + 4)) / 1e6)}
     roofline_att = None
     if att_ms:
         att_info = ksum["att_score"][0][0]
         flops = att_info[0] * (4 * D * D + 3 * D)
         tf_ = flops / (att_ms * 1e-3) / 1e12
-        roofline_att = {"bound": "mfma", "kernel": "kgat_att_score_f32 (att_score_mfma_kernel)", "achieved": round(tf_, 2),
+        roofline_att = {"bound": "mfma", "kernel": "kgat_att_score_f32 (att_score_persistent_kernel)", "achieved": round(tf_, 2),
                         "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_ / FP32_MFMA_PEAK_TF, 4),
                         "traffic": None, "avg_ms": round(att_ms, 4), "min_ms": round(att_min, 4)}
 
@@ -204,7 +219,7 @@ def main():
         "roofline": roofline,
         "roofline_att": roofline_att,
         "breakdown_ms": {"att_score": att_ms, "edge_softmax": sm_ms, "spmm_D%d" % D: spmm_ms,
-                         "spmm_all": avg_ms("spmm")[0]},
+                         "spmm_all": avg_ms("spmm")[0], "bi_interaction_all": avg_ms("bi_interaction")[0]},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -216,7 +216,7 @@ constexpr int kAttMaxRelLds = 4096;
 
 template <int D_, int ACC_TANH>
 __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
-    int n_rel, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ perm,
+    int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ src_g, const int32_t* __restrict__ dst_g,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
     float* __restrict__ logits, float* __restrict__ logits_csr,
@@ -244,6 +244,18 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
   const int64_t wv = (int64_t)blockIdx.x * (kAttThreads / kWave) + tid / kWave;
   const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
+
+  // Edges whose type is outside [0, R) sit after rel_ptr[R] in perm: logit 0 (DGL's
+  // zero-initialised column); each wave clears its slice of that tail.
+  {
+    const int64_t tail0 = rel_ptr[n_rel];
+    const int64_t n_tail = n_edges - tail0;
+    for (int64_t p = tail0 + n_tail * wv / n_waves + lane; p < tail0 + n_tail * (wv + 1) / n_waves; p += kWave) {
+      logits[perm[p]] = 0.f;
+      if (logits_csr) logits_csr[pos_g[p]] = 0.f;
+    }
+  }
+  if (t_begin >= t_end) return;
 
   float wreg[KS][KT];
   float relv[KT];
@@ -419,6 +431,8 @@ struct AttArgs {
   const int32_t* pos_g;
   int waves_per_simd = 0;
   unsigned long long table_bytes = 0;
+  int64_t n_edges = 0;
+  bool needs_memset = true;
 };
 
 template <int D_, int K_, int TILES, int ACC_TANH>
@@ -450,7 +464,7 @@ static int launch_att_persistent(const AttArgs& a) {
   const int per_cu = a.waves_per_simd > 0 ? a.waves_per_simd : blocks_per_cu;
   const unsigned grid = (unsigned)(cus * per_cu);  // 4 waves per block, one per SIMD
   hipLaunchKernelGGL((att_score_persistent_kernel<D_, ACC_TANH>), dim3(grid), dim3(kAttThreads), 0, a.st,
-                     a.n_rel, a.rel_ptr, a.perm, a.src_g, a.dst_g, a.ent, a.W_R, a.rel, a.logits,
+                     a.n_rel, a.n_edges, a.rel_ptr, a.perm, a.src_g, a.dst_g, a.ent, a.W_R, a.rel, a.logits,
                      a.logits_csr, a.pos_g);
   KGAT_CHECK_LAUNCH("att_score_persistent");
   return KGAT_OK;
@@ -495,12 +509,19 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
                      (algo >= KGAT_ATT_ALGO_VARIANT_BASE && algo < KGAT_ATT_ALGO_VARIANT_BASE + 16),
                  "att_score: bad algo");
   hipStream_t st = as_stream(stream);
-  // edges whose type is outside [0, R) keep logit 0 (DGL zero-initialised column)
-  hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)n_edges, st);
-  if (e == hipSuccess && logits_csr) e = hipMemsetAsync(logits_csr, 0, sizeof(float) * (size_t)n_edges, st);
-  if (e != hipSuccess) {
-    set_error("att_score: memset failed: %s", hipGetErrorString(e));
-    return KGAT_E_HIP;
+  // edges whose type is outside [0, R) keep logit 0 (DGL zero-initialised column): the
+  // persistent kernel clears that tail itself, the other kernels rely on a memset
+  const bool persistent = (d == k) && (d == 16 || d == 32 || d == 64) && n_rel > 0 &&
+                          n_rel <= kAttMaxRelLds && (unsigned long long)n_nodes * d * 4ull < (1ull << 32) &&
+                          (algo == KGAT_ATT_ALGO_AUTO || algo == KGAT_ATT_ALGO_MFMA ||
+                           (algo >= KGAT_ATT_ALGO_VARIANT_BASE && !((algo - KGAT_ATT_ALGO_VARIANT_BASE) & 4)));
+  if (!persistent) {
+    hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)n_edges, st);
+    if (e == hipSuccess && logits_csr) e = hipMemsetAsync(logits_csr, 0, sizeof(float) * (size_t)n_edges, st);
+    if (e != hipSuccess) {
+      set_error("att_score: memset failed: %s", hipGetErrorString(e));
+      return KGAT_E_HIP;
+    }
   }
   if (n_rel == 0) return KGAT_OK;
   KGAT_CHECK_ARG(rel_ptr && perm && src_g && dst_g && ent && W_R && rel, "att_score: null pointer");
@@ -510,6 +531,7 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
   a.pos_g = pos_g;
   a.table_bytes = (unsigned long long)n_nodes * (unsigned long long)d * 4ull;
+  a.n_edges = n_edges;
   const unsigned grid = a.grid;
   const bool mfma_ok = (d == k) && (d == 16 || d == 32 || d == 64 || d == 128);
   int variant = 0;
