@@ -8,7 +8,18 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libkgat_hip.so")
-SOURCES = ["kgat_graph.hip", "kgat_spmm.hip", "kgat_softmax.hip", "kgat_att.hip", "kgat_dense.hip"]
+# source -> extra hipcc flags.  -amdgpu-mfma-vgpr-form puts MFMA results in VGPRs so the VALU
+# epilogue reads them without v_accvgpr_read copies (f32 MFMA and VALU share the SIMD's issue
+# port - measured with scripts/micro/mfma_rate.hip - so fewer instructions is the lever); the
+# LDS-staged chunk kernels lose occupancy with it and are built without.
+SOURCES = {
+    "kgat_graph.hip": [],
+    "kgat_spmm.hip": [],
+    "kgat_softmax.hip": [],
+    "kgat_att.hip": [],
+    "kgat_att_persistent.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "kgat_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "kgat_hip.h")
 
 _i64, _i32, _u32, _sz, _p = C.c_int64, C.c_int, C.c_uint, C.c_size_t, C.c_void_p
@@ -46,25 +57,37 @@ class KGATLibraryError(RuntimeError):
     pass
 
 
-def hipcc_command(out=SO_PATH):
+def _hipcc():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-            "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+OBJ_DIR = os.path.join(_HERE, "build")
 
 
 def needs_build():
     if not os.path.exists(SO_PATH):
         return True
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER, os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps)
 
 
 def build(force=False):
-    """Compile the HIP sources for gfx950 in-tree (cross-compiles without a GPU)."""
-    if force or needs_build():
-        subprocess.check_call(hipcc_command())
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU): one
+    object per source (per-file flags), then one shared library."""
+    if not (force or needs_build()):
+        return SO_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    procs, objs = [], []
+    for src, extra in SOURCES.items():
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen([_hipcc()] + BASE_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]))
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, p.args)
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs)
     return SO_PATH
 
 
@@ -76,6 +99,11 @@ def load():
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (loads torch's libamdhip64.so first)
+    if not os.path.exists(SO_PATH):
+        try:  # a source checkout without the built library: compile it (hipcc cross-compiles)
+            build()
+        except (OSError, subprocess.CalledProcessError):
+            pass
     if not os.path.exists(SO_PATH):
         raise KGATLibraryError(
             "libkgat_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "

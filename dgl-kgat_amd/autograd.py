@@ -51,7 +51,7 @@ class _UMulESum(torch.autograd.Function):
         grad_x = grad_w = None
         if ctx.needs_input_grad[0]:
             rev = st.csr_rev(dev)
-            grad_x = ops.spmm(rev.indptr, rev.col, rev.row_of, go, w_flat.detach(), eid=rev.eid)
+            grad_x = ops.spmm(rev.indptr, rev.col, rev.row_of, go, st.weight_in_rev_order(w_flat.detach()))
             if ctx.squeeze:
                 grad_x = grad_x.squeeze(1)
         if ctx.needs_input_grad[1]:

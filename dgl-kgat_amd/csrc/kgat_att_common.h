@@ -1,0 +1,104 @@
+// Shared pieces of the attention-logit kernels (internal; see kgat_att.hip for the design).
+#pragma once
+#include <math.h>
+
+#include "kgat_common.h"
+
+namespace kgat {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kAttThreads = 256;
+constexpr int kAttChunk = 1024;  // edges of one relation per workgroup
+
+// Locate (relation, chunk) for a block: blocks are laid out relation by relation,
+// ceil(E_r / kAttChunk) blocks each.  Returns false past the end.
+__device__ __forceinline__ bool att_locate(const int32_t* __restrict__ rel_ptr, int n_rel,
+                                           int block, int& r_out, int32_t& beg, int32_t& end) {
+  int acc = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    const int32_t b = rel_ptr[r], e = rel_ptr[r + 1];
+    const int nb = (e - b + kAttChunk - 1) / kAttChunk;
+    if (block < acc + nb) {
+      r_out = r;
+      beg = b + (block - acc) * kAttChunk;
+      end = (beg + kAttChunk < e) ? beg + kAttChunk : e;
+      return true;
+    }
+    acc += nb;
+  }
+  return false;
+}
+
+// tanh for the epilogue.  ACCURATE = 0: 1 - 2/(exp(2x)+1) with the hardware exp2/rcp
+// (absolute error ~1e-7, which is what the logit sum_j t_j*tanh(.) is sensitive to; the
+// relative error near 0 is not preserved).  ACCURATE = 1: the device library's tanhf.
+template <int ACCURATE>
+__device__ __forceinline__ float att_tanh(float x) {
+  if (ACCURATE) return tanhf(x);
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x) = 2^(2x*log2 e)
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+// tanh(x) given y = x * 2*log2(e) (the scale is folded into the caller's fma)
+__device__ __forceinline__ float att_tanh_scaled(float y) {
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 1.0f);
+}
+constexpr float kTwoLog2e = 2.8853900817779268f;
+
+// Sum over the 16 lanes of a DPP row (= one slot q of the MFMA layout); every lane gets the
+// total.  Four v_add_f32 with DPP operands, no LDS round trip.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+template <int D_, int TILES>
+struct AFrag {
+  float t[TILES][D_ / 4], h[TILES][D_ / 4];
+};
+
+// Gather the A fragments (tail and head embedding rows) of TILES 16-edge tiles.
+template <int D_, int TILES>
+__device__ __forceinline__ void att_load_a(AFrag<D_, TILES>& f, const float* __restrict__ ent,
+                                           const int32_t (&rs)[TILES], const int32_t (&rd)[TILES],
+                                           int q) {
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const float4* ps = reinterpret_cast<const float4*>(ent + (size_t)rs[t] * D_) + q;
+    const float4* pd = reinterpret_cast<const float4*>(ent + (size_t)rd[t] * D_) + q;
+#pragma unroll
+    for (int m = 0; m < D_ / 16; ++m) {
+      const float4 a = ps[m * 4];
+      const float4 b = pd[m * 4];
+      f.t[t][4 * m + 0] = a.x; f.t[t][4 * m + 1] = a.y; f.t[t][4 * m + 2] = a.z; f.t[t][4 * m + 3] = a.w;
+      f.h[t][4 * m + 0] = b.x; f.h[t][4 * m + 1] = b.y; f.h[t][4 * m + 2] = b.z; f.h[t][4 * m + 3] = b.w;
+    }
+  }
+}
+
+
+struct AttArgs {
+  unsigned grid;
+  hipStream_t st;
+  int n_rel;
+  const int32_t *rel_ptr, *perm, *src_g, *dst_g;
+  const float *ent, *W_R, *rel;
+  float *logits, *logits_csr;
+  const int32_t* pos_g;
+  int waves_per_simd = 0;
+  unsigned long long table_bytes = 0;
+  int64_t n_edges = 0;
+  bool needs_memset = true;
+};
+
+
+// kgat_att_persistent.hip (compiled with -amdgpu-mfma-vgpr-form: its epilogue reads the MFMA
+// results from VGPRs directly); returns KGAT_E_UNSUPPORTED for widths it does not cover.
+int launch_att_persistent_any(int d, bool accurate_tanh, const AttArgs& a);
+constexpr int kAttMaxRelLds = 4096;
+
+}  // namespace kgat

@@ -191,6 +191,17 @@ class _Structure:
             c["w_csr"] = hit
         return hit[1]
 
+    def weight_in_rev_order(self, w_flat):
+        """The same weights in the reversed graph's CSR order (SpMM backward, S1b), cached the
+        same way: one permutation per attention refresh, not one per backward call."""
+        c = self._cache(w_flat.device)
+        key = (w_flat.data_ptr(), w_flat._version, w_flat.numel())
+        hit = c.get("w_rev")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.gather(self.csr_rev(w_flat.device).eid, w_flat), w_flat)
+            c["w_rev"] = hit
+        return hit[1]
+
     def remember_weight(self, w_flat, w_csr):
         self._cache(w_flat.device)["w_csr"] = ((w_flat.data_ptr(), w_flat._version, w_flat.numel()),
                                                w_csr, w_flat)

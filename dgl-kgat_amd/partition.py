@@ -53,11 +53,16 @@ class Partition:
         return full
 
     def propagate_local(self, g, h, weight):
-        """The owned rows of one KGATConv output: local aggregation (+ h*h_N epilogue) over the
-        shard's edges, dense part on the owned rows only."""
-        from .autograd import u_mul_e_sum
-        prod = u_mul_e_sum(g, h, g.edata["w"], mul_self=True)
-        return torch.nn.functional.leaky_relu(torch.nn.functional.linear(prod[self.lo:self.hi], weight))
+        """The owned rows of one KGATConv output: aggregation (+ h*h_N epilogue) over the
+        shard's edges restricted to the owned row range - every local edge ends in it, so the
+        CSR positions are [0, E_local) - then the dense part on those rows only."""
+        st = g._st
+        csr = st.csr(h.device)
+        w = g.edata["w"]
+        w_csr = st.weight_in_csr_order(w.detach().reshape(-1).contiguous())
+        prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
+                        rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
+        return torch.nn.functional.leaky_relu(torch.nn.functional.linear(prod, weight))
 
     def propagate(self, g, h, weight):
         """One KGATConv on a shard + the all-reduce of its D_out-wide result."""

@@ -36,7 +36,7 @@ def timeit(fns, rounds, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["att", "spmm", "softmax"])
+    ap.add_argument("kernel", choices=["att", "spmm", "softmax", "train"])
     ap.add_argument("--algos", default=None)
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--rounds", type=int, default=20)
@@ -106,6 +106,40 @@ def main():
         for a, t in res.items():
             print("spmm %-13s median %.4f ms  min %.4f ms -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), %.2f G edges/s"
                   % (a, np.median(t), t.min(), b / np.median(t) / 1e6, b / np.median(t) / 1e6 / 80, E / np.median(t) / 1e6))
+    elif args.kernel == "train":
+        # the CF step of kgat.py:146-168: gnn (all layers, full graph) -> BPR loss -> backward -> Adam
+        import time
+        import dgl_kgat_amd as K
+        torch.manual_seed(0)
+        model = K.KGATPropagation(n, R, D, D, 3, D, dropout=0.1).to(dev)
+        graph = synth.build_graph(n, trip, dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        with torch.no_grad():
+            graph.edata["w"] = model.compute_attention(graph)
+        B = 10240
+        u = torch.randint(0, 70679, (B,), device=dev)
+        pi = torch.randint(70679, 95594, (B,), device=dev)
+        ni = torch.randint(70679, 95594, (B,), device=dev)
+
+        def step():
+            loss = model.get_loss(model.gnn(graph), u, pi, ni)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        with ops.KernelTimer() as kt:
+            t0 = time.perf_counter()
+            for _ in range(args.rounds):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.rounds
+        print("train step (fwd+bwd+Adam, 3 layers, batch %d): %.3f ms -> %.2f G edge traversals/s (fwd+bwd = 6E)"
+              % (B, dt * 1e3, 6 * E / dt / 1e9))
+        for name, v in kt.summary().items():
+            print("   %-14s %4d launches  avg %.4f ms" % (name, len(v), float(np.mean([m for _, m in v]))))
     else:
         logits = torch.randn(E, generator=g).to(dev)
         fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
