@@ -263,4 +263,39 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
   return KGAT_OK;
 }
 
+int kgat_att_score_split_supported(int64_t n_nodes, int d, int k, int n_rel) {
+  return d == k && (d == 16 || d == 32 || d == 64) && n_rel > 0 && n_rel <= kAttMaxRelLds &&
+         (unsigned long long)n_nodes * (unsigned long long)d * 4ull < (1ull << 32);
+}
+
+int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* g_node, int64_t n_groups, const float* ent,
+                             const float* W_R, const float* rel, float* G_tab, float* logits,
+                             float* logits_csr, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_groups >= 0 && n_edges < INT32_MAX,
+                 "att_score_split: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  if (!kgat_att_score_split_supported(n_nodes, d, k, n_rel)) {
+    set_error("att_score_split: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+              kAttMaxRelLds, d, k, n_rel);
+    return KGAT_E_UNSUPPORTED;
+  }
+  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && ent && W_R && rel && logits,
+                 "att_score_split: null pointer");
+  KGAT_CHECK_ARG(n_groups == 0 || (g_node && G_tab), "att_score_split: null group table");
+  KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_split: logits_csr needs pos_g");
+  AttArgs a;
+  a.grid = 0;
+  a.st = as_stream(stream);
+  a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
+  a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
+  a.pos_g = pos_g;
+  a.table_bytes = (unsigned long long)n_nodes * (unsigned long long)d * 4ull;
+  a.n_edges = n_edges;
+  a.gid = gid; a.gptr = gptr; a.g_node = g_node; a.G_tab = G_tab;
+  return launch_att_split_any(d, a);
+}
+
 }  // extern "C"

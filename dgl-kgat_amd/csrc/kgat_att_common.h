@@ -90,6 +90,10 @@ struct AttArgs {
   float *logits, *logits_csr;
   const int32_t* pos_g;
   int waves_per_simd = 0;
+  // split form (head groups): gid per grouped position, gptr per relation, g_node per group,
+  // G table (n_groups x k)
+  const int32_t *gid = nullptr, *gptr = nullptr, *g_node = nullptr;
+  float* G_tab = nullptr;
   unsigned long long table_bytes = 0;
   int64_t n_edges = 0;
   bool needs_memset = true;
@@ -99,6 +103,7 @@ struct AttArgs {
 // kgat_att_persistent.hip (compiled with -amdgpu-mfma-vgpr-form: its epilogue reads the MFMA
 // results from VGPRs directly); returns KGAT_E_UNSUPPORTED for widths it does not cover.
 int launch_att_persistent_any(int d, bool accurate_tanh, const AttArgs& a);
+int launch_att_split_any(int d, const AttArgs& a);
 constexpr int kAttMaxRelLds = 4096;
 
 }  // namespace kgat

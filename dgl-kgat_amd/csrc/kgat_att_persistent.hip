@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
   const int32_t n_tiles = s_tptr[n_rel];
   const int lane = tid % kWave;
   const int i = lane & 15, q = lane >> 4;
+  const int32_t* __restrict__ pos_or_perm = logits_csr ? pos_g : perm;
   const int64_t n_waves = (int64_t)gridDim.x * (kAttThreads / kWave);
   const int64_t wv = (int64_t)blockIdx.x * (kAttThreads / kWave) + tid / kWave;
   const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(kAttThreads) void att_score_persistent_kernel(
       int32_t po = base + 4 * q + (i & 3);
       po = po < rend ? po : rend - 1;
       x.oe = perm[po];
-      x.op = logits_csr ? pos_g[po] : 0;
+      x.op = pos_or_perm[po];  // unconditional: a branch around a load makes the counted waits conservative
     };
     // 32-bit byte offsets from the table base (the launcher guarantees N*d*4 < 4 GiB): one
     // scalar base + one VGPR offset per row instead of 64-bit address arithmetic per load
@@ -212,6 +213,270 @@ static int launch_att_persistent(const AttArgs& a) {
   return KGAT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split form: the head projection tanh(e_h W_r + e_r) depends only on (head, relation).  With
+// every relation's edges sorted by destination, the edges of one (head, relation) pair are
+// consecutive ("head group"), so the projection is computed once per group (MODE_HEAD, writes
+// the G table) and the per-edge kernel (MODE_TAIL) only projects the tail and takes the dot
+// product with its group's G row - half the MFMAs and none of the tanh work per edge.  The
+// arithmetic per edge is unchanged (same fma chains, same reduction order), so results are
+// bit-identical to the one-kernel form.
+constexpr int MODE_HEAD = 1, MODE_TAIL = 2;
+#ifndef KGAT_ATT_SPLIT_RING
+#define KGAT_ATT_SPLIT_RING 1
+#endif
+
+template <int D_, int MODE>
+__global__ __launch_bounds__(kAttThreads) void att_split_kernel(
+    int n_rel, int64_t n_edges, const int32_t* __restrict__ seg_ptr /* gptr | rel_ptr */,
+    const int32_t* __restrict__ row_idx /* g_node | src_g */, const int32_t* __restrict__ gid,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ G_tab, float* __restrict__ logits, float* __restrict__ logits_csr) {
+  constexpr int K_ = D_;
+  constexpr int KS = D_ / 4, KT = K_ / 16;
+  __shared__ int32_t s_tptr[kAttMaxRelLds + 1];  // tile prefix per relation
+  const int tid = threadIdx.x;
+  for (int r = tid; r < n_rel; r += kAttThreads)
+    s_tptr[r + 1] = (seg_ptr[r + 1] - seg_ptr[r] + 15) >> 4;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t run = 0;
+    s_tptr[0] = 0;
+    for (int r = 0; r < n_rel; ++r) {
+      run += s_tptr[r + 1];
+      s_tptr[r + 1] = run;
+    }
+  }
+  __syncthreads();
+  const int32_t n_tiles = s_tptr[n_rel];
+  const int lane = tid % kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int32_t* __restrict__ pos_or_perm = logits_csr ? pos_g : perm;
+  const int64_t n_waves = (int64_t)gridDim.x * (kAttThreads / kWave);
+  const int64_t wv = (int64_t)blockIdx.x * (kAttThreads / kWave) + tid / kWave;
+  const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
+  const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
+
+  if (MODE == MODE_TAIL) {  // unscored tail of the edge list: logit 0
+    const int64_t tail0 = seg_ptr[n_rel];
+    const int64_t n_tail = n_edges - tail0;
+    for (int64_t p = tail0 + n_tail * wv / n_waves + lane; p < tail0 + n_tail * (wv + 1) / n_waves; p += kWave) {
+      logits[perm[p]] = 0.f;
+      if (logits_csr) logits_csr[pos_g[p]] = 0.f;
+    }
+  }
+  if (t_begin >= t_end) return;
+
+  float wreg[KS][KT];
+  float relv[KT];
+  int32_t t = t_begin;
+  while (t < t_end) {
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = __builtin_amdgcn_readfirstlane(lo);
+    const int32_t rbeg = __builtin_amdgcn_readfirstlane(seg_ptr[r]);
+    const int32_t rend = __builtin_amdgcn_readfirstlane(seg_ptr[r + 1]);
+    const int32_t tfirst = __builtin_amdgcn_readfirstlane(s_tptr[r]);
+    int32_t seg_end = __builtin_amdgcn_readfirstlane(s_tptr[r + 1]);
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    const int32_t n_seg = seg_end - t;
+    const int32_t pe0 = rbeg + ((t - tfirst) << 4);
+    {
+      const float* W = W_R + (size_t)r * D_ * K_;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int krow = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) wreg[s][c] = W[krow * K_ + 16 * c + i];
+      }
+      if (MODE == MODE_HEAD) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c) relv[c] = rel[(size_t)r * K_ + 16 * c + i] * kTwoLog2e;
+      }
+    }
+
+    // Per-tile index sets.  L = what the row/G loads of a tile need (source row, group ids);
+    // O = where the tile's results go (edge id, CSR position).  Both are clamped past the
+    // segment end so that every step issues the same loads.
+    struct alignas(KT * 4) GVec { float v[KT]; };  // G table row layout: [column slot i][tile c]
+    struct __attribute__((packed, aligned(4))) Gid4 { int32_t v[4]; };
+    struct LIdx { int32_t row, g[4]; };
+    struct OIdx { int32_t oe, op; };
+    auto load_l = [&](int32_t n, LIdx& x) {
+      n = n < n_seg ? n : n_seg - 1;
+      const int32_t base = pe0 + (n << 4);
+      int32_t pe = base + i;
+      pe = pe < rend ? pe : rend - 1;
+      x.row = row_idx[pe];
+      if (MODE == MODE_TAIL) {
+        // group ids of edges 4q .. 4q+3: one 16-byte load (positions past the relation's end
+        // read the next relation's ids or the array's padding; their results are never stored)
+        const Gid4 g4 = *reinterpret_cast<const Gid4*>(gid + base + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x.g[j] = g4.v[j];
+      }
+    };
+    auto load_o = [&](int32_t n, OIdx& x) {
+      if (MODE == MODE_TAIL) {
+        n = n < n_seg ? n : n_seg - 1;
+        int32_t po = pe0 + (n << 4) + 4 * q + (i & 3);
+        po = po < rend ? po : rend - 1;
+        x.oe = perm[po];
+        x.op = pos_or_perm[po];  // unconditional: a branch around a load makes the counted waits conservative
+      }
+    };
+    struct Buf { float a[KS]; float g[KT][4]; };
+    auto load_rows = [&](Buf& f, const LIdx& x) {
+      const char* base = reinterpret_cast<const char*>(ent);
+      const uint32_t o = (uint32_t)x.row * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+      for (int m = 0; m < D_ / 16; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(base + o + m * 64);
+        f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
+      }
+      if (MODE == MODE_TAIL) {  // the KT values of column slot i of group g sit together: one load per edge
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const GVec v = *reinterpret_cast<const GVec*>(G_tab + (size_t)x.g[j] * K_ + i * KT);
+#pragma unroll
+          for (int c = 0; c < KT; ++c) f.g[c][j] = v.v[c];
+        }
+      }
+    };
+    auto tile = [&](int32_t n, const Buf& f, const OIdx& x) {
+      floatx4 acc[KT];
+#pragma unroll
+      for (int cc = 0; cc < KT; ++cc) acc[cc] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int cc = 0; cc < KT; ++cc)
+          acc[cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s], wreg[s][cc], acc[cc], 0, 0, 0);
+      const int32_t item0 = pe0 + (n << 4) + 4 * q;  // this lane's rows: item0 + j
+      if (MODE == MODE_HEAD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (item0 + j < rend) {
+            GVec v;
+#pragma unroll
+            for (int cc = 0; cc < KT; ++cc) v.v[cc] = att_tanh_scaled(fmaf(acc[cc][j], kTwoLog2e, relv[cc]));
+            *reinterpret_cast<GVec*>(G_tab + (size_t)(item0 + j) * K_ + i * KT) = v;
+          }
+      } else {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < KT; ++cc)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) part[j] = fmaf(acc[cc][j], f.g[cc][j], part[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[j] = row16_sum(part[j]);
+        const float v = i == 0 ? part[0] : (i == 1 ? part[1] : (i == 2 ? part[2] : part[3]));
+        if (i < 4 && item0 + i < rend) {
+          logits[x.oe] = v;
+          if (logits_csr) logits_csr[x.op] = v;
+        }
+      }
+    };
+
+#if KGAT_ATT_SPLIT_RING
+    // Three-deep ring: step n computes tile n while the rows of tiles n+1 and n+2 are in
+    // flight (a tile is ~2,700 cycles of issue here, less than the gather latency under load,
+    // so one tile of look-ahead is not enough).  Inside a step the small index loads are
+    // issued BEFORE the row loads: vmcnt retires in order, and the next step's wait for
+    // those indices must not have to wait for this step's row loads behind them.
+    Buf b0, b1, b2;
+    LIdx lc, ln;
+    OIdx oc, on;
+    {
+      LIdx l0, l1;
+      load_l(0, l0);
+      load_l(1, l1);
+      load_l(2, lc);
+      load_o(0, oc);
+      load_rows(b0, l0);
+      load_rows(b1, l1);
+    }
+#define KGAT_SPLIT_STEP(BCUR, BFILL)                 \
+    {                                                \
+      load_l(n + 3, ln);                             \
+      load_o(n + 1, on);                             \
+      load_rows(BFILL, lc);                          \
+      __builtin_amdgcn_sched_barrier(0);             \
+      tile(n, BCUR, oc);                             \
+      __builtin_amdgcn_sched_barrier(0);             \
+      lc = ln;                                       \
+      oc = on;                                       \
+      ++n;                                           \
+    }
+    int32_t n = 0;
+    while (n < n_seg) {
+      KGAT_SPLIT_STEP(b0, b2)
+      if (n >= n_seg) break;
+      KGAT_SPLIT_STEP(b1, b0)
+      if (n >= n_seg) break;
+      KGAT_SPLIT_STEP(b2, b1)
+    }
+#undef KGAT_SPLIT_STEP
+#else
+    // no software prefetch: latency is hidden by wavefront-level parallelism (the register
+    // budget of this form admits 3-4 waves per SIMD)
+    for (int32_t n = 0; n < n_seg; ++n) {
+      LIdx l;
+      OIdx o;
+      Buf b;
+      load_l(n, l);
+      load_o(n, o);
+      load_rows(b, l);
+      tile(n, b, o);
+    }
+#endif
+    t = seg_end;
+  }
+}
+
+template <int D_, int MODE>
+static int launch_att_split(const AttArgs& a, const int32_t* seg_ptr, const int32_t* row_idx) {
+  static int blocks_per_cu = 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_split_kernel<D_, MODE>, kAttThreads, 0) !=
+            hipSuccess || nb < 1)
+      nb = 1;
+    blocks_per_cu = nb > 8 ? 8 : nb;
+  }
+  hipLaunchKernelGGL((att_split_kernel<D_, MODE>), dim3((unsigned)(cus * blocks_per_cu)), dim3(kAttThreads), 0,
+                     a.st, a.n_rel, a.n_edges, seg_ptr, row_idx, a.gid, a.perm, a.pos_g, a.ent, a.W_R, a.rel,
+                     a.G_tab, a.logits, a.logits_csr);
+  KGAT_CHECK_LAUNCH("att_split");
+  return KGAT_OK;
+}
+
+int launch_att_split_any(int d, const AttArgs& a) {
+  int rc;
+  switch (d) {
+    case 16:
+      rc = launch_att_split<16, MODE_HEAD>(a, a.gptr, a.g_node);
+      return rc != KGAT_OK ? rc : launch_att_split<16, MODE_TAIL>(a, a.rel_ptr, a.src_g);
+    case 32:
+      rc = launch_att_split<32, MODE_HEAD>(a, a.gptr, a.g_node);
+      return rc != KGAT_OK ? rc : launch_att_split<32, MODE_TAIL>(a, a.rel_ptr, a.src_g);
+    case 64:
+      rc = launch_att_split<64, MODE_HEAD>(a, a.gptr, a.g_node);
+      return rc != KGAT_OK ? rc : launch_att_split<64, MODE_TAIL>(a, a.rel_ptr, a.src_g);
+    default:
+      return KGAT_E_UNSUPPORTED;
+  }
+}
 
 int launch_att_persistent_any(int d, bool acc, const AttArgs& a) {
   switch (d) {

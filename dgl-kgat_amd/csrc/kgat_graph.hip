@@ -275,6 +275,35 @@ __global__ void degree_key_kernel(int64_t n, const int32_t* __restrict__ indptr,
   }
 }
 
+// ---- head groups: runs of equal (relation, destination) in a relation-grouped edge list whose
+// relations are internally sorted by destination
+__global__ void group_flag_kernel(int64_t n, int64_t n_scored, const int32_t* __restrict__ dst_g,
+                                  int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  flag[i] = (i < n_scored && (i == 0 || dst_g[i] != dst_g[i - 1])) ? 1 : 0;
+}
+__global__ void group_relstart_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
+                                      int32_t* __restrict__ flag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rel && rel_ptr[r] < rel_ptr[r + 1]) flag[rel_ptr[r]] = 1;
+}
+// ex = exclusive scan of the flags (E+1 entries): ex[i+1] - ex[i] recovers flag i
+__global__ void group_fill_kernel(int64_t n, const int32_t* __restrict__ ex,
+                                  const int32_t* __restrict__ dst_g, int32_t* __restrict__ gid,
+                                  int32_t* __restrict__ g_node) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t inc = ex[i + 1];
+  gid[i] = inc - 1;
+  if (inc != ex[i]) g_node[inc - 1] = dst_g[i];
+}
+__global__ void group_ptr_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
+                                 const int32_t* __restrict__ ex, int32_t* __restrict__ gptr) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= n_rel) gptr[r] = ex[rel_ptr[r]];
+}
+
 static inline unsigned blocks_for(int64_t n, int threads) {
   return (unsigned)((n + threads - 1) / threads);
 }
@@ -373,6 +402,48 @@ int kgat_group_by_relation(int64_t n_edges, int n_rel, const int32_t* etype, int
     set_error("group_by_relation: memcpy failed: %s", hipGetErrorString(e));
     return KGAT_E_HIP;
   }
+  return KGAT_OK;
+}
+
+size_t kgat_head_groups_workspace_bytes(int64_t n_edges) {
+  const size_t n = (size_t)(n_edges > 0 ? n_edges : 0) + 1;
+  return align_up(n * 4, 256) + align_up(scan_workspace_elems((int64_t)n) * 4, 256);
+}
+
+int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* dst_g,
+                     int32_t* gid, int32_t* gptr, int32_t* g_node, void* workspace,
+                     size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0 && n_edges < INT32_MAX - 1 && n_rel >= 0, "head_groups: bad size");
+  KGAT_CHECK_ARG(rel_ptr && gptr && workspace, "head_groups: null pointer");
+  KGAT_CHECK_ARG(n_edges == 0 || (dst_g && gid && g_node), "head_groups: null pointer");
+  if (workspace_bytes < kgat_head_groups_workspace_bytes(n_edges)) {
+    set_error("head_groups: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace);
+  int32_t* ex = cv.take<int32_t>((size_t)n_edges + 1);
+  int32_t* scan_ws = cv.take<int32_t>(scan_workspace_elems(n_edges + 1));
+  // (positions past rel_ptr[n_rel] - edges whose type is never scored - open groups of their
+  // own beyond gptr[n_rel]; nothing reads them, g_node is sized for them)
+  hipLaunchKernelGGL(group_flag_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0, st,
+                     n_edges, n_edges, dst_g, ex);
+  KGAT_CHECK_LAUNCH("group_flag");
+  if (n_rel > 0) {
+    hipLaunchKernelGGL(group_relstart_kernel, dim3(blocks_for(n_rel, 256)), dim3(256), 0, st, n_rel,
+                       rel_ptr, ex);
+    KGAT_CHECK_LAUNCH("group_relstart");
+  }
+  int rc = exclusive_scan_i32(ex, n_edges + 1, scan_ws, st);
+  if (rc != KGAT_OK) return rc;
+  if (n_edges > 0) {
+    hipLaunchKernelGGL(group_fill_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st, n_edges,
+                       (const int32_t*)ex, dst_g, gid, g_node);
+    KGAT_CHECK_LAUNCH("group_fill");
+  }
+  hipLaunchKernelGGL(group_ptr_kernel, dim3(blocks_for(n_rel + 1, 256)), dim3(256), 0, st, n_rel,
+                     rel_ptr, (const int32_t*)ex, gptr);
+  KGAT_CHECK_LAUNCH("group_ptr");
   return KGAT_OK;
 }
 

@@ -79,7 +79,7 @@ class Frame(MutableMapping):
 
 
 CSR = namedtuple("CSR", "indptr col eid row_of")
-RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g pos_g")
+RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g pos_g gid gptr g_node n_groups g_tab")
 
 
 class _Structure:
@@ -165,17 +165,23 @@ class _Structure:
             c["order"] = ops.row_order_by_degree(self.csr(device).indptr)
         return c["order"]
 
-    def rel_groups(self, etype, n_rel):
-        """Edges grouped by relation (kgat_group_by_relation) + grouped endpoint arrays."""
+    def rel_groups(self, etype, n_rel, k=None):
+        """Edges grouped by relation and, inside a relation, sorted by destination (the CSR-ordered
+        edge list grouped stably by relation, kgat_group_by_relation), with the grouped endpoint
+        arrays, the CSR position of every grouped position, and the (head, relation) groups the
+        split attention kernels share projections over (kgat_head_groups)."""
         c = self._cache(etype.device)
         key = ("rel", etype.data_ptr(), etype._version, int(n_rel))
         hit = c.get("rel_groups")
         if hit is None or hit[0] != key:
-            et32 = etype if etype.dtype == torch.int32 else etype.to(torch.int32)
-            rel_ptr, perm = ops.group_by_relation(et32.contiguous(), int(n_rel))
-            src, dst = self.coo(etype.device)
-            hit = (key, RelGroups(rel_ptr, perm, ops.gather(perm, src), ops.gather(perm, dst),
-                                   ops.gather(perm, self.csr_pos(etype.device))), etype)
+            dev = etype.device
+            csr = self.csr(dev)
+            et32 = (etype if etype.dtype == torch.int32 else etype.to(torch.int32)).contiguous()
+            rel_ptr, idx = ops.group_by_relation(ops.gather(csr.eid, et32), int(n_rel))
+            dst_g = ops.gather(idx, csr.row_of)
+            gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+            hit = (key, RelGroups(rel_ptr, ops.gather(idx, csr.eid), ops.gather(idx, csr.col), dst_g, idx,
+                                  gid, gptr, g_node, n_groups, {}), etype)
             c["rel_groups"] = hit
         return hit[1]
 
@@ -423,9 +429,23 @@ class DGLGraph:
         dev = ent.device
         csr = st.csr(dev)
         groups = st.rel_groups(etype.to(dev), W_R.shape[0])
-        _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
-                                      ent.detach().contiguous(), W_R.detach().contiguous(),
-                                      rel.detach().contiguous(), pos_g=groups.pos_g, algo=algo)
+        n_rel, d, k = W_R.shape
+        ent_c, W_c, rel_c = ent.detach().contiguous(), W_R.detach().contiguous(), rel.detach().contiguous()
+        # split form (head projection once per (head, relation) group) when the groups actually
+        # share work: >= 2 edges per group on average; otherwise the one-kernel form
+        shares = 2 * groups.n_groups <= st.n_edges
+        if algo in ("auto", "split") and ops.att_score_split_supported(st.n_nodes, d, k, n_rel) and \
+                (shares or algo == "split"):
+            g_tab = groups.g_tab.get(k)  # scratch for the per-group projections, kept with the graph
+            if g_tab is None:
+                g_tab = groups.g_tab[k] = torch.empty((max(groups.n_groups, 1), k), dtype=torch.float32, device=dev)
+            _, logits_csr = ops.att_score_split(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
+                                                groups.gid, groups.gptr, groups.g_node, groups.n_groups,
+                                                ent_c, W_c, rel_c, g_tab=g_tab)
+        else:
+            _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
+                                          ent_c, W_c, rel_c, pos_g=groups.pos_g,
+                                          algo="auto" if algo in ("auto", "split") else algo)
         a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
                                     want_out=True, want_csr=True)
         st.remember_weight(a, a_csr)

@@ -175,6 +175,55 @@ def att_score(n_nodes, rel_ptr, perm, src_g, dst_g, ent, W_R, rel, pos_g=None, a
     return logits, logits_csr
 
 
+def head_groups(rel_ptr, dst_g):
+    """(gid, gptr, g_node, n_groups) of a relation-grouped, destination-sorted edge list.
+    Reads the group count back to the host (one sync, once per graph)."""
+    rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr")
+    dst_g = _need(dst_g, torch.int32, "dst_g")
+    lib = _lib.load()
+    e, n_rel, dev = dst_g.numel(), rel_ptr.numel() - 1, dst_g.device
+    gid_pad = torch.zeros(e + 16, dtype=torch.int32, device=dev)  # kernels read 16-byte groups: 16 ids of slack
+    gid = gid_pad[:e]
+    gptr = torch.empty(n_rel + 1, dtype=torch.int32, device=dev)
+    g_node = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.kgat_head_groups_workspace_bytes(e), dev)
+    check(lib.kgat_head_groups(e, n_rel, _ptr(rel_ptr), _ptr(dst_g), _ptr(gid), _ptr(gptr), _ptr(g_node),
+                               _ptr(ws), ws.numel(), _stream(dst_g)), "kgat_head_groups")
+    n_groups = int(gptr[n_rel].item())
+    return gid, gptr, g_node[:max(n_groups, 1)].clone(), n_groups
+
+
+def att_score_split_supported(n_nodes, d, k, n_rel):
+    return bool(_lib.load().kgat_att_score_split_supported(int(n_nodes), int(d), int(k), int(n_rel)))
+
+
+def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups, ent, W_R, rel,
+                    want_csr=True, g_tab=None):
+    """Attention logits via head groups (see kgat_att_score_split_f32).  Returns
+    (logits edge-id order, logits CSR order or None)."""
+    ent = _need(ent, torch.float32, "ent")
+    n_rel, d, k = W_R.shape
+    W_R = _need(W_R, torch.float32, "W_R")
+    rel = _need(rel, torch.float32, "rel", (n_rel, k))
+    perm = _need(perm, torch.int32, "perm")
+    e = perm.numel()
+    for name, t in (("src_g", src_g), ("pos_g", pos_g), ("gid", gid)):
+        _need(t, torch.int32, name, (e,))
+    _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
+    _need(gptr, torch.int32, "gptr", (n_rel + 1,))
+    _need(g_node, torch.int32, "g_node")
+    if g_tab is None:
+        g_tab = torch.empty((max(n_groups, 1), k), dtype=torch.float32, device=ent.device)
+    logits = torch.empty(e, dtype=torch.float32, device=ent.device)
+    logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
+    with _timed("att_score", (e, d, k)):
+        check(_lib.load().kgat_att_score_split_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
+                                                   _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), n_groups,
+                                                   _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(g_tab), _ptr(logits),
+                                                   _ptr(logits_csr), _stream(ent)), "kgat_att_score_split_f32")
+    return logits, logits_csr
+
+
 def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
                  want_csr=False):
     """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
@@ -292,6 +341,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported",
            "KGATLibraryError"]

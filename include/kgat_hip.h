@@ -111,6 +111,32 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
                        float* logits, float* logits_csr, const int32_t* pos_g, int algo,
                        kgat_stream_t stream);
 
+/* Head groups for the split attention path.  Input: a relation-grouped edge list whose
+ * relations are internally sorted by destination (group the CSR-ordered edge list by relation:
+ * rel_ptr[R+1], dst_g[E]).  Consecutive positions with the same (relation, destination) form
+ * one group: gid[E] = group of each position, gptr[R+1] = first group of each relation
+ * (gptr[R] = number of groups over the scored relations), g_node[<= E] = destination (head)
+ * of each group.  The attention kernels read gid in 16-byte pieces: allocate 16 entries of
+ * slack after gid[E-1] holding valid group ids (e.g. 0). */
+size_t kgat_head_groups_workspace_bytes(int64_t n_edges);
+int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* dst_g,
+                     int32_t* gid, int32_t* gptr, int32_t* g_node, void* workspace,
+                     size_t workspace_bytes, kgat_stream_t stream);
+
+/* Same logits as kgat_att_score_f32, computed in two launches: tanh(ent[h] W_R[r] + rel[r]) once
+ * per (head, relation) group into G_tab (n_groups x k floats, caller scratch), then per edge
+ * the tail projection and its dot product with the group's row.  The head projection and all
+ * tanh work are shared by the edges of a group (3.8 edges per group on the amazon-book-shaped
+ * CKG).  Arithmetic per edge is unchanged.  Needs d == k in {16,32,64}
+ * (kgat_att_score_split_supported). */
+int kgat_att_score_split_supported(int64_t n_nodes, int d, int k, int n_rel);
+int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* g_node, int64_t n_groups, const float* ent,
+                             const float* W_R, const float* rel, float* G_tab, float* logits,
+                             float* logits_csr, kgat_stream_t stream);
+
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
  *   a[e] = exp(s[e] - max_{e'->dst e} s[e']) / sum_{e'->dst e} exp(s[e'] - max)

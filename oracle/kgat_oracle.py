@@ -28,7 +28,7 @@ index.  All per-edge arrays handed in or out are in edge-id order.
 import numpy as np
 
 __all__ = [
-    "csr_from_coo", "group_by_relation", "att_score", "edge_softmax",
+    "csr_from_coo", "group_by_relation", "head_groups", "att_score", "edge_softmax",
     "spmm_u_mul_e_sum", "spmm_backward_x", "sddmm_dot", "bi_interaction",
     "l2_normalize", "gnn_forward", "compute_attention",
     "dense_spmm", "dense_edge_softmax", "edge_softmax_backward",
@@ -73,6 +73,28 @@ def group_by_relation(etype, n_rel):
     rel_ptr = np.zeros(n_rel + 1, dtype=np.int64)
     np.cumsum(counts, out=rel_ptr[1:])
     return rel_ptr.astype(np.int32), perm.astype(np.int32)
+
+
+def head_groups(rel_ptr, dst_g):
+    """Runs of equal (relation, destination) in a relation-grouped edge list whose relations
+    are sorted by destination: (gid[E], gptr[R+1], g_node[n_groups]).  Structure used by the
+    split attention kernels to evaluate ``tanh(ent[h] W_r + e_r)`` (reference models.py:141-143)
+    once per (head, relation) instead of once per edge; only positions below rel_ptr[R] count."""
+    rel_ptr = np.asarray(rel_ptr, np.int64)
+    dst_g = np.asarray(dst_g, np.int64)
+    n_rel, scored = len(rel_ptr) - 1, int(rel_ptr[-1])
+    flag = np.zeros(len(dst_g) + 1, np.int64)
+    if scored:
+        flag[0] = 1
+        flag[1:scored] = dst_g[1:scored] != dst_g[:scored - 1]
+        starts = rel_ptr[:-1][rel_ptr[:-1] < rel_ptr[1:]]
+        flag[starts] = 1
+    inc = np.cumsum(flag)
+    gid = (inc[:len(dst_g)] - 1).astype(np.int32)
+    ex = np.concatenate([[0], inc])
+    gptr = ex[rel_ptr].astype(np.int32)
+    heads = np.nonzero(flag[:scored])[0]
+    return gid, gptr, dst_g[heads].astype(np.int32)
 
 
 # ----------------------------------------------------------------------- attention

@@ -69,6 +69,16 @@ def main():
         rel = torch.randn(R, D, generator=g).to(dev)
         algos = (args.algos or "mfma_v0,mfma_v2,mfma_v4,mfma_v5,mfma_v8").split(",")
         fns = {a: (lambda a=a: ops.att_score(n, rel_ptr, perm, sg, dg, ent, W, rel, pos_g=pos, algo=a)) for a in algos}
+        # split form: head projections once per (head, relation) group
+        et_csr = ops.gather(eid, et)
+        rp2, idx2 = ops.group_by_relation(et_csr, R)
+        perm2, sg2, dg2 = ops.gather(idx2, eid), ops.gather(idx2, col), ops.gather(idx2, row_of)
+        gid, gptr, g_node, n_groups = ops.head_groups(rp2, dg2)
+        g_tab = torch.empty((max(n_groups, 1), D), device=dev)
+        print("head groups: %d (%.2f edges per group)" % (n_groups, E / max(n_groups, 1)))
+        if ops.att_score_split_supported(n, D, D, R):
+            fns["split"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab)
+            algos = algos + ["split"]
         if args.same_rows:  # diagnostic: every edge reads rows 0..15 (cache resident): isolates gather latency
             sz, dz = sg % 16, dg % 16
             for a in algos:

@@ -249,6 +249,52 @@ def test_att_score_mfma_vs_oracle(K, dev, d):
         assert rel_err_inf(logits, ref) < 1e-5, algo
 
 
+def _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev):
+    """The structure DGLGraph.rel_groups builds: CSR-ordered edges grouped stably by relation."""
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    rel_ptr, idx = ops.group_by_relation(ops.gather(eid, t32(et, dev)), R)
+    perm, src_g, dst_g = ops.gather(idx, eid), ops.gather(idx, col), ops.gather(idx, row_of)
+    return rel_ptr, perm, src_g, dst_g, idx
+
+
+@pytest.mark.parametrize("d", [16, 32, 64])
+def test_att_split_head_groups(K, dev, d):
+    """Head-group structure bit-exact vs the oracle; split attention == one-kernel attention
+    bit for bit (same arithmetic per edge) and within tolerance of the fp64 oracle."""
+    from dgl_kgat_amd import ops
+    n, e, R = 700, 30000, 6
+    src, dst = random_graph(12, n, e, hub=4000, isolated_tail=20)
+    rng = np.random.default_rng(13)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)
+    et[rng.choice(e, e // 2, replace=False)] = 3
+    et[et == 1] = 2  # an empty relation in the middle
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    ogid, ogptr, ognode = orc.head_groups(rel_ptr.cpu().numpy(), dst_g.cpu().numpy())
+    scored = int(rel_ptr[-1])
+    assert n_groups == len(ognode) == int(ogptr[-1])
+    assert np.array_equal(gid.cpu().numpy()[:scored], ogid[:scored])
+    assert np.array_equal(gptr.cpu().numpy(), ogptr) and np.array_equal(g_node.cpu().numpy()[:n_groups], ognode)
+    # every scored position's group has its (relation, destination)
+    perm_h, et_g = perm.cpu().numpy(), et[perm.cpu().numpy()]
+    assert np.array_equal(ognode[ogid[:scored]], dst[perm_h[:scored]])
+    assert np.all(np.diff(ogid[:scored]) >= 0) and np.all(et_g[:scored][1:] >= et_g[:scored][:-1])
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    split, split_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                           tf(ent, dev), tf(W, dev), tf(rel, dev))
+    full, full_csr = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent, dev), tf(W, dev), tf(rel, dev),
+                                   pos_g=pos_g, algo="mfma")
+    assert torch.equal(split, full) and torch.equal(split_csr, full_csr)
+    split = split.cpu().numpy()
+    assert np.all(split[(et < 0) | (et >= R)] == 0)
+    assert rel_err_inf(split, ref) < 1e-5
+    _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    assert np.array_equal(split_csr.cpu().numpy(), split[eid.cpu().numpy()])
+
+
 def _model_from_golden(K, g, dev):
     d, k = g["entity_embed"].shape[1], g["W_R"].shape[2]
     hidden = g["W2"][0].shape[0]
