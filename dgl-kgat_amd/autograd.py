@@ -81,7 +81,8 @@ class _EdgeSoftmax(torch.autograd.Function):
         if flat.dtype != torch.float32:
             raise TypeError("logits must be float32, got %s" % flat.dtype)
         csr = st.csr(flat.device)
-        a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, flat, want_out=True, want_csr=True)
+        _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, flat, want_out=False, want_csr=True)
+        a = ops.gather(st.csr_pos(flat.device), a_csr)  # back to edge-id order
         st.remember_weight(a, a_csr)
         ctx.g = g
         ctx.save_for_backward(a)

@@ -10,10 +10,11 @@
 //  * Inside a wavefront the lanes of one destination form a contiguous segment; a segmented
 //    shuffle scan reduces them and only the last lane of each segment touches global memory.
 //  * Pass 1: row max via integer-ordered atomic max (order independent).
-//    Pass 2: row sum of exp(s - M) accumulated in 2^-40 fixed point with 64-bit integer
-//            atomic adds - integer addition is associative, so the sum does not depend on
-//            arrival order and the result is bitwise reproducible (a float atomic add would
-//            not be).  exp(s - M) <= 1, so 2^24 edges per destination fit in 64 bits.
+//    Pass 2: row sum of exp(s - M): per-wave partials in fp32 (fixed order), combined across
+//            waves in 2^-40 fixed point with 64-bit integer atomic adds - integer addition is
+//            associative, so the sum does not depend on arrival order and the result is bitwise
+//            reproducible (a float atomic add would not be).  A partial is <= 64, so 2^18
+//            waves (2^24 edges) per destination fit in 64 bits.
 //    Pass 3: normalise, write in CSR order (consumed by the SpMM) and/or edge-id order.
 #include <math.h>
 
@@ -40,25 +41,62 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+// Lanes of one destination form a contiguous segment of the wavefront (edges are sorted by
+// destination).  Segment bounds come from one neighbour exchange + one ballot; the reductions
+// below then need only the value shuffles (6 steps), not a second shuffle of the row ids.
+struct WaveSeg {
+  int start;  // first lane of this lane's segment
+  bool last;  // this lane is the segment's last lane
+};
+__device__ __forceinline__ WaveSeg wave_segment(int32_t r, int lane) {
+  const int32_t rprev = __shfl_up(r, 1, kWave);
+  const unsigned long long heads = __ballot(lane == 0 || rprev != r);
+  const unsigned long long upto = (lane == kWave - 1) ? ~0ull : ((2ull << lane) - 1ull);  // bits 0..lane
+  WaveSeg s;
+  s.start = 63 - __clzll(heads & upto);
+  s.last = (lane == kWave - 1) || ((heads >> (lane + 1)) & 1ull);
+  return s;
+}
+
+// Every wavefront handles kItems consecutive 64-edge chunks; the loads of all chunks are issued
+// before the first reduction so that the two dependent memory latencies of a chunk (row id ->
+// row statistic) are paid once per wavefront, not once per chunk.
+constexpr int kItems = 4;
+constexpr int kBlockEdges = 256 * kItems;
+
+__device__ __forceinline__ int64_t chunk_pos(int64_t e0, int k) {
+  // block tile = 4 waves x kItems chunks of 64 edges; wave w owns chunks [w*kItems, (w+1)*kItems)
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  return e0 + (int64_t)blockIdx.x * kBlockEdges + (int64_t)(wave * kItems + k) * kWave + lane;
+}
+
 template <bool IN_CSR>
 __global__ __launch_bounds__(256) void softmax_max_kernel(int64_t e0, int64_t e1,
                                                           const int32_t* __restrict__ row_of,
                                                           const int32_t* __restrict__ eid,
                                                           const float* __restrict__ logits,
                                                           float* __restrict__ M) {
-  const int64_t p = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
-  const bool valid = p < e1;
-  const int32_t r = valid ? row_of[p] : -1;
-  float v = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : -INFINITY;
+  int32_t r[kItems];
+  float v[kItems];
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const float up = __shfl_up(v, off, kWave);
-    const int32_t rup = __shfl_up(r, off, kWave);
-    if (lane >= off && rup == r) v = fmaxf(v, up);
+  for (int k = 0; k < kItems; ++k) {
+    const int64_t p = chunk_pos(e0, k);
+    const bool valid = p < e1;
+    r[k] = valid ? row_of[p] : -1;
+    v[k] = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : -INFINITY;
   }
-  const int32_t rnext = __shfl_down(r, 1, kWave);
-  if (valid && (lane == kWave - 1 || rnext != r)) atomic_max_f32(&M[r], v);
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const WaveSeg sg = wave_segment(r[k], lane);
+    float x = v[k];
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const float up = __shfl_up(x, off, kWave);
+      if (lane - off >= sg.start) x = fmaxf(x, up);
+    }
+    if (r[k] >= 0 && sg.last) atomic_max_f32(&M[r[k]], x);
+  }
 }
 
 template <bool IN_CSR>
@@ -68,23 +106,31 @@ __global__ __launch_bounds__(256) void softmax_sum_kernel(int64_t e0, int64_t e1
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ M,
                                                           unsigned long long* __restrict__ Z) {
-  const int64_t p = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
-  const bool valid = p < e1;
-  const int32_t r = valid ? row_of[p] : -1;
-  unsigned long long q = 0ull;
-  if (valid) {
-    const float s = IN_CSR ? logits[p] : logits[eid[p]];
-    q = __float2ull_rn(expf(s - M[r]) * kFixScale);
+  int32_t r[kItems];
+  float s[kItems], m[kItems];
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const int64_t p = chunk_pos(e0, k);
+    const bool valid = p < e1;
+    r[k] = valid ? row_of[p] : -1;
+    s[k] = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : 0.f;
   }
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned long long up = __shfl_up(q, off, kWave);
-    const int32_t rup = __shfl_up(r, off, kWave);
-    if (lane >= off && rup == r) q += up;
+  for (int k = 0; k < kItems; ++k) m[k] = r[k] >= 0 ? M[r[k]] : 0.f;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    float x = r[k] >= 0 ? expf(s[k] - m[k]) : 0.f;
+    const WaveSeg sg = wave_segment(r[k], lane);
+    // in-wave partial in fp32 (fixed scan order, <= 64 terms each <= 1); only the cross-wave
+    // combination has to be order independent, so the partial is added in 2^-40 fixed point
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const float up = __shfl_up(x, off, kWave);
+      if (lane - off >= sg.start) x += up;
+    }
+    if (r[k] >= 0 && sg.last) atomicAdd(&Z[r[k]], __float2ull_rn(x * kFixScale));
   }
-  const int32_t rnext = __shfl_down(r, 1, kWave);
-  if (valid && (lane == kWave - 1 || rnext != r)) atomicAdd(&Z[r], q);
 }
 
 template <bool IN_CSR>
@@ -93,15 +139,30 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
     const float* __restrict__ logits, const float* __restrict__ M,
     const unsigned long long* __restrict__ Z, float* __restrict__ out,
     float* __restrict__ out_csr) {
-  const int64_t p = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= e1) return;
-  const int32_t r = row_of[p];
-  const int32_t e = eid ? eid[p] : (int32_t)p;
-  const float s = IN_CSR ? logits[p] : logits[e];
-  const float z = (float)Z[r] * kFixInv;
-  const float a = expf(s - M[r]) / z;
-  if (out_csr) out_csr[p] = a;
-  if (out) out[e] = a;
+  int32_t r[kItems], e[kItems];
+  float s[kItems], m[kItems];
+  unsigned long long z[kItems];
+  int64_t p[kItems];
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    p[k] = chunk_pos(e0, k);
+    const bool valid = p[k] < e1;
+    r[k] = valid ? row_of[p[k]] : -1;
+    e[k] = valid ? (eid ? eid[p[k]] : (int32_t)p[k]) : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    s[k] = r[k] >= 0 ? (IN_CSR ? logits[p[k]] : logits[e[k]]) : 0.f;
+    m[k] = r[k] >= 0 ? M[r[k]] : 0.f;
+    z[k] = r[k] >= 0 ? Z[r[k]] : 1ull;
+  }
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    if (r[k] < 0) continue;
+    const float a = expf(s[k] - m[k]) / ((float)z[k] * kFixInv);
+    if (out_csr) out_csr[p[k]] = a;
+    if (out) out[e[k]] = a;
+  }
 }
 
 // Backward (DGL 0.4.x EdgeSoftmax.backward): grad_s = a*g - a * sum_row(a*g).
@@ -163,7 +224,7 @@ int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
   float* M = cv.take<float>((size_t)n_nodes);
   unsigned long long* Z = cv.take<unsigned long long>((size_t)n_nodes);
   const int64_t ne = e_end - e_begin;
-  const unsigned eb = (unsigned)((ne + 255) / 256);
+  const unsigned eb = (unsigned)((ne + kBlockEdges - 1) / kBlockEdges);
   hipLaunchKernelGGL(softmax_init_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0,
                      st, n_nodes, M, Z);
   KGAT_CHECK_LAUNCH("softmax_init");

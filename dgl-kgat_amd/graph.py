@@ -446,7 +446,8 @@ class DGLGraph:
             _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                           ent_c, W_c, rel_c, pos_g=groups.pos_g,
                                           algo="auto" if algo in ("auto", "split") else algo)
-        a, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
-                                    want_out=True, want_csr=True)
+        _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
+                                    want_out=False, want_csr=True)
+        a = ops.gather(st.csr_pos(dev), a_csr)  # edge-id order: coalesced writes, cached reads
         st.remember_weight(a, a_csr)
         return a.unsqueeze(1)
