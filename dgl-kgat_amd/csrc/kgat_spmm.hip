@@ -160,6 +160,218 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second form of the merge kernel (weights in CSR order).  Same decomposition, combine and
+// summation order as spmm_merge_kernel; what changes is the instruction count per edge, which
+// - not the gather - bounds the first form (with every gather hitting L1 it still ran at 70 %
+// of its time): the tile's (col, row, w) triples are staged once into LDS as 16-byte records
+// (coalesced dword loads, one ds_write_b128 per edge), so an edge costs one ds_read_b128
+// broadcast instead of three ds_bpermute; a group of four edges takes a wave-level "no lane
+// group changes row" fast path (one compare + ballot instead of a divergent branch per edge);
+// the FMAs are packed (v_pk_fma_f32); the next group's records and X rows are requested before
+// the current group is consumed.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+#ifdef KGAT_SPMM_STAMPS
+// Diagnostic build only (-DKGAT_SPMM_STAMPS): per-tile phase stamps of the merge kernel, read
+// back by scripts/micro/spmm_stamps.py.  Never compiled into the shipped library.
+__device__ unsigned long long* g_spmm_stamps = nullptr;
+#define KGAT_STAMP(k)                                                                  \
+  do {                                                                                 \
+    if (g_spmm_stamps && threadIdx.x == 0)                                             \
+      g_spmm_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define KGAT_STAMP(k) do { } while (0)
+#endif
+
+struct alignas(16) EdgeRec {
+  int32_t c;  // source row
+  int32_t r;  // destination row
+  float w;
+  int32_t pad;
+};
+
+template <int LPR, int C, bool MUL_SELF>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
+    int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ row_of, const float4* __restrict__ X, const float* __restrict__ w,
+    float4* __restrict__ out, float4* __restrict__ bpart) {
+  constexpr int NSUB = SpmmGeom<LPR>::NSUB;
+  constexpr int TE = NSUB * C;
+#ifndef KGAT_SPMM_GROUP
+#define KGAT_SPMM_GROUP 4
+#endif
+#ifndef KGAT_SPMM_PREFETCH
+#define KGAT_SPMM_PREFETCH 1
+#endif
+  constexpr int G = (C % KGAT_SPMM_GROUP == 0) ? KGAT_SPMM_GROUP : 4;  // edges per group
+  static_assert(C % G == 0, "run length must be a multiple of the group size");
+  __shared__ EdgeRec s_rec[TE];
+  __shared__ float4 s_part[NSUB][2][LPR];
+  __shared__ int32_t s_row[NSUB][2];
+
+  const int tid = threadIdx.x;
+  const int sub = tid / LPR, sl = tid % LPR;
+  const int64_t tile0 = e0 + (int64_t)blockIdx.x * TE;
+  const int64_t tile1 = (tile0 + TE < e1) ? tile0 + TE : e1;
+  const int n_tile = (int)(tile1 - tile0);
+  KGAT_STAMP(0);
+
+  for (int k = tid; k < TE; k += kSpmmThreads) {
+    EdgeRec rec;
+    if (k < n_tile) {
+      const int64_t p = tile0 + k;
+      rec.c = col[p];
+      rec.r = row_of[p];
+      rec.w = w[p];
+    } else {
+      rec.c = 0;
+      rec.r = -1;
+      rec.w = 0.f;
+    }
+    rec.pad = 0;
+    s_rec[k] = rec;
+  }
+  __syncthreads();
+  KGAT_STAMP(1);
+
+  const EdgeRec* run = s_rec + sub * C;
+  int n_run = n_tile - sub * C;
+  n_run = n_run < 0 ? 0 : (n_run > C ? C : n_run);
+  const int ng = n_run / G;
+
+  int32_t cur_row = n_run > 0 ? run[0].r : -1;
+  bool head_done = false;
+  float2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+
+  auto flush = [&]() {  // the open row ends here
+    const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+    if (!head_done) {
+      s_part[sub][0][sl] = acc;
+      if (sl == 0) s_row[sub][0] = cur_row;
+      head_done = true;
+    } else {
+      store_row<LPR, MUL_SELF>(out, X, cur_row, row0, sl, acc);
+    }
+    a01 = (float2v){0.f, 0.f};
+    a23 = (float2v){0.f, 0.f};
+  };
+  auto accum = [&](float wv, const float4& x) {
+    const float2v ww = {wv, wv};
+    a01 = __builtin_elementwise_fma(ww, (float2v){x.x, x.y}, a01);
+    a23 = __builtin_elementwise_fma(ww, (float2v){x.z, x.w}, a23);
+  };
+  auto load_group = [&](int g, EdgeRec (&rec)[G], float4 (&x)[G]) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) rec[i] = run[g * G + i];
+#pragma unroll
+    for (int i = 0; i < G; ++i) x[i] = X[(size_t)rec[i].c * LPR + sl];
+  };
+  auto consume = [&](const EdgeRec (&rec)[G], const float4 (&x)[G]) {
+    // rows are sorted: the group stays inside the open row iff its last edge does
+    if (__ballot(rec[G - 1].r != cur_row) == 0ull) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) accum(rec[i].w, x[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        if (rec[i].r != cur_row) {
+          flush();
+          cur_row = rec[i].r;
+        }
+        accum(rec[i].w, x[i]);
+      }
+    }
+  };
+
+#if KGAT_SPMM_PREFETCH
+  EdgeRec ra[G], rb[G];
+  float4 xa[G], xb[G];
+  if (ng > 0) load_group(0, ra, xa);
+  for (int g = 0; g < ng; g += 2) {
+    if (g + 1 < ng) load_group(g + 1, rb, xb);
+    consume(ra, xa);
+    if (g + 1 >= ng) break;
+    if (g + 2 < ng) load_group(g + 2, ra, xa);
+    consume(rb, xb);
+  }
+#else
+  for (int g = 0; g < ng; ++g) {
+    EdgeRec ra[G];
+    float4 xa[G];
+    load_group(g, ra, xa);
+    consume(ra, xa);
+  }
+#endif
+  for (int j = ng * G; j < n_run; ++j) {  // only the last run of the edge range is ragged
+    const EdgeRec rec = run[j];
+    const float4 x = X[(size_t)rec.c * LPR + sl];
+    if (rec.r != cur_row) {
+      flush();
+      cur_row = rec.r;
+    }
+    accum(rec.w, x);
+  }
+
+  KGAT_STAMP(2);
+  // the run's last open row: head slot if the run never changed row, else tail slot
+  {
+    const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+    if (!head_done) {
+      s_part[sub][0][sl] = acc;
+      if (sl == 0) {
+        s_row[sub][0] = cur_row;  // -1 for an empty run
+        s_row[sub][1] = -1;
+      }
+    } else {
+      s_part[sub][1][sl] = acc;
+      if (sl == 0) s_row[sub][1] = cur_row;
+    }
+  }
+  __syncthreads();
+
+  // Combine of the run-boundary partials, in parallel: the 2*NSUB partials are in run order and
+  // the partials of one row are consecutive.  Lane group s looks at its own two entries; an
+  // entry that starts a row segment (its row differs from the previous valid entry's) sums
+  // the segment in entry order and emits it.  Typical segments have two entries (tail of a run
+  // + head of the next); a hub row's long segment is walked by one lane group, like before.
+  // (One lane group walking all 2*NSUB entries used to take a fifth of a tile's time, with
+  // the dependent X[row] load of the h*h_N epilogue serialised behind every emit.)
+  KGAT_STAMP(3);
+  {
+    const int32_t first_row = s_rec[0].r;
+    const int32_t last_row = s_rec[n_tile - 1].r;
+    float4* bp = bpart + (size_t)blockIdx.x * 2 * LPR;
+    constexpr int NE = 2 * NSUB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = 2 * sub + t;
+      const int32_t rr = s_row[sub][t];
+      if (rr < 0) continue;
+      // previous valid entry: entry k-1, or k-2 when k-1 is an unused tail slot
+      int32_t prev = -1;
+      if (k > 0) {
+        prev = s_row[(k - 1) >> 1][(k - 1) & 1];
+        if (prev < 0 && k > 1) prev = s_row[(k - 2) >> 1][(k - 2) & 1];
+      }
+      if (prev == rr) continue;  // not the start of its segment
+      float4 v = s_part[sub][t][sl];
+      for (int k2 = k + 1; k2 < NE; ++k2) {
+        const int32_t r2 = s_row[k2 >> 1][k2 & 1];
+        if (r2 < 0) continue;
+        if (r2 != rr) break;
+        v = add4(v, s_part[k2 >> 1][k2 & 1][sl]);
+      }
+      if (rr == first_row) bp[sl] = v;
+      else if (rr == last_row) bp[LPR + sl] = v;
+      else store_row<LPR, MUL_SELF>(out, X, rr, row0, sl, v);
+    }
+  }
+  KGAT_STAMP(4);
+  KGAT_STAMP(5);
+}
+
 // Finish: (a) rows that are first/last in some tile: sum their tile partials in tile order;
 // (b) rows without in-edges: write zeros.  One wavefront per (tile, slot) item for (a).
 template <int LPR, int C, bool MUL_SELF>
@@ -302,11 +514,13 @@ struct SpmmArgs {
   hipStream_t st;
 };
 
-constexpr int kRunLen = 64;  // C: edges per subgroup run in the merge kernel
+// C: edges per lane-group run in the merge kernels; tiles are NSUB * C <= 2048 edges (the
+// LDS record stage of the second form holds one tile)
+constexpr int run_len(int lpr) { return lpr >= 8 ? 64 : (lpr == 4 ? 32 : (lpr == 2 ? 16 : 8)); }
 
 template <int LPR>
 static int64_t merge_tiles(int64_t n_edges) {
-  constexpr int TE = SpmmGeom<LPR>::NSUB * kRunLen;
+  constexpr int TE = SpmmGeom<LPR>::NSUB * run_len(LPR);
   return (n_edges + TE - 1) / TE;
 }
 
@@ -321,16 +535,22 @@ static int launch_merge(const SpmmArgs& a) {
   }
   float4* bpart = static_cast<float4*>(a.ws);
   if (tiles > 0) {
-    hipLaunchKernelGGL((spmm_merge_kernel<LPR, kRunLen, MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
-                       dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
-                       a.eid, (const float4*)a.X, a.w, (float4*)a.out, bpart);
+    if (!HAS_EID && a.algo != KGAT_SPMM_ALGO_MERGE1) {
+      hipLaunchKernelGGL((spmm_merge2_kernel<LPR, run_len(LPR), MUL_SELF>), dim3((unsigned)tiles),
+                         dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
+                         (const float4*)a.X, a.w, (float4*)a.out, bpart);
+    } else {
+      hipLaunchKernelGGL((spmm_merge_kernel<LPR, run_len(LPR), MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
+                         dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
+                         a.eid, (const float4*)a.X, a.w, (float4*)a.out, bpart);
+    }
     KGAT_CHECK_LAUNCH("spmm_merge");
   }
   const int32_t fix_blocks = (int32_t)((tiles * 2 + 3) / 4);
   int64_t nz_blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
-  hipLaunchKernelGGL((spmm_finish_kernel<LPR, kRunLen, MUL_SELF>),
+  hipLaunchKernelGGL((spmm_finish_kernel<LPR, run_len(LPR), MUL_SELF>),
                      dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kSpmmThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
                      (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks);
@@ -412,11 +632,17 @@ using namespace kgat;
 
 extern "C" {
 
+#ifdef KGAT_SPMM_STAMPS
+int kgat_debug_set_spmm_stamps(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_spmm_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
+}
+#endif
+
 size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   const int lpr = lpr_for(D);
   if (lpr == 0 || n_edges <= 0) return 256;
   const int nsub = kSpmmThreads / lpr;
-  const int64_t te = (int64_t)nsub * kRunLen;
+  const int64_t te = (int64_t)nsub * run_len(lpr);
   const int64_t tiles = (n_edges + te - 1) / te;
   return align_up((size_t)tiles * 2 * lpr * sizeof(float4), 256) + 256;
 }
@@ -434,13 +660,13 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
   KGAT_CHECK_ARG(indptr && X && out, "spmm: null pointer");
   KGAT_CHECK_ARG(e_end == e_begin || (col && w), "spmm: null col/w");
   KGAT_CHECK_ARG((flags & ~(unsigned)KGAT_SPMM_MUL_SELF) == 0, "spmm: unknown flags 0x%x", flags);
-  KGAT_CHECK_ARG(algo >= KGAT_SPMM_ALGO_AUTO && algo <= KGAT_SPMM_ALGO_GENERIC,
+  KGAT_CHECK_ARG(algo >= KGAT_SPMM_ALGO_AUTO && algo <= KGAT_SPMM_ALGO_MERGE1,
                  "spmm: unknown algo %d", algo);
   if (algo == KGAT_SPMM_ALGO_AUTO)
     algo = (lpr_for(D) && (row_of || e_end == e_begin)) ? KGAT_SPMM_ALGO_MERGE
                                   : (lpr_for(D) ? KGAT_SPMM_ALGO_ROWS : KGAT_SPMM_ALGO_GENERIC);
   if (lpr_for(D) == 0) algo = KGAT_SPMM_ALGO_GENERIC;
-  KGAT_CHECK_ARG(algo != KGAT_SPMM_ALGO_MERGE || row_of != nullptr || e_end == e_begin,
+  KGAT_CHECK_ARG((algo != KGAT_SPMM_ALGO_MERGE && algo != KGAT_SPMM_ALGO_MERGE1) || row_of != nullptr || e_end == e_begin,
                  "spmm: merge algorithm needs row_of");
   KGAT_CHECK_ARG(order == nullptr || algo == KGAT_SPMM_ALGO_ROWS,
                  "spmm: a row order only applies to the rows algorithm");

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import KGATLibraryError, check
 
 SPMM_MUL_SELF = 1
-SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3}
+SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3, "merge1": 4}
 ATT_ALGO = dict({"auto": 0, "mfma": 1, "generic": 2}, **{"mfma_v%d" % v: 16 + v for v in range(16)})
 
 

@@ -48,7 +48,8 @@ enum {
   KGAT_SPMM_ALGO_AUTO = 0,
   KGAT_SPMM_ALGO_MERGE = 1,  /* edge-balanced tiles over the destination-sorted edge array */
   KGAT_SPMM_ALGO_ROWS = 2,   /* one lane group per destination row (optionally degree ordered) */
-  KGAT_SPMM_ALGO_GENERIC = 3 /* any feature width, one wavefront per row */
+  KGAT_SPMM_ALGO_GENERIC = 3, /* any feature width, one wavefront per row */
+  KGAT_SPMM_ALGO_MERGE1 = 4   /* first form of the merge kernel (shuffle-fed), kept for A/B */
 };
 enum {
   KGAT_ATT_ALGO_AUTO = 0,

@@ -111,6 +111,9 @@ def main():
                 fns[a] = lambda: ops.spmm(indptr, col, row_of, X, w_csr, out=out, order=order, algo="rows", workspace=ws)
             else:
                 fns[a] = lambda a=a: ops.spmm(indptr, col, row_of, X, w_csr, out=out, algo=a, workspace=ws, mul_self=True)
+        if args.same_rows:  # diagnostic: every edge gathers one of 16 rows (cache resident)
+            col16 = col % 16
+            fns["merge_samerows"] = lambda: ops.spmm(indptr, col16, row_of, X, w_csr, out=out, algo="merge", workspace=ws, mul_self=True)
         res = timeit(fns, args.rounds)
         b = E * (4 * D + 8) + n * (4 * D + 4)
         for a, t in res.items():

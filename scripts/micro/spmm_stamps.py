@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Diagnostic (developer tool): phase times inside spmm_merge2_kernel from s_memtime stamps.
+Builds a private copy of the library with -DKGAT_SPMM_STAMPS (the shipped library never
+contains the stamps), runs the D=64 aggregation on the benchmark graph and prints the median
+cycles per phase per tile and the tile start/end spread."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from dgl_kgat_amd import _lib, ops, synth  # noqa: E402
+
+so = "/tmp/libkgat_hip_stamps.so"
+srcs = [os.path.join(_lib.CSRC, s) for s in _lib.SOURCES]
+extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + ["-DKGAT_SPMM_STAMPS"] + extra + ["-shared", "-o", so] + srcs)
+print("build flags:", extra)
+_lib.SO_PATH = so
+_lib._lib = None
+lib = _lib.load()
+lib.kgat_debug_set_spmm_stamps.restype = C.c_int
+lib.kgat_debug_set_spmm_stamps.argtypes = [C.c_void_p]
+
+dev = torch.device("cuda:0")
+same_rows = "--same-rows" in sys.argv
+n, trip, R = synth.amazon_book_ckg()
+E, D = len(trip), 64
+src = torch.as_tensor(trip[:, 2].copy(), device=dev)
+dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
+indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
+if same_rows:
+    col = col % 16
+X = torch.randn(n, D, device=dev)
+w = torch.rand(E, device=dev)
+tiles = (E + 1023) // 1024
+stamps = torch.zeros(tiles * 8, dtype=torch.int64, device=dev)
+out = torch.empty(n, D, device=dev)
+for _ in range(3):
+    ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+assert lib.kgat_debug_set_spmm_stamps(stamps.data_ptr()) == 0
+ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+torch.cuda.synchronize()
+st = stamps.cpu().numpy().reshape(tiles, 8).astype(np.float64)
+names = ["stage (loads -> LDS records, barrier)", "edge loop", "partials -> LDS, barrier", "combine walk, barrier", "emit"]
+print("same_rows =", same_rows, " tiles =", tiles, " (s_memtime ticks = shader cycles)")
+for i, nm in enumerate(names):
+    d = st[:, i + 1] - st[:, i]
+    print("  %-40s median %8.0f   p10 %8.0f   p90 %8.0f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+import time
+fn = lambda: ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+assert lib.kgat_debug_set_spmm_stamps(None) == 0
+for _ in range(5): fn()
+ts = []
+for _ in range(20):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); ts.append((a, b))
+torch.cuda.synchronize()
+print("  op time (merge + finish): median %.4f ms" % np.median([a.elapsed_time(b) for a, b in ts]))
+tot = st[:, 5] - st[:, 0]
+print("  %-40s median %8.0f" % ("whole tile", np.median(tot)))
+t0 = st[:, 0].min()
+print("  kernel span (first start -> last end): %.0f cycles; tile starts: p50 %.0f p90 %.0f max %.0f" % (
+    st[:, 5].max() - t0, np.median(st[:, 0] - t0), np.percentile(st[:, 0] - t0, 90), (st[:, 0] - t0).max()))

@@ -113,7 +113,7 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
     indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
     Xd, wd = tf(X, dev), tf(w, dev)
     w_csr = ops.gather(eid, wd) if e else wd
-    algos = ["generic"] + (["merge", "rows"] if D in (4, 8, 16, 32, 64, 128, 256) else [])
+    algos = ["generic"] + (["merge", "merge1", "rows"] if D in (4, 8, 16, 32, 64, 128, 256) else [])
     for algo in algos:
         out = ops.spmm(indptr, col, row_of, Xd, w_csr, algo=algo).cpu().numpy()
         assert out.shape == (n, D)
@@ -153,7 +153,7 @@ def test_spmm_row_range_shard(K, dev):
     ip = indptr.cpu().numpy()
     w_csr = ops.gather(eid, tf(w, dev))
     for lo, hi in [(0, 3), (3, 4), (4, 250), (250, 700), (690, 700)]:
-        for algo in ["merge", "rows", "generic"]:
+        for algo in ["merge", "merge1", "rows", "generic"]:
             out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, rows=(lo, hi - lo),
                            e_range=(int(ip[lo]), int(ip[hi])), algo=algo).cpu().numpy()
             assert out.shape == (hi - lo, D)
