@@ -282,8 +282,8 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
               kAttMaxRelLds, d, k, n_rel);
     return KGAT_E_UNSUPPORTED;
   }
-  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && ent && W_R && rel && logits,
-                 "att_score_split: null pointer");
+  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && ent && W_R && rel, "att_score_split: null pointer");
+  KGAT_CHECK_ARG(logits || logits_csr, "att_score_split: no output requested");
   KGAT_CHECK_ARG(n_groups == 0 || (g_node && G_tab), "att_score_split: null group table");
   KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_split: logits_csr needs pos_g");
   AttArgs a;

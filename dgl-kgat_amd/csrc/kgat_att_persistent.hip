@@ -227,7 +227,7 @@ constexpr int MODE_HEAD = 1, MODE_TAIL = 2;
 #define KGAT_ATT_SPLIT_RING 1
 #endif
 
-template <int D_, int MODE>
+template <int D_, int MODE, bool LOGITS_EID>
 __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
     int n_rel, int64_t n_edges, const int32_t* __restrict__ seg_ptr /* gptr | rel_ptr */,
     const int32_t* __restrict__ row_idx /* g_node | src_g */, const int32_t* __restrict__ gid,
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
     const int64_t tail0 = seg_ptr[n_rel];
     const int64_t n_tail = n_edges - tail0;
     for (int64_t p = tail0 + n_tail * wv / n_waves + lane; p < tail0 + n_tail * (wv + 1) / n_waves; p += kWave) {
-      logits[perm[p]] = 0.f;
+      if (LOGITS_EID) logits[perm[p]] = 0.f;
       if (logits_csr) logits_csr[pos_g[p]] = 0.f;
     }
   }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
         n = n < n_seg ? n : n_seg - 1;
         int32_t po = pe0 + (n << 4) + 4 * q + (i & 3);
         po = po < rend ? po : rend - 1;
-        x.oe = perm[po];
+        x.oe = LOGITS_EID ? perm[po] : 0;
         x.op = pos_or_perm[po];  // unconditional: a branch around a load makes the counted waits conservative
       }
     };
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
         for (int j = 0; j < 4; ++j) part[j] = row16_sum(part[j]);
         const float v = i == 0 ? part[0] : (i == 1 ? part[1] : (i == 2 ? part[2] : part[3]));
         if (i < 4 && item0 + i < rend) {
-          logits[x.oe] = v;
+          if (LOGITS_EID) logits[x.oe] = v;
           if (logits_csr) logits_csr[x.op] = v;
         }
       }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
   }
 }
 
-template <int D_, int MODE>
+template <int D_, int MODE, bool LOGITS_EID>
 static int launch_att_split(const AttArgs& a, const int32_t* seg_ptr, const int32_t* row_idx) {
   static int blocks_per_cu = 0;
   int dev = 0, cus = 256;
@@ -449,32 +449,32 @@ static int launch_att_split(const AttArgs& a, const int32_t* seg_ptr, const int3
   }
   if (blocks_per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_split_kernel<D_, MODE>, kAttThreads, 0) !=
-            hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_split_kernel<D_, MODE, LOGITS_EID>, kAttThreads,
+                                                     0) != hipSuccess || nb < 1)
       nb = 1;
     blocks_per_cu = nb > 8 ? 8 : nb;
   }
-  hipLaunchKernelGGL((att_split_kernel<D_, MODE>), dim3((unsigned)(cus * blocks_per_cu)), dim3(kAttThreads), 0,
-                     a.st, a.n_rel, a.n_edges, seg_ptr, row_idx, a.gid, a.perm, a.pos_g, a.ent, a.W_R, a.rel,
-                     a.G_tab, a.logits, a.logits_csr);
+  hipLaunchKernelGGL((att_split_kernel<D_, MODE, LOGITS_EID>), dim3((unsigned)(cus * blocks_per_cu)),
+                     dim3(kAttThreads), 0, a.st, a.n_rel, a.n_edges, seg_ptr, row_idx, a.gid, a.perm, a.pos_g,
+                     a.ent, a.W_R, a.rel, a.G_tab, a.logits, a.logits_csr);
   KGAT_CHECK_LAUNCH("att_split");
   return KGAT_OK;
 }
 
+template <int D_>
+static int launch_att_split_d(const AttArgs& a) {
+  int rc = launch_att_split<D_, MODE_HEAD, false>(a, a.gptr, a.g_node);
+  if (rc != KGAT_OK) return rc;
+  return a.logits ? launch_att_split<D_, MODE_TAIL, true>(a, a.rel_ptr, a.src_g)
+                  : launch_att_split<D_, MODE_TAIL, false>(a, a.rel_ptr, a.src_g);
+}
+
 int launch_att_split_any(int d, const AttArgs& a) {
-  int rc;
   switch (d) {
-    case 16:
-      rc = launch_att_split<16, MODE_HEAD>(a, a.gptr, a.g_node);
-      return rc != KGAT_OK ? rc : launch_att_split<16, MODE_TAIL>(a, a.rel_ptr, a.src_g);
-    case 32:
-      rc = launch_att_split<32, MODE_HEAD>(a, a.gptr, a.g_node);
-      return rc != KGAT_OK ? rc : launch_att_split<32, MODE_TAIL>(a, a.rel_ptr, a.src_g);
-    case 64:
-      rc = launch_att_split<64, MODE_HEAD>(a, a.gptr, a.g_node);
-      return rc != KGAT_OK ? rc : launch_att_split<64, MODE_TAIL>(a, a.rel_ptr, a.src_g);
-    default:
-      return KGAT_E_UNSUPPORTED;
+    case 16: return launch_att_split_d<16>(a);
+    case 32: return launch_att_split_d<32>(a);
+    case 64: return launch_att_split_d<64>(a);
+    default: return KGAT_E_UNSUPPORTED;
   }
 }
 

@@ -441,7 +441,7 @@ class DGLGraph:
                 g_tab = groups.g_tab[k] = torch.empty((max(groups.n_groups, 1), k), dtype=torch.float32, device=dev)
             _, logits_csr = ops.att_score_split(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
                                                 groups.gid, groups.gptr, groups.g_node, groups.n_groups,
-                                                ent_c, W_c, rel_c, g_tab=g_tab)
+                                                ent_c, W_c, rel_c, g_tab=g_tab, want_eid=False)
         else:
             _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                           ent_c, W_c, rel_c, pos_g=groups.pos_g,

@@ -198,7 +198,7 @@ def att_score_split_supported(n_nodes, d, k, n_rel):
 
 
 def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups, ent, W_R, rel,
-                    want_csr=True, g_tab=None):
+                    want_csr=True, g_tab=None, want_eid=True):
     """Attention logits via head groups (see kgat_att_score_split_f32).  Returns
     (logits edge-id order, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
@@ -214,7 +214,7 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
     _need(g_node, torch.int32, "g_node")
     if g_tab is None:
         g_tab = torch.empty((max(n_groups, 1), k), dtype=torch.float32, device=ent.device)
-    logits = torch.empty(e, dtype=torch.float32, device=ent.device)
+    logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
     with _timed("att_score", (e, d, k)):
         check(_lib.load().kgat_att_score_split_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),

@@ -129,7 +129,7 @@ int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const i
  * the tail projection and its dot product with the group's row.  The head projection and all
  * tanh work are shared by the edges of a group (3.8 edges per group on the amazon-book-shaped
  * CKG).  Arithmetic per edge is unchanged.  Needs d == k in {16,32,64}
- * (kgat_att_score_split_supported). */
+ * (kgat_att_score_split_supported).  logits (edge-id order) or logits_csr may be NULL. */
 int kgat_att_score_split_supported(int64_t n_nodes, int d, int k, int n_rel);
 int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
