@@ -8,7 +8,8 @@
 //
 // Design: N x D_in x D_out with D <= 128 is a skinny GEMM that streams P once (HBM bound:
 // 4*(D_in + 2*D_out) bytes per row against 2*D_in*D_out FLOP).  One wavefront owns 16-row
-// tiles; W2 (<= 32 KB) lives in registers as fp32 MFMA B fragments for the whole launch
+// tiles; W2 (<= 32 KB) is staged once per workgroup through LDS and then lives in registers as
+// fp32 MFMA B fragments for the whole launch
 // (v_mfma_f32_16x16x4_f32, exact fp32); the rows of a tile are contiguous, so the A-fragment
 // loads are fully coalesced float4 reads; the row norm is a DPP reduction over the 16 lanes
 // that hold one row's columns.
@@ -33,6 +34,24 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ W2, float slope,
     float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride) {
   constexpr int KS = DI / 4, KT = DO / 16;
+  // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
+  // laid out in B-fragment order so that every wave then pulls its fragments with
+  // conflict-free ds_read_b32: s_w[(s*KT + c)*64 + q*16 + i] = W2[16c + i][16*(s>>2) + 4q + (s&3)]
+  __shared__ float s_w[KS * KT * kWave];
+  for (int idx = threadIdx.x * 4; idx < DO * DI; idx += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(W2 + idx);
+    const int j = idx / DI, k0 = idx % DI;  // four consecutive k of output column j
+    const int c = j >> 4, i = j & 15;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + t;
+      const int s = (k >> 4) * 4 + (k & 3), q = (k >> 2) & 3;
+      s_w[(s * KT + c) * kWave + q * 16 + i] = vv[t];
+    }
+  }
+  __syncthreads();
+
   const int lane = threadIdx.x % kWave;
   const int i = lane & 15, q = lane >> 4;
   const int64_t n_waves = (int64_t)gridDim.x * (256 / kWave);
@@ -42,26 +61,24 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
   if (t_begin >= t_end) return;
 
-  // B fragments: B[k][j] = W2[j][k]; k-step s, slot q -> k = 16*(s>>2) + 4*q + (s&3)
   float wreg[KS][KT];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+  for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int c = 0; c < KT; ++c) wreg[s][c] = W2[(size_t)(16 * c + i) * DI + k];
-  }
+    for (int c = 0; c < KT; ++c) wreg[s][c] = s_w[(s * KT + c) * kWave + lane];
 
-  for (int32_t t = t_begin; t < t_end; ++t) {
-    const int32_t row0 = t << 4;
-    int32_t ra = row0 + i;
+  auto load_a = [&](int32_t t, float (&a)[KS]) {
+    int32_t ra = (t << 4) + i;
     ra = ra < n_rows ? ra : n_rows - 1;
     const float4* pa = reinterpret_cast<const float4*>(P + (size_t)ra * DI) + q;
-    float a[KS];
 #pragma unroll
     for (int m = 0; m < DI / 16; ++m) {
       const float4 v = pa[m * 4];
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
+  };
+  auto tile = [&](int32_t t, const float (&a)[KS]) {
+    const int32_t row0 = t << 4;
     floatx4_d acc[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){0.f, 0.f, 0.f, 0.f};
@@ -94,6 +111,17 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         }
       }
     }
+  };
+
+  // rows of the next tile are requested before the current tile is computed
+  float a0[KS], a1[KS];
+  load_a(t_begin, a0);
+  for (int32_t t = t_begin; t < t_end; t += 2) {
+    load_a(t + 1 < t_end ? t + 1 : t, a1);
+    tile(t, a0);
+    if (t + 1 >= t_end) break;
+    load_a(t + 2 < t_end ? t + 2 : t + 1, a0);
+    tile(t + 1, a1);
   }
 }
 
