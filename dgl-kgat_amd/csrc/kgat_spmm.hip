@@ -13,8 +13,12 @@
 //    edges per load instruction; each lane group ("subgroup") walks its own run of C
 //    consecutive edges with U loads in flight, accumulating in registers and flushing when
 //    the destination row changes (the row id of every CSR position is a graph-static array).
-//  * col / w / row ids of a run are read coalesced (LPR consecutive entries per load) and
-//    handed around the subgroup with wavefront shuffles (ds_bpermute), not re-read.
+//  * The (col, w, row id) triples reach the lane groups in one of two ways: the second form
+//    (spmm_merge2_kernel, weights in CSR order - the path the KGAT layer uses) stages a tile's
+//    triples once into LDS as 16-byte records and reads one record per edge with a
+//    ds_read_b128 broadcast; the first form (spmm_merge_kernel, also serves weights given in
+//    edge-id order through eid) reads them coalesced per lane group and hands them around with
+//    wavefront shuffles (ds_bpermute).
 //  * Rows that end inside a run are stored straight to `out`.  A run's first and last row
 //    may continue in a neighbour run: those partial sums are combined through LDS in run
 //    order by the workgroup; only the first/last row of the whole tile goes to a small

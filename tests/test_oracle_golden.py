@@ -142,3 +142,26 @@ def test_edge_softmax_backward_fd():
         sm = s.copy(); sm[i] -= eps
         fd = np.dot(ga, orc.edge_softmax(n, dst, sp) - orc.edge_softmax(n, dst, sm)) / (2 * eps)
         assert abs(fd - gs[i]) < 1e-7
+
+
+def test_c1_config_cpu_anchor():
+    """BASELINE configs[0] - the reference's own CPU-runnable case (last-fm CKG, 1 propagation
+    layer, embed_dim = 8) - on a 5 % last-fm-shaped graph: the two independently written CPU
+    restatements (numpy fp64, C/OpenMP fp32) agree on the whole path."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.last_fm_ckg(scale=0.05)
+    src, dst, et = trip[:, 2], trip[:, 0], trip[:, 1]
+    rng = np.random.default_rng(1234)
+    d = 8
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W_R = ((rng.random((R, d, d)) - 0.5) * 0.8).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    W2 = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+    a64 = orc.compute_attention(n, src, dst, et, ent, W_R, rel)
+    out64 = orc.gnn_forward(n, src, dst, a64, ent, [W2])
+    indptr, col, eid = co.csr_from_coo(n, src, dst)
+    a32 = co.edge_softmax(n, indptr, eid, co.att_score(ent, W_R, rel, src, dst, et))
+    h = co.bi_interaction(ent, co.spmm(n, indptr, col, eid, ent, a32), W2)
+    out32 = np.concatenate([ent, co.l2_normalize(h)], 1)
+    assert rel_err(a32, a64.reshape(-1)) < 1e-4
+    assert np.max(np.abs(out32 - out64)) < 1e-4 * np.abs(out64).max()
