@@ -155,6 +155,16 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
+    # informational: the propagation layers alone (attention fixed, as in the 54 CF batches per
+    # epoch of kgat.py:146-168 that reuse one attention refresh); not the headline value
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        with torch.no_grad():
+            model.gnn(g)
+    sync()
+    gnn_dt = (time.perf_counter() - t1) / args.steps
+
     # per-kernel HIP-event timing over an identical set of steps (events on the launch stream)
     with ops.KernelTimer() as kt:
         for _ in range(args.steps):
@@ -226,6 +236,8 @@ def main():
                                % (name, n, E, n_rel, args.layers, D, args.layers),
                    "partition": "none" if world == 1 else "dst-range x%d, all-reduce of layer outputs" % world,
                    "edges_counted_per_step": args.layers * E},
+        "propagation_only": {"ms_per_pass": round(gnn_dt * 1e3, 4), "edges_per_s": round(args.layers * E / gnn_dt, 1),
+                             "note": "3 propagation layers with the attention weights held fixed (rank-local clock)"},
         "roofline": roofline,
         "roofline_att": roofline_att,
         "breakdown_ms": {"att_score": att_ms, "edge_softmax": sm_ms, "spmm_D%d" % D: spmm_ms,
