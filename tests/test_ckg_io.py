@@ -1,0 +1,59 @@
+"""CPU: on-disk formats + CKG construction (SURVEY 8f "next" #4) against golden vectors produced
+by the reference's own dataset.DataLoader (tests/golden/make_golden_dataset.py)."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN_DIR
+
+from dgl_kgat_amd import ckg_io
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "toy_dataset.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _rows_sorted(a):
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_loader_matches_reference_dataloader(tmp_path):
+    g = _golden()
+    d = str(tmp_path / "data")
+    ckg_io.save_ckg_files(d, int(g["n_users"]), g["uv_train"], g["uv_val"], g["uv_test"], g["kg"])
+    ds = ckg_io.CKGDataset(d)
+    assert (ds.n_users, ds.n_items, ds.n_KG_relation, ds.n_KG_entity) == (
+        int(g["n_users"]), int(g["n_items"]), int(g["n_KG_relation"]), int(g["n_KG_entity"]))
+    assert np.array_equal(ds.item_id_range, g["item_id_range"])
+    n_kg = len(g["kg"])
+    for mine, ref in ((ds.train_KG_triplet, g["train_KG_triplet"]), (ds.test_KG_triplet, g["test_KG_triplet"])):
+        assert mine.dtype == np.int32 and mine.shape == ref.shape
+        # the item-KG block is in file order; the interaction blocks are sorted by user (the order
+        # inside one user is not specified by the reference: pandas' unstable default sort)
+        assert np.array_equal(mine[:n_kg], ref[:n_kg])
+        half = (len(ref) - n_kg) // 2
+        for lo, hi, key in ((n_kg, n_kg + half, 0), (n_kg + half, len(ref), 2)):
+            assert np.array_equal(mine[lo:hi, key], ref[lo:hi, key])  # same user order
+            assert np.array_equal(_rows_sorted(mine[lo:hi]), _rows_sorted(ref[lo:hi]))
+        # the reversed block mirrors the forward block row by row
+        assert np.array_equal(mine[n_kg:n_kg + half][:, [2, 0]], mine[n_kg + half:][:, [0, 2]])
+    graph = ds.train_graph()
+    src, dst = graph.edges()
+    assert graph.number_of_nodes() == int(g["n_KG_entity"]) and graph.number_of_edges() == len(g["train_g_src"])
+    assert np.array_equal(np.sort(src.numpy() * 10_000 + dst.numpy()),
+                          np.sort(g["train_g_src"].astype(np.int64) * 10_000 + g["train_g_dst"]))
+    assert np.array_equal(src.numpy(), ds.train_KG_triplet[:, 2]) and np.array_equal(dst.numpy(), ds.train_KG_triplet[:, 0])
+    assert graph.edata["type"].dtype.is_floating_point is False and graph.ndata["id"].tolist() == list(range(ds.n_KG_entity))
+    assert np.array_equal(np.bincount(graph.edata["type"].numpy()), np.bincount(g["train_g_type"]))
+
+
+def test_tables_round_trip(tmp_path):
+    p = str(tmp_path / "t.pd")
+    a = np.array([[3, 1, 7], [0, 0, 2]], np.int32)
+    ckg_io.write_table(p, ["h", "r", "t"], a)
+    assert open(p).readline() == "h\tr\tt\n"
+    names, b = ckg_io.read_table(p, ("h", "r", "t"))
+    assert names == ["h", "r", "t"] and np.array_equal(a, b)
+    ckg_io.write_table(p, ["u", "v"], np.zeros((0, 2), np.int32))
+    assert ckg_io.read_table(p)[1].shape == (0, 2)
