@@ -144,6 +144,23 @@ class KGATPropagation(nn.Module):
             off += widths[li + 1]
         return out
 
+    def transR(self, h, r, pos_t, neg_t, reg_lambda_kg=0.01):
+        """TransR pairwise ranking loss of the KG phase (reference models.py:114-133 with
+        bmm_maybe_select :13-47).  Dense torch arithmetic only - outside the propagation path
+        (SURVEY 8f #3); kept so that this module covers the reference Model's training API."""
+        W = self.W_R.index_select(0, r)  # (B, d, k)
+
+        def proj(ids):
+            return F.normalize(torch.bmm(self.entity_embed(ids).unsqueeze(1), W).squeeze(1), p=2, dim=1)
+
+        h_vec, pos_vec, neg_vec = proj(h), proj(pos_t), proj(neg_t)
+        r_vec = F.normalize(self.relation_embed(r), p=2, dim=1)
+        pos_score = (h_vec + r_vec - pos_vec).pow(2).sum(1, keepdim=True)
+        neg_score = (h_vec + r_vec - neg_vec).pow(2).sum(1, keepdim=True)
+        loss = (-F.logsigmoid(neg_score - pos_score)).mean()
+        reg = sum((v.pow(2).sum(1) / 2.0).mean() for v in (h_vec, r_vec, pos_vec, neg_vec))
+        return loss + reg_lambda_kg * reg
+
     def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids):
         """BPR loss of reference models.py:170-178 (harness only)."""
         s, p, n = embedding[src_ids], embedding[pos_dst_ids], embedding[neg_dst_ids]

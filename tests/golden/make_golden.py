@@ -187,6 +187,16 @@ def run_case(models, name, seed, d, k, hidden, n_layers, graph_kw):
         for i, layer in enumerate(model.layers):
             h = layer(g, h)
             out["layer_out_%d" % i] = h.numpy()
+    # dense losses of the reference Model (pure torch, no graph): transR (models.py:114-133) and
+    # the BPR loss get_loss (models.py:170-178) on fixed index batches
+    rng = np.random.default_rng(seed)
+    B = 37
+    hh = th.as_tensor(rng.integers(0, n, B)); rr = th.as_tensor(rng.integers(0, n_rel, B))
+    pt = th.as_tensor(rng.integers(0, n, B)); nt = th.as_tensor(rng.integers(0, n, B))
+    with th.no_grad():
+        out["transR_idx"] = np.stack([hh.numpy(), rr.numpy(), pt.numpy(), nt.numpy()])
+        out["transR_loss"] = model.transR(hh, rr, pt, nt).numpy()
+        out["bpr_loss"] = model.get_loss(th.as_tensor(out["gnn_out"]), hh, pt, nt).numpy()
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%s: N=%d E=%d R=%d d=%d k=%d -> %s (%.1f KB)" % (

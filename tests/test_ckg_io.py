@@ -57,3 +57,16 @@ def test_tables_round_trip(tmp_path):
     assert names == ["h", "r", "t"] and np.array_equal(a, b)
     ckg_io.write_table(p, ["u", "v"], np.zeros((0, 2), np.int32))
     assert ckg_io.read_table(p)[1].shape == (0, 2)
+
+
+def test_ranking_metrics_match_reference():
+    """recall@K / ndcg@K (metric.py:36-68) against the value the reference's own code returns."""
+    import torch
+    from dgl_kgat_amd import metrics
+    g = _golden()
+    as_dict = lambda users, items: {int(u): np.array([int(x) for x in str(s).split(";")]) for u, s in zip(users, items)}  # noqa: E731
+    train = as_dict(g["train_users"], g["train_user_items"])
+    test = as_dict(g["test_users"], g["test_user_items"])
+    rec, ndcg = metrics.calc_recall_ndcg(torch.as_tensor(g["metric_embedding"]), train, test, g["item_id_range"], K=5,
+                                         batch_users=4)
+    assert abs(rec - g["metric_recall_ndcg_at5"][0]) < 1e-12 and abs(ndcg - g["metric_recall_ndcg_at5"][1]) < 1e-12

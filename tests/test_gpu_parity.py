@@ -467,3 +467,21 @@ def test_full_size_properties(K, dev):
         seg = eid_h[ip[v]:ip[v + 1]]
         ref = (ah[seg, None] * Xh[src[seg]]).sum(0) if len(seg) else np.zeros(64)
         assert np.max(np.abs(mh[v] - ref)) < 1e-4 * max(np.abs(ref).max(), 1e-3 * scale)
+
+
+def test_training_harness_end_to_end(K, dev):
+    """examples/train_kgat.py: reference-format files -> CKGDataset -> KG phase / attention refresh /
+    CF phase / recall@20 + ndcg@20, the epoch structure of kgat.py:114-196, on the kernels."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_kgat.py"), "--synthetic", "0.01",
+                          "--epochs", "2", "--max_iters", "8", "--lr", "0.01"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "loss" in l or "recall" in l]
+    kge = [float(l.split("loss")[1]) for l in lines if "KGE" in l]
+    assert len(kge) == 2 and kge[1] < kge[0] and all(np.isfinite(kge))
+    rec = [float(l.split("recall@20")[1].split()[0]) for l in lines if "recall@20" in l]
+    assert len(rec) == 4 and all(0.0 <= r <= 1.0 for r in rec)

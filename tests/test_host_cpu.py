@@ -211,3 +211,19 @@ def test_partition_exchange_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+@pytest.mark.parametrize("case", ["toy_d8", "toy_d16_k32", "toy_d64"])
+def test_dense_losses_match_reference(case):
+    """transR (models.py:114-133) and the BPR loss (models.py:170-178): torch-only parts of the
+    reference Model, checked against values produced by the reference's own code."""
+    g = load_golden(case)
+    d, k = g["entity_embed"].shape[1], g["W_R"].shape[2]
+    m = K.KGATPropagation(g["n"], g["R"], d, k, len(g["W2"]), g["W2"][0].shape[0], dropout=0.0).double()
+    sd = {"entity_embed.weight": g["entity_embed"], "relation_embed.weight": g["relation_embed"], "W_R": g["W_R"]}
+    sd.update({"layers.%d.res_fc_2.weight" % i: W for i, W in enumerate(g["W2"])})
+    m.load_state_dict({k_: torch.as_tensor(v, dtype=torch.float64) for k_, v in sd.items()})
+    h, r, pt, nt = (torch.as_tensor(x) for x in g["transR_idx"])
+    with torch.no_grad():
+        assert abs(float(m.transR(h, r, pt, nt)) - float(g["transR_loss"])) < 1e-12
+        assert abs(float(m.get_loss(torch.as_tensor(g["gnn_out"]), h, pt, nt)) - float(g["bpr_loss"])) < 1e-12
