@@ -125,6 +125,22 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   }
 }
 
+// F.normalize(x, p=2, dim=1, eps=1e-12) of contiguous rows into a strided destination (a column
+// slice of the concatenated readout, reference models.py:165-167).  One 16-lane group per row.
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(int64_t n_rows, int d,
+                                                                const float* __restrict__ x,
+                                                                float* __restrict__ out,
+                                                                int64_t out_stride) {
+  const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + sub; row < n_rows; row += (int64_t)gridDim.x * 16) {
+    const float* xr = x + (size_t)row * d;
+    float ss = 0.f;
+    for (int c = sl; c < d; c += 16) ss = fmaf(xr[c], xr[c], ss);
+    const float nrm = fmaxf(sqrtf(row16_sum_d(ss)), 1e-12f);
+    for (int c = sl; c < d; c += 16) out[(size_t)row * out_stride + c] = xr[c] / nrm;
+  }
+}
+
 template <int DI, int DO>
 static int launch_bi(int64_t n_rows, const float* P, const float* W2, float slope, float* h_out,
                      float* norm_out, int64_t norm_stride, hipStream_t st) {
@@ -142,6 +158,19 @@ static int launch_bi(int64_t n_rows, const float* P, const float* W2, float slop
 using namespace kgat;
 
 extern "C" {
+
+int kgat_l2_normalize_rows_f32(int64_t n_rows, int d, const float* x, float* out, int64_t out_stride,
+                               kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && d > 0 && out_stride >= d, "l2_normalize_rows: bad size");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(x && out, "l2_normalize_rows: null pointer");
+  int64_t blocks = (n_rows + 15) / 16;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n_rows, d,
+                     x, out, out_stride);
+  KGAT_CHECK_LAUNCH("l2_normalize_rows");
+  return KGAT_OK;
+}
 
 int kgat_bi_interaction_supported(int d_in, int d_out) {
   auto ok = [](int d) { return d == 16 || d == 32 || d == 64 || d == 128; };

@@ -99,8 +99,8 @@ class KGATPropagation(nn.Module):
     def gnn(self, g, x=None, fused=None):
         if fused is None:
             fused = not torch.is_grad_enabled()
-        if fused and g.partition is None and self._can_fuse_readout():
-            return self._gnn_fused(g)
+        if fused and self._can_fuse_readout():
+            return self._gnn_fused(g) if g.partition is None else self._gnn_fused_sharded(g)
         g = g.local_var()
         h = self._node_embeddings(g)
         node_embed_cache = [h]
@@ -160,6 +160,23 @@ class KGATPropagation(nn.Module):
         loss = (-F.logsigmoid(neg_score - pos_score)).mean()
         reg = sum((v.pow(2).sum(1) / 2.0).mean() for v in (h_vec, r_vec, pos_vec, neg_vec))
         return loss + reg_lambda_kg * reg
+
+    def _gnn_fused_sharded(self, g):
+        """No-grad path on a destination-range shard: per layer the local aggregation, the
+        bi-interaction kernel on the owned rows, one all-reduce, and the row normalisation of the
+        assembled layer output into its slice of the readout."""
+        from . import ops
+        part = g.partition
+        h = self._node_embeddings(g).detach()
+        widths = [h.shape[1]] + [layer.res_fc_2.out_features for layer in self.layers]
+        out = torch.empty((h.shape[0], sum(widths)), dtype=torch.float32, device=h.device)
+        out[:, :widths[0]] = h
+        off = widths[0]
+        for li, layer in enumerate(self.layers):
+            h = part.propagate_fused(g, h, layer.res_fc_2.weight)
+            ops.l2_normalize_rows(h, out[:, off:off + widths[li + 1]])
+            off += widths[li + 1]
+        return out
 
     def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids):
         """BPR loss of reference models.py:170-178 (harness only)."""

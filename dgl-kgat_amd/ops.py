@@ -327,6 +327,16 @@ def bi_interaction(P, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h
     return h_out
 
 
+def l2_normalize_rows(x, out):
+    """out[:, :] = x / max(||x_row||, 1e-12); `out` may be a column slice of a wider buffer."""
+    x = _need(x, torch.float32, "x")
+    if (not out.is_cuda or out.dtype != torch.float32 or tuple(out.shape) != tuple(x.shape) or out.stride(1) != 1):
+        raise ValueError("out must be a float32 device view of x's shape with unit column stride")
+    check(_lib.load().kgat_l2_normalize_rows_f32(x.shape[0], x.shape[1], _ptr(x), _ptr(out), out.stride(0), _stream(x)),
+          "kgat_l2_normalize_rows_f32")
+    return out
+
+
 def sddmm_dot(src, dst, X, G):
     X = _need(X, torch.float32, "X")
     G = _need(G, torch.float32, "grad_out")
@@ -342,5 +352,5 @@ def sddmm_dot(src, dst, X, G):
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
            "att_score", "att_score_split", "att_score_split_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
-           "bi_interaction", "bi_interaction_supported",
+           "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
            "KGATLibraryError"]

@@ -68,6 +68,22 @@ class Partition:
         """One KGATConv on a shard + the all-reduce of its D_out-wide result."""
         return self.exchange(self.propagate_local(g, h, weight), weight.shape[0])
 
+    def propagate_fused(self, g, h, weight):
+        """Forward-only form of `propagate` with fewer launches: the owned rows of
+        LeakyReLU((h*h_N) W2^T) are written by the bi-interaction kernel straight into the
+        zeroed exchange buffer, then all-reduced."""
+        st = g._st
+        csr = st.csr(h.device)
+        w_csr = st.weight_in_csr_order(g.edata["w"].detach().reshape(-1).contiguous())
+        prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
+                        rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
+        full = torch.zeros((self.n_nodes, weight.shape[0]), dtype=torch.float32, device=h.device)
+        if self.hi > self.lo:
+            ops.bi_interaction(prod, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
+        if self.world > 1:
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        return full
+
 
 def shard_graph(g, rank, world, group=None, bounds=None):
     """The rank's shard of `g`: all nodes, the edges whose destination lies in the rank's row

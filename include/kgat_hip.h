@@ -199,6 +199,13 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
                             float negative_slope, float* h_out, float* norm_out,
                             int64_t norm_stride, kgat_stream_t stream);
 
+/* F.normalize(x, p=2, dim=1, eps=1e-12) of n_rows contiguous d-wide rows (reference
+ * models.py:165) into a destination with row stride out_stride floats (a column slice of the
+ * concatenated output, models.py:167).  Used where the rows of a layer come back from the
+ * multi-GPU exchange and the fused kernel above could not normalise them. */
+int kgat_l2_normalize_rows_f32(int64_t n_rows, int d, const float* x, float* out, int64_t out_stride,
+                               kgat_stream_t stream);
+
 /* Permute a per-edge array: out[i] = in[index[i]]. */
 int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out,
                     kgat_stream_t stream);

@@ -424,10 +424,20 @@ def test_destination_shards_reassemble_to_unsharded(K, dev):
             acc += sg.partition.pad(out_loc, out_loc.shape[1])
         assert rel_err_inf(a_parts.cpu().numpy(), a_full.cpu().numpy()) < 1e-6
         assert rel_err_inf(acc.cpu().numpy(), h_full.cpu().numpy()) < 1e-6
-        # world = 1: the sharded code path end to end (exchange without a process group)
+        # world = 1: the sharded code paths end to end (exchange without a process group)
         sg, _ = partition.shard_graph(g, 0, 1)
         sg.edata["w"] = model.compute_attention(sg)
-        assert rel_err_inf(model.gnn(sg).cpu().numpy(), model.gnn(g).cpu().numpy()) < 1e-6
+        ref = model.gnn(g).cpu().numpy()
+        assert rel_err_inf(model.gnn(sg, fused=True).cpu().numpy(), ref) < 1e-6   # bi-interaction kernel + row normalise
+        assert rel_err_inf(model.gnn(sg, fused=False).cpu().numpy(), ref) < 1e-6  # torch dense part
+        # row normalisation kernel alone, into a column slice, zero rows stay zero
+        from dgl_kgat_amd import ops
+        x = torch.randn(1000, 48, device=dev)
+        x[7] = 0
+        wide = torch.full((1000, 60), 3.0, device=dev)
+        ops.l2_normalize_rows(x, wide[:, 4:52])
+        assert torch.allclose(wide[:, 4:52], torch.nn.functional.normalize(x, dim=1), atol=1e-6)
+        assert torch.all(wide[:, :4] == 3.0) and torch.all(wide[:, 52:] == 3.0) and torch.all(wide[7, 4:52] == 0)
 
 
 def test_full_size_properties(K, dev):
