@@ -29,6 +29,55 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// same FLOPs per k-step with the 32x32x2 form: 4 accumulator tiles of 32x32, K = 2 per MFMA
+template <int FILL>
+__global__ __launch_bounds__(256) void k32(float* out, int iters, float seed) {
+  floatx16 acc[4];
+  for (int c = 0; c < 4; ++c)
+    for (int j = 0; j < 16; ++j) acc[c][j] = 0.f;
+  float a[16], b[16];
+  for (int s = 0; s < 16; ++s) { a[s] = seed + s + threadIdx.x; b[s] = seed * 2 + s; }
+  float f = seed;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[(s + c) & 15], acc[c], 0, 0, 0);
+      if (FILL) {
+#pragma unroll
+        for (int j = 0; j < FILL; ++j) f = fmaf(f, 1.0001f, 0.5f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float r = f;
+  for (int c = 0; c < 4; ++c)
+    for (int j = 0; j < 16; ++j) r += acc[c][j];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int FILL>
+void run32(const char* name, int blocks) {
+  float* out;
+  hipMalloc(&out, sizeof(float) * blocks * 256);
+  const int iters = 2000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  k32<FILL><<<blocks, 256>>>(out, 10, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k32<FILL><<<blocks, 256>>>(out, iters, 1.0f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  double flop = (double)blocks * 4 * iters * 64 * (32 * 32 * 2 * 2);
+  printf("%-36s blocks=%d  %.3f ms  %.1f TFLOP/s\n", name, blocks, ms, flop / ms / 1e9);
+  hipFree(out);
+}
+
 template <int FILL>
 void run(const char* name, int blocks) {
   float* out;
@@ -57,5 +106,9 @@ int main() {
   run<8>("mfma + 8 fma/kstep, 1 w/SIMD", 256);
   run<16>("mfma + 16 fma/kstep, 1 w/SIMD", 256);
   run<8>("mfma + 8 fma/kstep, 2 w/SIMD", 512);
+  run32<0>("32x32x2 only, 1 wave/SIMD", 256);
+  run32<8>("32x32x2 + 8 fma/kstep, 1 w/SIMD", 256);
+  run32<16>("32x32x2 + 16 fma/kstep, 1 w/SIMD", 256);
+  run32<8>("32x32x2 + 8 fma/kstep, 2 w/SIMD", 512);
   return 0;
 }
