@@ -4,22 +4,29 @@
 //     for i in range(R): eids = g.filter_edges(type == i); g.apply_edges(_att_score, eids)
 // and the UDF models.py:135-144
 //     t_r = ent[src] @ W_r ; h_r = ent[dst] @ W_r ; att = sum_j t_r[j] * tanh(h_r[j] + rel_r[j])
-// by ONE launch over relation-grouped edges.
+// by launches over relation-grouped edges.  Three kernel families, chosen by the host:
+//   * kgat_att_score_split_f32 (kgat_att_persistent.hip, d = k <= 64, default when the (head,
+//     relation) groups share work): head projections + tanh once per group, tail projection
+//     + dot product per edge;
+//   * kgat_att_score_f32 -> persistent one-kernel form (kgat_att_persistent.hip, d = k <= 64);
+//   * kgat_att_score_f32 -> the workgroup-chunk kernel below (d = k = 128, or forced for A/B)
+//     and the VALU kernel for any other (d, k).
 //
 // Design: this is the only dense contraction on the path (4*d*k FLOP per edge against
 // ~8*d bytes of gathered rows, AI ~ 31 FLOP/B at d = k = 64 > the fp32 ridge), so it is
 // bound by the fp32 matrix pipe: v_mfma_f32_16x16x4_f32 (exact fp32, a k-ordered fma chain).
-//  * A workgroup (4 wavefronts) owns a chunk of one relation's edges; W_r (d x k) is staged
-//    once per chunk into LDS in MFMA B-fragment order, so every B fetch is one conflict-free
-//    ds_read_b32 per lane, shared by 2*TILES MFMAs (t and h projections of TILES 16-edge tiles).
+// Common to the MFMA kernels:
 //  * A fragments come straight from global memory: lane (edge i = lane&15, slot q = lane>>4)
 //    loads float4 pieces of its edge's embedding row so that the 4 lanes of an edge read 64
 //    contiguous bytes per instruction; the contraction index is permuted consistently in A
 //    and B (k-step s, slot q -> element 16*(s>>2) + 4*q + (s&3)), which MFMA does not care about.
-//  * The 16 x k projection tiles stay in the accumulators; tanh, the product and the row sum
-//    run on the VALU from there (row sum = 4 DPP-width shuffles over the 16 lanes of a slot).
-//  * Relation-grouped src/dst arrays make the per-tile index reads coalesced; logits are
-//    scattered back to edge-id order (and optionally to CSR position order for the softmax).
+//  * The 16 x k projection tiles stay in registers; tanh, the product and the row sum run on
+//    the VALU from there (row sum = 4 DPP adds over the 16 lanes of a slot).
+//  * Relation-grouped endpoint arrays make the per-tile index reads coalesced; logits are
+//    scattered to CSR position order for the softmax (and optionally to edge-id order).
+// The chunk kernel of this file: a workgroup (4 wavefronts) owns a chunk of one relation's
+// edges; W_r (d x k) is staged once per chunk into LDS in MFMA B-fragment order, so every B
+// fetch is one conflict-free ds_read_b32 per lane, shared by 2*TILES MFMAs.
 #include "kgat_att_common.h"
 
 namespace kgat {
