@@ -227,3 +227,43 @@ def test_dense_losses_match_reference(case):
     with torch.no_grad():
         assert abs(float(m.transR(h, r, pt, nt)) - float(g["transR_loss"])) < 1e-12
         assert abs(float(m.get_loss(torch.as_tensor(g["gnn_out"]), h, pt, nt)) - float(g["bpr_loss"])) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (authoring container)")
+def test_unmodified_reference_model_over_the_surface():
+    """INTEGRATION.md path A in the authoring container: the reference's models.py, imported
+    unmodified over install_as_dgl(), drives this package's DGLGraph.  Without a GPU the torch
+    part (filter_edges / apply_edges with Model._att_score) runs and must reproduce the golden
+    logits; the sparse kernels must refuse to run on CPU tensors."""
+    import importlib
+    from dgl_kgat_amd import synth as _synth
+    g = load_golden("toy_d8")
+    K.install_as_dgl()
+    sys.path.insert(0, "/root/reference")
+    sys.dont_write_bytecode = True
+    try:
+        sys.modules.pop("models", None)
+        models = importlib.import_module("models")
+        model = models.Model(use_KG=True, input_node_dim=8, gnn_model="kgat", num_gnn_layers=3, n_hidden=8,
+                             dropout=0.0, n_entities=g["n"], n_relations=g["R"], relation_dim=8).double()
+        sd = {"entity_embed.weight": g["entity_embed"], "relation_embed.weight": g["relation_embed"], "W_R": g["W_R"]}
+        sd.update({"layers.%d.res_fc_2.weight" % i: W for i, W in enumerate(g["W2"])})
+        model.load_state_dict({k_: torch.as_tensor(v, dtype=torch.float64) for k_, v in sd.items()})
+        graph = _synth.build_graph(g["n"], g["triplets"])
+        lv = graph.local_var()
+        with torch.no_grad():
+            for i in range(g["R"]):  # the body of Model.compute_attention (models.py:149-152)
+                e_idxs = lv.filter_edges(lambda edges: edges.data["type"] == i)
+                model.W_r = model.W_R[i]
+                lv.apply_edges(model._att_score, e_idxs)
+                assert np.allclose(lv.edata["att_w"][e_idxs].numpy(), g["att_score_%d" % i], rtol=1e-12, atol=1e-14)
+            model = model.float()
+            with pytest.raises(K.KGATLibraryError):
+                model.compute_attention(graph)  # edge_softmax needs the HIP device
+            graph.edata["w"] = torch.as_tensor(g["attention"], dtype=torch.float32)
+            with pytest.raises(K.KGATLibraryError):
+                model.gnn(graph, graph.ndata["id"])  # update_all needs the HIP device
+    finally:
+        sys.path.remove("/root/reference")
+        for name in [n for n in sys.modules if n == "dgl" or n.startswith("dgl.") or n == "models"]:
+            del sys.modules[name]
