@@ -201,11 +201,15 @@ def main():
         ach = b_spmm / (spmm_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge2_kernel + spmm_finish_kernel), D=%d" % D,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes": int(b_spmm), "avg_ms": round(spmm_ms, 4),
+                    "traffic": traffic,
+                    "traffic_rate": None if traffic is None else round(traffic / (spmm_ms * 1e-3) / 1e9, 1),
+                    "traffic_frac": None if traffic is None else round(traffic / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes": int(b_spmm), "avg_ms": round(spmm_ms, 4),
                     "min_ms": round(spmm_min, 4), "launches": spmm_cnt,
                     "edges_per_s": round(e_loc / (spmm_ms * 1e-3), 1),
                     "note": ("X (N*D*4 = %.1f MB) fits the 256 MiB Infinity Cache: gathered bytes are largely cache-served, "
-                             "not HBM bytes (a fraction above 1.0 means exactly that, not >peak HBM); "
+                             "not HBM bytes (a fraction above 1.0 means exactly that, not >peak HBM; traffic_rate = "
+                             "PMC-measured fabric-side bytes / time is the upper bound on the HBM rate); "
                              if n * D * 4 < 200e6 else
                              "X (N*D*4 = %.1f MB) exceeds the 256 MiB Infinity Cache: gathers are HBM-served; ")
                             % (n * D * 4 / 1e6) +
