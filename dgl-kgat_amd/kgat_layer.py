@@ -23,6 +23,38 @@ from . import function as fn
 from .autograd import edge_softmax, u_mul_e_sum
 
 
+class _TallLinear(torch.autograd.Function):
+    """``x @ W^T`` for a tall x (N ~ 10^5 rows, <= 128 columns).  Forward and grad_x are ordinary
+    library GEMMs; the weight gradient ``grad^T @ x`` reduces over N into a tiny (D_out, D_in)
+    result, a shape the library handles badly (0.45-0.5 ms at N = 159k against ~25 us for the
+    other two GEMMs), so it is computed as a batched GEMM over row slabs plus a sum."""
+
+    SLABS = 128
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        grad = grad.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = grad @ weight
+        if ctx.needs_input_grad[1]:
+            n, s = x.shape[0], _TallLinear.SLABS
+            m = (n // s) * s
+            if m >= 16 * s:
+                gw = torch.bmm(grad[:m].view(s, m // s, -1).transpose(1, 2), x[:m].view(s, m // s, -1)).sum(0)
+                if m < n:
+                    gw = gw + grad[m:].t() @ x[m:]
+            else:
+                gw = grad.t() @ x
+        return gx, gw
+
+
 class KGATConv(nn.Module):
     """Bi-interaction propagation layer: LeakyReLU_{0.01}(W2 (h * h_N)), dropout
     (reference models.py:49-70; only the ``Bi`` branch with ``res_fc_2`` exists there)."""
@@ -50,7 +82,7 @@ class KGATConv(nn.Module):
             g.ndata["h"] = nfeat
             g.update_all(fn.u_mul_e("h", "w", "m"), fn.sum("m", "h_neighbor"))
             h_neighbor = g.ndata["h_neighbor"]
-            out = F.leaky_relu(self.res_fc_2(torch.mul(g.ndata["h"], h_neighbor)))
+            out = F.leaky_relu(_TallLinear.apply(torch.mul(g.ndata["h"], h_neighbor), self.res_fc_2.weight))
         return self.mess_drop(out)
 
 

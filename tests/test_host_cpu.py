@@ -267,3 +267,17 @@ def test_unmodified_reference_model_over_the_surface():
         sys.path.remove("/root/reference")
         for name in [n for n in sys.modules if n == "dgl" or n.startswith("dgl.") or n == "models"]:
             del sys.modules[name]
+
+
+def test_tall_linear_gradients_match_torch():
+    from dgl_kgat_amd.kgat_layer import _TallLinear
+    torch.manual_seed(0)
+    for n in (5, 2048, 2048 + 77, 5000):
+        x = torch.randn(n, 24, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(12, 24, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(n, 12, dtype=torch.float64)
+        _TallLinear.apply(x, w).backward(g)
+        gx, gw = x.grad.clone(), w.grad.clone()
+        x.grad = w.grad = None
+        torch.nn.functional.linear(x, w).backward(g)
+        assert torch.allclose(gx, x.grad, rtol=1e-12, atol=1e-12) and torch.allclose(gw, w.grad, rtol=1e-11, atol=1e-11)
