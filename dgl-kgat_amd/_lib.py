@@ -42,6 +42,9 @@ SIGNATURES = {
     "kgat_att_score_split_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "kgat_att_score_split_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
                                         _p, _p, _p, _p, _p]),
+    "kgat_att_score_folded_supported": (_i32, [_i64, _i32, _i32, _i32]),
+    "kgat_att_score_folded_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
+                                         _p, _p, _p, _p, _p]),
     "kgat_edge_softmax_workspace_bytes": (_sz, [_i64]),
     "kgat_edge_softmax_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "kgat_edge_softmax_bwd_f32": (_i32, [_i64, _i64, _p, _p, _p, _p, _p, _p]),

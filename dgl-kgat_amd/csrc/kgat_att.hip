@@ -196,6 +196,90 @@ static int dispatch_att_variant(AttArgs a, int variant) {
   return KGAT_E_UNSUPPORTED;
 }
 
+// Per-edge half of the folded form (head half: att_fold_head_kernel): logit = e_t . V[group].
+// A gather-dot, bound by the tail-row gather like the SpMM.  LPE = d/4 lanes hold one edge's
+// rows as float4; a wavefront takes 64 consecutive grouped positions, reads their indices with
+// one coalesced load each and hands them to the lane groups through ds_bpermute; lane group u
+// owns positions p0 + u*LPE .. + LPE-1 and walks them in LPE steps.  The reduced dot products
+// are collected so that lane l ends up with position p0 + l, and the results leave with one
+// scattered store per output array.
+template <int D_, bool LOGITS_EID>
+__global__ __launch_bounds__(256) void att_fold_tail_kernel(
+    int n_rel, const int32_t* __restrict__ rel_ptr, int64_t n_edges, const int32_t* __restrict__ src_g,
+    const int32_t* __restrict__ gid,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g, const float* __restrict__ ent,
+    const float* __restrict__ V_tab, float* __restrict__ logits, float* __restrict__ logits_csr) {
+  constexpr int LPE = D_ / 4;
+  const int64_t n_scored = rel_ptr[n_rel];
+  const int lane = threadIdx.x % kWave;
+  const int li = lane % LPE;
+  const int64_t wv = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  const int64_t p0 = wv * kWave;
+  if (p0 >= n_edges) return;
+  const int64_t p = p0 + lane;
+  if (p0 >= n_scored) {  // relation ids outside [0, R): logit 0
+    if (p < n_edges) {
+      if (LOGITS_EID) logits[perm[p]] = 0.f;
+      if (logits_csr) logits_csr[pos_g[p]] = 0.f;
+    }
+    return;
+  }
+  const int64_t pc = p < n_scored ? p : n_scored - 1;
+  const int32_t my_row = src_g[pc], my_g = gid[pc];
+  const int32_t oe = LOGITS_EID ? perm[p < n_edges ? p : n_edges - 1] : 0;
+  const int32_t op = logits_csr ? pos_g[p < n_edges ? p : n_edges - 1] : 0;
+  const uint32_t e_off = (uint32_t)my_row * (uint32_t)(D_ * 4), v_off_lo = (uint32_t)li * 16u;
+  const char* eb = reinterpret_cast<const char*>(ent) + v_off_lo;
+  const char* vb = reinterpret_cast<const char*>(V_tab) + v_off_lo;
+  float mine = 0.f;
+  constexpr int U = LPE < 4 ? LPE : 4;
+#pragma unroll
+  for (int s0 = 0; s0 < LPE; s0 += U) {
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int from = (lane - li + s0 + u) << 2;  // lane (group base + step)
+      const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)e_off);
+      const int32_t g = __builtin_amdgcn_ds_bpermute(from, my_g);
+      a[u] = *reinterpret_cast<const float4*>(eb + eo);
+      b[u] = *reinterpret_cast<const float4*>(vb + (size_t)g * (D_ * 4));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = a[u].x * b[u].x;
+      d = fmaf(a[u].y, b[u].y, d);
+      d = fmaf(a[u].z, b[u].z, d);
+      d = fmaf(a[u].w, b[u].w, d);
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+      if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+      if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
+      mine = li == s0 + u ? d : mine;
+    }
+  }
+  if (p < n_scored) {
+    if (LOGITS_EID) logits[oe] = mine;
+    if (logits_csr) logits_csr[op] = mine;
+  } else if (p < n_edges) {
+    if (LOGITS_EID) logits[oe] = 0.f;
+    if (logits_csr) logits_csr[op] = 0.f;
+  }
+}
+
+template <int D_>
+static int launch_att_fold_tail(const AttArgs& a) {
+  const int64_t waves = (a.n_edges + kWave - 1) / kWave;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  if (a.logits)
+    hipLaunchKernelGGL((att_fold_tail_kernel<D_, true>), dim3(blocks), dim3(256), 0, a.st, a.n_rel, a.rel_ptr,
+                       a.n_edges, a.src_g, a.gid, a.perm, a.pos_g, a.ent, a.G_tab, a.logits, a.logits_csr);
+  else
+    hipLaunchKernelGGL((att_fold_tail_kernel<D_, false>), dim3(blocks), dim3(256), 0, a.st, a.n_rel, a.rel_ptr,
+                       a.n_edges, a.src_g, a.gid, a.perm, a.pos_g, a.ent, a.G_tab, a.logits, a.logits_csr);
+  KGAT_CHECK_LAUNCH("att_fold_tail");
+  return KGAT_OK;
+}
+
 }  // namespace kgat
 
 using namespace kgat;
@@ -303,6 +387,49 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   a.n_edges = n_edges;
   a.gid = gid; a.gptr = gptr; a.g_node = g_node; a.G_tab = G_tab;
   return launch_att_split_any(d, a);
+}
+
+int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel) {
+  return kgat_att_score_split_supported(n_nodes, d, k, n_rel);
+}
+
+int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                              const int32_t* g_node, int64_t n_groups, const float* ent,
+                              const float* W_R, const float* rel, float* V_tab, float* logits,
+                              float* logits_csr, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_groups >= 0 && n_edges < INT32_MAX,
+                 "att_score_folded: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  if (!kgat_att_score_folded_supported(n_nodes, d, k, n_rel)) {
+    set_error("att_score_folded: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+              kAttMaxRelLds, d, k, n_rel);
+    return KGAT_E_UNSUPPORTED;
+  }
+  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && ent && W_R && rel, "att_score_folded: null pointer");
+  KGAT_CHECK_ARG(logits || logits_csr, "att_score_folded: no output requested");
+  KGAT_CHECK_ARG(n_groups == 0 || (g_node && V_tab), "att_score_folded: null group table");
+  KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_folded: logits_csr needs pos_g");
+  KGAT_CHECK_ARG((unsigned long long)n_groups * (unsigned long long)d * 4ull < (1ull << 40),
+                 "att_score_folded: group table too large");
+  AttArgs a;
+  a.grid = 0;
+  a.st = as_stream(stream);
+  a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
+  a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
+  a.pos_g = pos_g;
+  a.n_edges = n_edges;
+  a.gid = gid; a.gptr = gptr; a.g_node = g_node; a.G_tab = V_tab;
+  if (n_groups > 0) {
+    const int rc = launch_att_fold_head_any(d, a);
+    if (rc != KGAT_OK) return rc;
+  }
+  switch (d) {
+    case 16: return launch_att_fold_tail<16>(a);
+    case 32: return launch_att_fold_tail<32>(a);
+    default: return launch_att_fold_tail<64>(a);
+  }
 }
 
 }  // extern "C"

@@ -104,6 +104,7 @@ struct AttArgs {
 // results from VGPRs directly); returns KGAT_E_UNSUPPORTED for widths it does not cover.
 int launch_att_persistent_any(int d, bool accurate_tanh, const AttArgs& a);
 int launch_att_split_any(int d, const AttArgs& a);
+int launch_att_fold_head_any(int d, const AttArgs& a);  // writes V (n_groups x d) into a.G_tab
 constexpr int kAttMaxRelLds = 4096;
 
 }  // namespace kgat

@@ -471,6 +471,204 @@ static int launch_att_split_d(const AttArgs& a) {
                   : launch_att_split<D_, MODE_TAIL, false>(a, a.rel_ptr, a.src_g);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Folded form.  The logit is bilinear in the tail row:
+//     sum_j (e_t W_r)_j * T_j  =  e_t . (W_r T),        T = tanh(e_h W_r + e_r),
+// so the whole relation-space work can be done once per (head, relation) group:
+// V[g] = W_r tanh(W_r^T e_h + e_r) (a d-vector), after which an edge costs one d-length dot
+// product with its tail row (att_fold_tail_kernel in kgat_att.hip) instead of a d x k
+// projection.  The contraction order differs from the reference's (sum over k first there,
+// over d last here): results agree to fp32 rounding (~1e-6 relative), not bit for bit.
+//
+// One wavefront owns 16-group tiles.  Both products run on the MFMA unit without a transpose
+// in between: the first one is issued with the operands swapped (A = W_r fragment, B = head
+// rows), which leaves G^T in the accumulators - lane (i, q), register (c, j) holds
+// G[group i][column 16c + 4q + j] - and that is exactly a B fragment of the second product if
+// its contraction steps are taken in the order (c, j), with W_r's A fragments loaded to match.
+template <int D_>
+__global__ __launch_bounds__(kAttThreads) void att_fold_head_kernel(
+    int n_rel, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ V_tab) {
+  constexpr int K_ = D_;
+  constexpr int KS = D_ / 4, KT = K_ / 16;
+  __shared__ int32_t s_tptr[kAttMaxRelLds + 1];  // tile prefix per relation
+  const int tid = threadIdx.x;
+  for (int r = tid; r < n_rel; r += kAttThreads) s_tptr[r + 1] = (gptr[r + 1] - gptr[r] + 15) >> 4;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t run = 0;
+    s_tptr[0] = 0;
+    for (int r = 0; r < n_rel; ++r) {
+      run += s_tptr[r + 1];
+      s_tptr[r + 1] = run;
+    }
+  }
+  __syncthreads();
+  const int32_t n_tiles = s_tptr[n_rel];
+  const int lane = tid % kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n_waves = (int64_t)gridDim.x * (kAttThreads / kWave);
+  const int64_t wv = (int64_t)blockIdx.x * (kAttThreads / kWave) + tid / kWave;
+  const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
+  const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
+  if (t_begin >= t_end) return;
+
+  float w1[KS][KT];      // W_r[krow(s, q)][16c + i]        (first product, as in the other kernels)
+  float w2[KT][KT][4];   // W_r[16c' + i][16c + 4q + j]     (second product, contraction step (c, j))
+  float relv[KT][4];     // e_r[16c + 4q + j] * 2 log2(e)
+  int32_t t = t_begin;
+  while (t < t_end) {
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = __builtin_amdgcn_readfirstlane(lo);
+    const int32_t rbeg = __builtin_amdgcn_readfirstlane(gptr[r]);
+    const int32_t rend = __builtin_amdgcn_readfirstlane(gptr[r + 1]);
+    const int32_t tfirst = __builtin_amdgcn_readfirstlane(s_tptr[r]);
+    int32_t seg_end = __builtin_amdgcn_readfirstlane(s_tptr[r + 1]);
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    const int32_t n_seg = seg_end - t;
+    const int32_t g0 = rbeg + ((t - tfirst) << 4);
+    {
+      const float* W = W_R + (size_t)r * D_ * K_;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int krow = 16 * (s >> 2) + 4 * q + (s & 3);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) w1[s][c] = W[krow * K_ + 16 * c + i];
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+          const float4 v = *reinterpret_cast<const float4*>(W + (16 * c2 + i) * K_ + 16 * c + 4 * q);
+          w2[c2][c][0] = v.x; w2[c2][c][1] = v.y; w2[c2][c][2] = v.z; w2[c2][c][3] = v.w;
+        }
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(rel + (size_t)r * K_ + 16 * c + 4 * q);
+        relv[c][0] = v.x * kTwoLog2e; relv[c][1] = v.y * kTwoLog2e;
+        relv[c][2] = v.z * kTwoLog2e; relv[c][3] = v.w * kTwoLog2e;
+      }
+    }
+
+    auto load_idx = [&](int32_t n) -> int32_t {
+      n = n < n_seg ? n : n_seg - 1;
+      int32_t g = g0 + (n << 4) + i;
+      g = g < rend ? g : rend - 1;
+      return g_node[g];
+    };
+    struct Buf { float a[KS]; };
+    auto load_rows = [&](Buf& f, int32_t row) {
+      const char* base = reinterpret_cast<const char*>(ent);
+      const uint32_t o = (uint32_t)row * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+      for (int m = 0; m < D_ / 16; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(base + o + m * 64);
+        f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
+      }
+    };
+    auto tile = [&](int32_t n, const Buf& f) {
+      floatx4 acc[KT];
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s][c], f.a[s], acc[c], 0, 0, 0);
+      // acc[c][j] = (e_h W_r)[group i][16c + 4q + j]
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
+      floatx4 v[KT];
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c2 = 0; c2 < KT; ++c2)
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c2][c][j], acc[c][j], v[c2], 0, 0, 0);
+      // v[c2][j] = V[group i][16c2 + 4q + j]
+      const int32_t g = g0 + (n << 4) + i;
+      if (g < rend) {
+#pragma unroll
+        for (int c2 = 0; c2 < KT; ++c2) {
+          float4 o;
+          o.x = v[c2][0]; o.y = v[c2][1]; o.z = v[c2][2]; o.w = v[c2][3];
+          *reinterpret_cast<float4*>(V_tab + (size_t)g * D_ + 16 * c2 + 4 * q) = o;
+        }
+      }
+    };
+
+    // three-deep ring, indices requested before rows (see att_split_kernel)
+    Buf b0, b1, b2;
+    int32_t rc;
+    {
+      const int32_t r0 = load_idx(0), r1 = load_idx(1);
+      rc = load_idx(2);
+      load_rows(b0, r0);
+      load_rows(b1, r1);
+    }
+#define KGAT_FOLD_STEP(BCUR, BFILL)                  \
+    {                                                \
+      const int32_t rn = load_idx(n + 3);            \
+      load_rows(BFILL, rc);                          \
+      __builtin_amdgcn_sched_barrier(0);             \
+      tile(n, BCUR);                                 \
+      __builtin_amdgcn_sched_barrier(0);             \
+      rc = rn;                                       \
+      ++n;                                           \
+    }
+    int32_t n = 0;
+    while (n < n_seg) {
+      KGAT_FOLD_STEP(b0, b2)
+      if (n >= n_seg) break;
+      KGAT_FOLD_STEP(b1, b0)
+      if (n >= n_seg) break;
+      KGAT_FOLD_STEP(b2, b1)
+    }
+#undef KGAT_FOLD_STEP
+    t = seg_end;
+  }
+}
+
+template <int D_>
+static int launch_att_fold_head(const AttArgs& a) {
+  static int blocks_per_cu = 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_fold_head_kernel<D_>, kAttThreads, 0) != hipSuccess ||
+        nb < 1)
+      nb = 1;
+    blocks_per_cu = nb > 8 ? 8 : nb;
+  }
+  hipLaunchKernelGGL((att_fold_head_kernel<D_>), dim3((unsigned)(cus * blocks_per_cu)), dim3(kAttThreads), 0, a.st,
+                     a.n_rel, a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
+  KGAT_CHECK_LAUNCH("att_fold_head");
+  return KGAT_OK;
+}
+
+int launch_att_fold_head_any(int d, const AttArgs& a) {
+  switch (d) {
+    case 16: return launch_att_fold_head<16>(a);
+    case 32: return launch_att_fold_head<32>(a);
+    case 64: return launch_att_fold_head<64>(a);
+    default: return KGAT_E_UNSUPPORTED;
+  }
+}
+
 int launch_att_split_any(int d, const AttArgs& a) {
   switch (d) {
     case 16: return launch_att_split_d<16>(a);

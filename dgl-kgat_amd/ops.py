@@ -197,9 +197,14 @@ def att_score_split_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_split_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
 
+def att_score_folded_supported(n_nodes, d, k, n_rel):
+    return bool(_lib.load().kgat_att_score_folded_supported(int(n_nodes), int(d), int(k), int(n_rel)))
+
+
 def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups, ent, W_R, rel,
-                    want_csr=True, g_tab=None, want_eid=True):
-    """Attention logits via head groups (see kgat_att_score_split_f32).  Returns
+                    want_csr=True, g_tab=None, want_eid=True, folded=False):
+    """Attention logits via head groups (see kgat_att_score_split_f32; folded=True:
+    kgat_att_score_folded_f32, whose scratch table is n_groups x d).  Returns
     (logits edge-id order, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
@@ -212,15 +217,21 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
     _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
     _need(gptr, torch.int32, "gptr", (n_rel + 1,))
     _need(g_node, torch.int32, "g_node")
+    width = d if folded else k
     if g_tab is None:
-        g_tab = torch.empty((max(n_groups, 1), k), dtype=torch.float32, device=ent.device)
+        g_tab = torch.empty((max(n_groups, 1), width), dtype=torch.float32, device=ent.device)
+    else:
+        _need(g_tab, torch.float32, "g_tab")
+        if g_tab.numel() < max(n_groups, 1) * width:
+            raise ValueError("g_tab holds %d floats, needs %d" % (g_tab.numel(), max(n_groups, 1) * width))
     logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
+    name = "kgat_att_score_folded_f32" if folded else "kgat_att_score_split_f32"
     with _timed("att_score", (e, d, k)):
-        check(_lib.load().kgat_att_score_split_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
-                                                   _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), n_groups,
-                                                   _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(g_tab), _ptr(logits),
-                                                   _ptr(logits_csr), _stream(ent)), "kgat_att_score_split_f32")
+        check(getattr(_lib.load(), name)(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
+                                         _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), n_groups,
+                                         _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(g_tab), _ptr(logits),
+                                         _ptr(logits_csr), _stream(ent)), name)
     return logits, logits_csr
 
 
@@ -351,6 +362,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
            "KGATLibraryError"]

@@ -138,6 +138,21 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const float* W_R, const float* rel, float* G_tab, float* logits,
                              float* logits_csr, kgat_stream_t stream);
 
+/* Folded form of the same logits (reference models.py:135-144, restated).  The logit is bilinear
+ * in the tail row: sum_j (ent[t] W_r)_j T_j = ent[t] . (W_r T) with T = tanh(ent[h] W_r + rel[r]),
+ * so V[g] = W_r T (a d-vector) is computed once per (head, relation) group into V_tab
+ * (n_groups x d floats, caller scratch) and an edge costs one d-length dot product.  Same
+ * inputs and outputs as kgat_att_score_split_f32; the contraction order differs from the
+ * reference's, so the results agree with the other forms to fp32 rounding (~1e-6 relative to
+ * sum_j |t_j T_j|), not bit for bit. */
+int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel);
+int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                              const int32_t* g_node, int64_t n_groups, const float* ent,
+                              const float* W_R, const float* rel, float* V_tab, float* logits,
+                              float* logits_csr, kgat_stream_t stream);
+
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
  *   a[e] = exp(s[e] - max_{e'->dst e} s[e']) / sum_{e'->dst e} exp(s[e'] - max)

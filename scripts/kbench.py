@@ -78,7 +78,10 @@ def main():
         print("head groups: %d (%.2f edges per group)" % (n_groups, E / max(n_groups, 1)))
         if ops.att_score_split_supported(n, D, D, R):
             fns["split"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab)
-            algos = algos + ["split"]
+            fns["split_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, want_eid=False)
+            fns["folded"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True)
+            fns["folded_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True, want_eid=False)
+            algos = algos + ["split", "folded"]
         if args.same_rows:  # diagnostic: every edge reads rows 0..15 (cache resident): isolates gather latency
             sz, dz = sg % 16, dg % 16
             for a in algos:

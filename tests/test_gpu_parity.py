@@ -293,6 +293,40 @@ def test_att_split_head_groups(K, dev, d):
     assert rel_err_inf(split, ref) < 1e-5
     _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
     assert np.array_equal(split_csr.cpu().numpy(), split[eid.cpu().numpy()])
+    # folded form: W_r tanh(.) once per group, a d-length dot per edge - another contraction
+    # order, so fp32 rounding apart from the others, same tolerance against the oracle
+    for want_eid in (True, False):
+        fold, fold_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                             tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True, want_eid=want_eid)
+        assert rel_err_inf(fold_csr.cpu().numpy(), ref[eid.cpu().numpy()]) < 1e-5
+        if want_eid:
+            assert torch.equal(fold_csr, fold[eid.long()])
+            assert np.all(fold.cpu().numpy()[(et < 0) | (et >= R)] == 0)
+        else:
+            assert fold is None
+
+
+def test_att_folded_ragged_tail_positions(K, dev):
+    """Folded form on edge counts that are not multiples of the 64-position wavefront chunk, with
+    and without an unscored tail, and one relation only."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(77)
+    for n, e, R, lo in ((50, 1, 1, 0), (50, 63, 2, 0), (90, 65, 3, -1), (300, 1000, 1, 0), (300, 4097, 5, -2)):
+        src, dst = rng.integers(0, n, e).astype(np.int32), rng.integers(0, max(n // 3, 1), e).astype(np.int32)
+        et = rng.integers(lo, R, e).astype(np.int32)
+        rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+        gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+        d = 32
+        ent = rng.standard_normal((n, d)).astype(np.float32)
+        W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+        rel = rng.standard_normal((R, d)).astype(np.float32)
+        ref = orc.att_score(ent, W, rel, src, dst, et)
+        fold, fold_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                             tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True)
+        _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        assert rel_err_inf(fold.cpu().numpy(), ref) < 1e-5, (n, e, R)
+        assert np.all(fold.cpu().numpy()[et < 0] == 0)
+        assert torch.equal(fold_csr, fold[eid.long()])
 
 
 def _model_from_golden(K, g, dev):
