@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
     const int32_t* __restrict__ gid,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g, const float* __restrict__ ent,
     const float* __restrict__ V_tab, float* __restrict__ logits, float* __restrict__ logits_csr) {
-  constexpr int LPE = D_ / 4;
+  constexpr int LPE = D_ / 4 < 16 ? D_ / 4 : 16;  // lanes per edge
+  constexpr int VPL = D_ / (4 * LPE);              // float4 pieces per lane (2 at d = 128)
   const int64_t n_scored = rel_ptr[n_rel];
   const int lane = threadIdx.x % kWave;
   const int li = lane % LPE;
@@ -232,24 +233,34 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
   const char* eb = reinterpret_cast<const char*>(ent) + v_off_lo;
   const char* vb = reinterpret_cast<const char*>(V_tab) + v_off_lo;
   float mine = 0.f;
-  constexpr int U = LPE < 4 ? LPE : 4;
+  constexpr int U = (LPE < 4 ? LPE : 4) / (VPL > 1 ? 2 : 1);
 #pragma unroll
   for (int s0 = 0; s0 < LPE; s0 += U) {
-    float4 a[U], b[U];
+    float4 a[U][VPL], b[U][VPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int from = (lane - li + s0 + u) << 2;  // lane (group base + step)
       const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)e_off);
       const int32_t g = __builtin_amdgcn_ds_bpermute(from, my_g);
-      a[u] = *reinterpret_cast<const float4*>(eb + eo);
-      b[u] = *reinterpret_cast<const float4*>(vb + (size_t)g * (D_ * 4));
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        a[u][v] = *reinterpret_cast<const float4*>(eb + eo + v * (LPE * 16));
+        b[u][v] = *reinterpret_cast<const float4*>(vb + (size_t)g * (D_ * 4) + v * (LPE * 16));
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float d = a[u].x * b[u].x;
-      d = fmaf(a[u].y, b[u].y, d);
-      d = fmaf(a[u].z, b[u].z, d);
-      d = fmaf(a[u].w, b[u].w, d);
+      float d = a[u][0].x * b[u][0].x;
+      d = fmaf(a[u][0].y, b[u][0].y, d);
+      d = fmaf(a[u][0].z, b[u][0].z, d);
+      d = fmaf(a[u][0].w, b[u][0].w, d);
+#pragma unroll
+      for (int v = 1; v < VPL; ++v) {
+        d = fmaf(a[u][v].x, b[u][v].x, d);
+        d = fmaf(a[u][v].y, b[u][v].y, d);
+        d = fmaf(a[u][v].z, b[u][v].z, d);
+        d = fmaf(a[u][v].w, b[u][v].w, d);
+      }
       d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
       d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
       if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
@@ -390,7 +401,8 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
 }
 
 int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel) {
-  return kgat_att_score_split_supported(n_nodes, d, k, n_rel);
+  return d == k && (d == 16 || d == 32 || d == 64 || d == 128) && n_rel > 0 && n_rel <= kAttMaxRelLds &&
+         (unsigned long long)n_nodes * (unsigned long long)d * 4ull < (1ull << 32);
 }
 
 int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
@@ -403,7 +415,7 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
                  "att_score_folded: bad size");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_folded_supported(n_nodes, d, k, n_rel)) {
-    set_error("att_score_folded: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+    set_error("att_score_folded: needs d == k in {16,32,64,128}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
               kAttMaxRelLds, d, k, n_rel);
     return KGAT_E_UNSUPPORTED;
   }
@@ -428,7 +440,8 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
   switch (d) {
     case 16: return launch_att_fold_tail<16>(a);
     case 32: return launch_att_fold_tail<32>(a);
-    default: return launch_att_fold_tail<64>(a);
+    case 64: return launch_att_fold_tail<64>(a);
+    default: return launch_att_fold_tail<128>(a);
   }
 }
 

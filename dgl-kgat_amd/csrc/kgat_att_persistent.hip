@@ -4,6 +4,8 @@
 // Separate translation unit because it is built with -mllvm -amdgpu-mfma-vgpr-form=1 (MFMA
 // results in VGPRs, no v_accvgpr_read copies in the epilogue), which the LDS-staged chunk
 // kernels of kgat_att.hip do not want (it costs them occupancy).
+#include <stdlib.h>
+
 #include "kgat_att_common.h"
 
 namespace kgat {
@@ -660,11 +662,174 @@ static int launch_att_fold_head(const AttArgs& a) {
   return KGAT_OK;
 }
 
+// Folded head kernel for widths whose W_r does not fit the register file (d = k = 128: 64 KB).
+// One 512-thread workgroup per CU keeps the current relation's W_r in LDS, row-major with a
+// 4-float pad (bank-conflict-free for both fragment shapes: the first product reads
+// W[f(s,q)][16c+i] as ds_read_b32, the second W[16c'+i][16c+4q .. +3] as ds_read_b128), and its
+// eight wavefronts take the 16-group tiles of the workgroup's contiguous tile range round
+// robin.  A tile is 2 * (d/4) * (d/16) MFMAs (512 at d = 128, ~16k cycles), so one tile of
+// row look-ahead hides the gather.
+constexpr int kFoldLdsThreads = 512;
+
+template <int D_>
+__global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
+    int n_rel, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ V_tab) {
+  constexpr int K_ = D_;
+  constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFoldLdsThreads / kWave;
+  __shared__ int32_t s_tptr[kAttMaxRelLds + 1];
+  __shared__ __attribute__((aligned(16))) float s_w[D_ * LD];
+  const int tid = threadIdx.x;
+  for (int r = tid; r < n_rel; r += kFoldLdsThreads) s_tptr[r + 1] = (gptr[r + 1] - gptr[r] + 15) >> 4;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t run = 0;
+    s_tptr[0] = 0;
+    for (int r = 0; r < n_rel; ++r) {
+      run += s_tptr[r + 1];
+      s_tptr[r + 1] = run;
+    }
+  }
+  __syncthreads();
+  const int32_t n_tiles = s_tptr[n_rel];
+  const int lane = tid % kWave, w = tid / kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int32_t t_begin = (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
+  const int32_t t_end = (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+
+  struct Buf { float a[KS]; };
+  auto load_rows = [&](Buf& f, int32_t row) {
+    const char* base = reinterpret_cast<const char*>(ent);
+    const uint32_t o = (uint32_t)row * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+    for (int m = 0; m < D_ / 16; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(base + o + m * 64);
+      f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
+    }
+  };
+
+  int32_t t = t_begin;
+  while (t < t_end) {  // workgroup-uniform loop over relation segments
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int32_t rbeg = gptr[r], rend = gptr[r + 1];
+    const int32_t tfirst = s_tptr[r];
+    int32_t seg_end = s_tptr[r + 1];
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    __syncthreads();  // every wave is done with the previous relation's W_r
+    {
+      const float* W = W_R + (size_t)r * D_ * K_;
+      for (int idx = tid * 4; idx < D_ * K_; idx += kFoldLdsThreads * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W + idx);
+        *reinterpret_cast<float4*>(s_w + (idx / K_) * LD + (idx % K_)) = v;
+      }
+    }
+    __syncthreads();
+    float relv[KT][4];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(rel + (size_t)r * K_ + 16 * c + 4 * q);
+      relv[c][0] = v.x * kTwoLog2e; relv[c][1] = v.y * kTwoLog2e;
+      relv[c][2] = v.z * kTwoLog2e; relv[c][3] = v.w * kTwoLog2e;
+    }
+    auto row_of_tile = [&](int32_t n) -> int32_t {
+      n = n < seg_end ? n : seg_end - 1;
+      int32_t g = rbeg + ((n - tfirst) << 4) + i;
+      g = g < rend ? g : rend - 1;
+      return g_node[g];
+    };
+    auto tile = [&](int32_t n, const Buf& f) {
+      floatx4 acc[KT];
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      const float* w1 = s_w + (4 * q) * LD + i;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
+      floatx4 v[KT];
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      const float* w2 = s_w + i * LD + 4 * q;
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < KT; ++c2) {
+          const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+        }
+      const int32_t g = rbeg + ((n - tfirst) << 4) + i;
+      if (g < rend) {
+#pragma unroll
+        for (int c2 = 0; c2 < KT; ++c2) {
+          float4 o;
+          o.x = v[c2][0]; o.y = v[c2][1]; o.z = v[c2][2]; o.w = v[c2][3];
+          *reinterpret_cast<float4*>(V_tab + (size_t)g * D_ + 16 * c2 + 4 * q) = o;
+        }
+      }
+    };
+    int32_t n = t + w;
+    if (n < seg_end) {
+      Buf b0, b1;
+      int32_t rn = row_of_tile(n + NW);
+      load_rows(b0, row_of_tile(n));
+      while (true) {
+        load_rows(b1, rn);
+        rn = row_of_tile(n + 2 * NW);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(n, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        n += NW;
+        if (n >= seg_end) break;
+        load_rows(b0, rn);
+        rn = row_of_tile(n + 2 * NW);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(n, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        n += NW;
+        if (n >= seg_end) break;
+      }
+    }
+    t = seg_end;
+  }
+}
+
+template <int D_>
+static int launch_att_fold_head_lds(const AttArgs& a) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  hipLaunchKernelGGL((att_fold_head_lds_kernel<D_>), dim3((unsigned)cus), dim3(kFoldLdsThreads), 0, a.st, a.n_rel,
+                     a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
+  KGAT_CHECK_LAUNCH("att_fold_head_lds");
+  return KGAT_OK;
+}
+
 int launch_att_fold_head_any(int d, const AttArgs& a) {
+  // A/B switch for measurements: the LDS-resident-W kernel at d = 64 (default: W_r in registers)
+  static const bool lds64 = getenv("KGAT_FOLD_HEAD_LDS") != nullptr;
   switch (d) {
     case 16: return launch_att_fold_head<16>(a);
     case 32: return launch_att_fold_head<32>(a);
-    case 64: return launch_att_fold_head<64>(a);
+    case 64: return lds64 ? launch_att_fold_head_lds<64>(a) : launch_att_fold_head<64>(a);
+    case 128: return launch_att_fold_head_lds<128>(a);
     default: return KGAT_E_UNSUPPORTED;
   }
 }

@@ -437,15 +437,17 @@ class DGLGraph:
         # actually share; otherwise the one-kernel form.
         # "folded" (default) does the whole relation-space product per group and a d-length dot
         # per edge; "split" keeps the reference's contraction order (bit-identical to "one")
-        if algo == "auto":
-            algo = os.environ.get("KGAT_ATT_FORM", "auto")
-        # (measured on MI355X, d = 64: folded ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges,
-        # one-kernel 0.153 ms per 1e6 edges -> folded wins below ~0.74 groups per edge)
-        shares = 4 * groups.n_groups <= 3 * st.n_edges if algo in ("auto", "folded") else \
-            2 * groups.n_groups <= st.n_edges
-        grouped = algo in ("auto", "folded", "split") and (shares or algo != "auto") and \
-            ops.att_score_split_supported(st.n_nodes, d, k, n_rel)
-        folded = grouped and algo != "split"
+        form = os.environ.get("KGAT_ATT_FORM", "auto") if algo == "auto" else algo
+        if form == "auto":
+            # measured on MI355X, d = 64: folded ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges,
+            # one-kernel 0.153 ms per 1e6 edges -> folded wins below ~0.74 groups per edge
+            if 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel):
+                form = "folded"
+            elif 2 * groups.n_groups <= st.n_edges and ops.att_score_split_supported(st.n_nodes, d, k, n_rel):
+                form = "split"
+            else:
+                form = "one"
+        grouped, folded = form in ("folded", "split"), form == "folded"
         if grouped:
             width = d if folded else k
             g_tab = groups.g_tab.get(width)  # per-group scratch table, kept with the graph
@@ -458,8 +460,8 @@ class DGLGraph:
         else:
             _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                           ent_c, W_c, rel_c, pos_g=groups.pos_g,
-                                          algo="auto" if algo in ("auto", "folded", "split", "one") else algo)
-        st.last_att_form = (("folded" if folded else "split") if grouped else "one", groups.n_groups)
+                                          algo="auto" if form == "one" else form)
+        st.last_att_form = (form if grouped else "one", groups.n_groups)
         _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
                                     want_out=False, want_csr=True)
         a = ops.gather(st.csr_pos(dev), a_csr)  # edge-id order: coalesced writes, cached reads

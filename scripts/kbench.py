@@ -76,6 +76,10 @@ def main():
         gid, gptr, g_node, n_groups = ops.head_groups(rp2, dg2)
         g_tab = torch.empty((max(n_groups, 1), D), device=dev)
         print("head groups: %d (%.2f edges per group)" % (n_groups, E / max(n_groups, 1)))
+        if ops.att_score_folded_supported(n, D, D, R) and not ops.att_score_split_supported(n, D, D, R):
+            fns["folded"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True)
+            fns["folded_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True, want_eid=False)
+            algos = algos + ["folded"]
         if ops.att_score_split_supported(n, D, D, R):
             fns["split"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab)
             fns["split_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, want_eid=False)

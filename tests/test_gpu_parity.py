@@ -306,6 +306,31 @@ def test_att_split_head_groups(K, dev, d):
             assert fold is None
 
 
+def test_att_folded_d128(K, dev):
+    """d = k = 128: W_r (64 KB) lives in LDS, 32 floats per lane in the per-edge dot."""
+    from dgl_kgat_amd import ops
+    n, e, R, d = 900, 40000, 5, 128
+    src, dst = random_graph(21, n, e, hub=3000, isolated_tail=10)
+    rng = np.random.default_rng(22)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)
+    et[et == 2] = 3  # an empty relation
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    assert ops.att_score_folded_supported(n, d, d, R) and not ops.att_score_split_supported(n, d, d, R)
+    fold, fold_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                         tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True)
+    _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    assert rel_err_inf(fold.cpu().numpy(), ref) < 1e-5
+    assert np.all(fold.cpu().numpy()[(et < 0) | (et >= R)] == 0)
+    assert torch.equal(fold_csr, fold[eid.long()])
+    full, _ = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent, dev), tf(W, dev), tf(rel, dev), pos_g=pos_g)
+    assert rel_err_inf(fold.cpu().numpy(), full.cpu().numpy()) < 1e-5
+
+
 def test_att_folded_ragged_tail_positions(K, dev):
     """Folded form on edge counts that are not multiples of the 64-position wavefront chunk, with
     and without an unscored tail, and one relation only."""
