@@ -7,11 +7,15 @@ destination, and the attention logit is per edge, so a rank that holds all in-ed
 rows computes attention -> softmax -> aggregation -> bi-interaction with no exchange; the one
 exchange per layer is the layer OUTPUT: each rank writes its (hi-lo) x D_out rows into a
 zeroed N x D_out buffer and the buffers are summed with an RCCL all-reduce over xGMI (every
-row has exactly one non-zero contributor, so the sum is exact and order independent).
+row has exactly one non-zero contributor, so the sum is exact and order independent).  Two
+cheaper equivalents of that sum (direct slice exchange, per-owner broadcast) are selectable,
+see `Partition`.
 
 A shard is an ordinary DGLGraph over the full node set holding only the local edges (in
 global edge-id order), so every kernel runs on it unchanged.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -33,24 +37,76 @@ def balanced_row_bounds(in_degrees, world):
     return bounds
 
 
+EXCHANGE_MODES = ("allreduce", "p2p", "broadcast")
+
+
 class Partition:
-    def __init__(self, rank, world, bounds, n_nodes, group=None):
+    """Row ownership of one rank + the exchange of a layer output.
+
+    Exchange modes (``mode`` argument, default from ``KGAT_EXCHANGE``, else "allreduce"):
+
+    * ``allreduce`` - the owned rows inside a zeroed N x width buffer, summed over ranks (every
+      row has exactly one non-zero contributor: exact and order independent).  Moves
+      2(P-1)/P x N x width x 4 bytes per rank.
+    * ``p2p`` - every rank sends its own row slice to each peer and receives the peers' slices
+      straight into their place in the buffer (``batch_isend_irecv``: one grouped RCCL
+      send/recv set, a direct xGMI link per pair).  Half the bytes of the all-reduce.
+    * ``broadcast`` - one broadcast per owner of its slice (what an all-gather of unequal
+      slices amounts to).
+    All three leave the same bits in the buffer."""
+
+    def __init__(self, rank, world, bounds, n_nodes, group=None, mode=None):
         self.rank, self.world, self.bounds, self.n_nodes, self.group = rank, world, list(bounds), n_nodes, group
         self.lo, self.hi = bounds[rank], bounds[rank + 1]
+        self.mode = mode or os.environ.get("KGAT_EXCHANGE", "allreduce")
+        if self.mode not in EXCHANGE_MODES:
+            raise ValueError("exchange mode %r is not one of %s" % (self.mode, EXCHANGE_MODES))
+
+    def _global_rank(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def new_buffer(self, width, device, dtype=torch.float32):
+        """The N x width exchange buffer; zeroed only where the exchange mode sums."""
+        alloc = torch.zeros if self.mode == "allreduce" else torch.empty
+        return alloc((self.n_nodes, width), dtype=dtype, device=device)
+
+    def assemble(self, full):
+        """Complete `full` (N x width, this rank's rows already in place) with the other ranks'
+        rows, in place."""
+        if self.world == 1:
+            return full
+        b = self.bounds
+        if self.mode == "allreduce":
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        elif self.mode == "p2p":
+            ops_ = []
+            mine = full[self.lo:self.hi]
+            for peer in range(self.world):
+                if peer == self.rank:
+                    continue
+                if self.hi > self.lo:
+                    ops_.append(dist.P2POp(dist.isend, mine, self._global_rank(peer), group=self.group))
+                if b[peer + 1] > b[peer]:
+                    ops_.append(dist.P2POp(dist.irecv, full[b[peer]:b[peer + 1]], self._global_rank(peer),
+                                           group=self.group))
+            if ops_:
+                for work in dist.batch_isend_irecv(ops_):
+                    work.wait()
+        else:
+            for owner in range(self.world):
+                if b[owner + 1] > b[owner]:
+                    dist.broadcast(full[b[owner]:b[owner + 1]], src=self._global_rank(owner), group=self.group)
+        return full
 
     def pad(self, local_rows, width):
-        """This rank's rows inside a zeroed N x width buffer."""
-        full = torch.zeros((self.n_nodes, width), dtype=local_rows.dtype, device=local_rows.device)
+        """This rank's rows inside an N x width exchange buffer."""
+        full = self.new_buffer(width, local_rows.device, local_rows.dtype)
         full[self.lo:self.hi] = local_rows
         return full
 
     def exchange(self, local_rows, width):
-        """Zero-padded N x width buffer holding this rank's rows, all-reduced (sum): every row
-        has exactly one non-zero contributor, so the result is exact and order independent."""
-        full = self.pad(local_rows, width)
-        if self.world > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
-        return full
+        """The assembled N x width layer output from this rank's rows."""
+        return self.assemble(self.pad(local_rows, width))
 
     def propagate_local(self, g, h, weight):
         """The owned rows of one KGATConv output: aggregation (+ h*h_N epilogue) over the
@@ -71,18 +127,16 @@ class Partition:
     def propagate_fused(self, g, h, weight):
         """Forward-only form of `propagate` with fewer launches: the owned rows of
         LeakyReLU((h*h_N) W2^T) are written by the bi-interaction kernel straight into the
-        zeroed exchange buffer, then all-reduced."""
+        exchange buffer, then exchanged."""
         st = g._st
         csr = st.csr(h.device)
         w_csr = st.weight_in_csr_order(g.edata["w"].detach().reshape(-1).contiguous())
         prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
                         rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
-        full = torch.zeros((self.n_nodes, weight.shape[0]), dtype=torch.float32, device=h.device)
+        full = self.new_buffer(weight.shape[0], h.device)
         if self.hi > self.lo:
             ops.bi_interaction(prod, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
-        if self.world > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
-        return full
+        return self.assemble(full)
 
 
 def shard_graph(g, rank, world, group=None, bounds=None):

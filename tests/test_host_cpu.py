@@ -195,6 +195,12 @@ full_ref = torch.randn(n, 16)                      # what a single process would
 mine = full_ref[p.lo:p.hi].clone()                 # this rank's rows of a layer output
 full = p.exchange(mine, 16)                        # zero-padded buffer + all-reduce (gloo here, RCCL on GPUs)
 assert torch.equal(full, full_ref), "exchange did not reassemble the layer output"
+for mode in partition.EXCHANGE_MODES:              # the cheaper equivalents leave the same bits
+    q = partition.Partition(rank, world, p.bounds, n, mode=mode)
+    assert torch.equal(q.exchange(mine, 16), full_ref), mode
+    empty = partition.Partition(rank, world, [0] + [n] * world, n, mode=mode)   # rank 0 owns everything
+    got = empty.exchange(full_ref[empty.lo:empty.hi].clone(), 16)
+    assert torch.equal(got, full_ref), mode + " with empty slices"
 cnt = torch.tensor([len(keep)]); dist.all_reduce(cnt)
 assert int(cnt) == len(trip)
 dist.destroy_process_group()
