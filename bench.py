@@ -220,7 +220,12 @@ def main():
         e_att = att_info[0]
         ref_flops = e_att * (4 * D * D + 3 * D)
         form, n_groups = getattr(g._st, "last_att_form", ("one", 0))
-        if form == "folded":      # per group W_r^T e_h and W_r T (2 x 2dk), per edge a d-length dot
+        if form == "fused":       # as folded, in one launch; hub blocks recompute their V rows per tile
+            n_fold_tiles = int(g._st.rel_groups(g.edata["type"], n_rel).g_tab["tiles"][1][-1])
+            flops = n_fold_tiles * 16 * 4 * D * D + e_att * 2 * D
+            kern = "kgat_att_score_fused_f32 (att_fold_fused_kernel: per 16-group tile 2 MFMA products, V rows " \
+                   "in LDS, gather-dot over the tile's edges; %d tiles)" % n_fold_tiles
+        elif form == "folded":    # per group W_r^T e_h and W_r T (2 x 2dk), per edge a d-length dot
             flops = n_groups * 4 * D * D + e_att * 2 * D
             kern = "kgat_att_score_folded_f32 (att_fold_head_kernel: 2 MFMA products per (head, relation) group; " \
                    "att_fold_tail_kernel: gather-dot per edge)"

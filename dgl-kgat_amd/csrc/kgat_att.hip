@@ -445,4 +445,36 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
   }
 }
 
+int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel) {
+  return kgat_att_score_split_supported(n_nodes, d, k, n_rel);
+}
+
+int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                             const float* ent, const float* W_R, const float* rel, float* logits,
+                             float* logits_csr, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  if (!kgat_att_score_fused_supported(n_nodes, d, k, n_rel)) {
+    set_error("att_score_fused: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+              kAttMaxRelLds, d, k, n_rel);
+    return KGAT_E_UNSUPPORTED;
+  }
+  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && g_node && tiles && rel_tptr && ent && W_R && rel,
+                 "att_score_fused: null pointer");
+  KGAT_CHECK_ARG(logits || logits_csr, "att_score_fused: no output requested");
+  KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_fused: logits_csr needs pos_g");
+  AttArgs a;
+  a.grid = 0;
+  a.st = as_stream(stream);
+  a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
+  a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
+  a.pos_g = pos_g;
+  a.n_edges = n_edges;
+  a.gid = gid; a.gptr = gptr; a.g_node = g_node;
+  return launch_att_fold_fused_any(d, a, rel_tptr, tiles);
+}
+
 }  // extern "C"

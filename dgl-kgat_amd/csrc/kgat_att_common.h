@@ -104,7 +104,8 @@ struct AttArgs {
 // results from VGPRs directly); returns KGAT_E_UNSUPPORTED for widths it does not cover.
 int launch_att_persistent_any(int d, bool accurate_tanh, const AttArgs& a);
 int launch_att_split_any(int d, const AttArgs& a);
-int launch_att_fold_head_any(int d, const AttArgs& a);  // writes V (n_groups x d) into a.G_tab
+int launch_att_fold_head_any(int d, const AttArgs& a);
+int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);  // writes V (n_groups x d) into a.G_tab
 constexpr int kAttMaxRelLds = 4096;
 
 }  // namespace kgat

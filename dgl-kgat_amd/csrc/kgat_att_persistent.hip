@@ -822,6 +822,269 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
   return KGAT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused folded form: the V rows never leave the CU.  Work comes as tiles (kgat_fold_tiles): at
+// most 16 consecutive head groups of one relation and at most `cap` grouped positions.  A wave
+// computes the tile's V rows (two MFMA products, as att_fold_head_lds_kernel, W_r in LDS), parks
+// them in its own 16 x d LDS patch and walks the tile's positions itself: d/4 lanes per edge,
+// tail row from global memory, V row from LDS, DPP reduction, lane l ends with position pb + l.
+// The first 64 positions' tail rows are requested BEFORE the MFMA phase (they arrive while it
+// runs); descriptors and indices are requested one and two tiles ahead so that every load of
+// the steady state is a prefetch.  Positions past the first 64 of a tile (<= cap) are walked
+// with their indices requested one chunk ahead; their tail rows are not (the row buffer is 64
+// registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
+constexpr int kFusedThreads = 512;
+
+template <int D_, bool LOGITS_EID>
+__global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
+    int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
+    const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const int32_t* __restrict__ gid, const int32_t* __restrict__ src_g, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ pos_g, const float* __restrict__ ent, const float* __restrict__ W_R,
+    const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr) {
+  constexpr int K_ = D_;
+  constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFusedThreads / kWave;
+  constexpr int LPE = D_ / 4 < 16 ? D_ / 4 : 16;  // lanes per edge in the edge phase
+  constexpr int LDV = D_ + 4;
+  static_assert(D_ <= 64, "one float4 per lane per row");
+  __shared__ __attribute__((aligned(16))) float s_w[D_ * LD];
+  __shared__ __attribute__((aligned(16))) float s_v[NW][16 * LDV];
+  __shared__ int32_t s_next;  // next unclaimed tile of the current relation segment
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave, w = tid / kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int li = lane % LPE;
+  const int32_t* __restrict__ pos_or_perm = logits_csr ? pos_g : perm;
+
+  {  // relation ids outside [0, R): logit 0
+    const int64_t n_scored = rel_ptr[n_rel];
+    for (int64_t p = n_scored + (int64_t)blockIdx.x * kFusedThreads + tid; p < n_edges;
+         p += (int64_t)gridDim.x * kFusedThreads) {
+      if (LOGITS_EID) logits[perm[p]] = 0.f;
+      if (logits_csr) logits_csr[pos_g[p]] = 0.f;
+    }
+  }
+  const int32_t n_tiles = rel_tptr[n_rel];
+  const int32_t t_begin = (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
+  const int32_t t_end = (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  float* vrow = s_v[w];
+
+  int32_t t = t_begin;
+  while (t < t_end) {  // workgroup-uniform loop over relation segments
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rel_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int32_t rend = gptr[r + 1];
+    int32_t seg_end = rel_tptr[r + 1];
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    __syncthreads();  // every wave is done with the previous relation's W_r
+    if (tid == 0) s_next = t;
+    {
+      const float* W = W_R + (size_t)r * D_ * K_;
+      for (int idx = tid * 4; idx < D_ * K_; idx += kFusedThreads * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W + idx);
+        *reinterpret_cast<float4*>(s_w + (idx / K_) * LD + (idx % K_)) = v;
+      }
+    }
+    __syncthreads();
+    float relv[KT][4];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(rel + (size_t)r * K_ + 16 * c + 4 * q);
+      relv[c][0] = v.x * kTwoLog2e; relv[c][1] = v.y * kTwoLog2e;
+      relv[c][2] = v.z * kTwoLog2e; relv[c][3] = v.w * kTwoLog2e;
+    }
+
+    // descriptor of the wave's k-th tile of this segment (clamped: past the end it repeats the
+    // last one, whose loads are then harmless duplicates)
+    auto desc_of = [&](int32_t n) -> int4 {
+      n = n < seg_end ? n : seg_end - 1;
+      return tiles[n];
+    };
+    struct CIdx { int32_t row_off, lg, oe, op; };
+    auto head_idx = [&](const int4& d) -> int32_t {
+      int32_t g = d.y + i;
+      g = g < rend ? g : rend - 1;
+      return g_node[g];
+    };
+    auto chunk_idx = [&](const int4& d, int32_t p0) -> CIdx {
+      int32_t p = p0 + lane;
+      p = p < d.w ? p : d.w - 1;
+      CIdx c;
+      c.row_off = src_g[p] * (D_ * 4);
+      c.lg = gid[p] - d.y;
+      c.oe = LOGITS_EID ? perm[p] : 0;
+      c.op = pos_or_perm[p];
+      return c;
+    };
+    struct HBuf { float a[KS]; };
+    auto load_head = [&](HBuf& f, int32_t row) {
+      const char* base = reinterpret_cast<const char*>(ent);
+      const uint32_t o = (uint32_t)row * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+      for (int m = 0; m < D_ / 16; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(base + o + m * 64);
+        f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
+      }
+    };
+    struct EBuf { float4 r[LPE]; };
+    const char* eb = reinterpret_cast<const char*>(ent) + li * 16;
+    auto load_edges = [&](EBuf& e, const CIdx& c) {
+#pragma unroll
+      for (int s = 0; s < LPE; ++s) {
+        const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.row_off);
+        e.r[s] = *reinterpret_cast<const float4*>(eb + eo);
+      }
+    };
+    auto mfma_phase = [&](const HBuf& f) {
+      floatx4 acc[KT];
+#pragma unroll
+      for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      const float* w1 = s_w + (4 * q) * LD + i;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
+      floatx4 v[KT];
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      const float* w2 = s_w + i * LD + 4 * q;
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < KT; ++c2) {
+          const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
+          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+        }
+      // v[c2][j] = V[group i][16c2 + 4q + j] -> the wave's LDS patch, row = group
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tile's reads are done
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) {
+        float4 o;
+        o.x = v[c2][0]; o.y = v[c2][1]; o.z = v[c2][2]; o.w = v[c2][3];
+        *reinterpret_cast<float4*>(vrow + i * LDV + 16 * c2 + 4 * q) = o;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto edge_phase = [&](const EBuf& e, const CIdx& c, int32_t p0, int32_t pe) {
+      float mine = 0.f;
+#pragma unroll
+      for (int s = 0; s < LPE; ++s) {
+        const int32_t lg = __builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.lg);
+        const float4 b = *reinterpret_cast<const float4*>(vrow + lg * LDV + 4 * li);
+        float d = e.r[s].x * b.x;
+        d = fmaf(e.r[s].y, b.y, d);
+        d = fmaf(e.r[s].z, b.z, d);
+        d = fmaf(e.r[s].w, b.w, d);
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+        if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+        if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
+        mine = li == s ? d : mine;
+      }
+      if (p0 + lane < pe) {
+        if (LOGITS_EID) logits[c.oe] = mine;
+        if (logits_csr) logits_csr[c.op] = mine;
+      }
+    };
+
+    // Waves claim tiles one at a time from the segment (LDS counter), three tiles before they
+    // compute them - the look-ahead of the descriptor/index prefetch - so a wave that meets
+    // heavy tiles simply claims fewer.
+    auto claim = [&]() -> int32_t {
+      int32_t g = 0;
+      if (lane == 0) g = atomicAdd(&s_next, 1);
+      return __builtin_amdgcn_readfirstlane(g);
+    };
+    int32_t n = claim();
+    if (n < seg_end) {
+      int32_t n1 = claim(), n2 = claim();
+      // prologue: descriptors of the wave's next three tiles; head row index of two; chunk indices of one
+      int4 d0 = desc_of(n), d1 = desc_of(n1), d2 = desc_of(n2);
+      int32_t h0 = head_idx(d0), h1 = head_idx(d1);
+      CIdx c0 = chunk_idx(d0, d0.z);
+      HBuf hb0, hb1;
+      load_head(hb0, h0);
+#define KGAT_FUSED_STEP(HCUR, HNEXT)                                                   \
+      {                                                                                \
+        const int32_t n3 = claim();                                                    \
+        const int4 d3 = desc_of(n3);                                                   \
+        const int32_t h2 = head_idx(d2);                                               \
+        const CIdx c1 = chunk_idx(d1, d1.z);                                           \
+        CIdx cx = chunk_idx(d0, d0.z + kWave);  /* second chunk's indices, if any */    \
+        EBuf eb0;                                                                      \
+        load_edges(eb0, c0);                                                           \
+        load_head(HNEXT, h1);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        mfma_phase(HCUR);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        edge_phase(eb0, c0, d0.z, d0.w);                                               \
+        for (int32_t p0 = d0.z + kWave; p0 < d0.w; p0 += kWave) {                      \
+          load_edges(eb0, cx);                                                         \
+          const CIdx cn = chunk_idx(d0, p0 + kWave);                                   \
+          edge_phase(eb0, cx, p0, d0.w);                                               \
+          cx = cn;                                                                     \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        d0 = d1; d1 = d2; d2 = d3;                                                     \
+        h1 = h2;                                                                       \
+        c0 = c1;                                                                       \
+        n = n1; n1 = n2; n2 = n3;                                                      \
+      }
+      while (true) {
+        KGAT_FUSED_STEP(hb0, hb1)
+        if (n >= seg_end) break;
+        KGAT_FUSED_STEP(hb1, hb0)
+        if (n >= seg_end) break;
+      }
+#undef KGAT_FUSED_STEP
+    }
+    t = seg_end;
+  }
+}
+
+template <int D_>
+static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  if (a.logits)
+    hipLaunchKernelGGL((att_fold_fused_kernel<D_, true>), dim3((unsigned)cus), dim3(kFusedThreads), 0, a.st, a.n_rel,
+                       a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
+                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr);
+  else
+    hipLaunchKernelGGL((att_fold_fused_kernel<D_, false>), dim3((unsigned)cus), dim3(kFusedThreads), 0, a.st, a.n_rel,
+                       a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
+                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr);
+  KGAT_CHECK_LAUNCH("att_fold_fused");
+  return KGAT_OK;
+}
+
+int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  switch (d) {
+    case 16: return launch_att_fold_fused<16>(a, rel_tptr, tiles);
+    case 32: return launch_att_fold_fused<32>(a, rel_tptr, tiles);
+    case 64: return launch_att_fold_fused<64>(a, rel_tptr, tiles);
+    default: return KGAT_E_UNSUPPORTED;
+  }
+}
+
 int launch_att_fold_head_any(int d, const AttArgs& a) {
   // A/B switch for measurements: the LDS-resident-W kernel at d = 64 (default: W_r in registers)
   static const bool lds64 = getenv("KGAT_FOLD_HEAD_LDS") != nullptr;

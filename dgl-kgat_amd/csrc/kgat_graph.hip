@@ -304,6 +304,73 @@ __global__ void group_ptr_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
   if (r <= n_rel) gptr[r] = ex[rel_ptr[r]];
 }
 
+// ---- work tiles of the fused folded attention kernel (see kgat_fold_tiles in the header)
+__global__ void fold_gstart_kernel(int n_rel, const int32_t* __restrict__ rel_ptr, int64_t n_groups,
+                                   const int32_t* __restrict__ gid, int32_t* __restrict__ gstart) {
+  const int64_t n_scored = rel_ptr[n_rel];
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_scored && (p == 0 || gid[p] != gid[p - 1])) gstart[gid[p]] = (int32_t)p;
+  if (p == 0) gstart[n_groups] = (int32_t)n_scored;
+}
+// one thread: base-tile prefix per relation (16 groups per base tile, relations kept apart)
+__global__ void fold_base_ptr_kernel(int n_rel, const int32_t* __restrict__ gptr, int32_t* __restrict__ bptr) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int32_t run = 0;
+  bptr[0] = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    run += (gptr[r + 1] - gptr[r] + 15) >> 4;
+    bptr[r + 1] = run;
+  }
+}
+__device__ __forceinline__ int fold_base_tile(int n_rel, const int32_t* __restrict__ bptr,
+                                              const int32_t* __restrict__ gptr,
+                                              const int32_t* __restrict__ gstart, int32_t b, int32_t& g0,
+                                              int32_t& pb, int32_t& pe) {
+  int lo = 0, hi = n_rel;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (bptr[mid] <= b) lo = mid; else hi = mid;
+  }
+  g0 = gptr[lo] + ((b - bptr[lo]) << 4);
+  const int32_t g1 = g0 + 16 < gptr[lo + 1] ? g0 + 16 : gptr[lo + 1];
+  pb = gstart[g0];
+  pe = gstart[g1];
+  return lo;
+}
+// cnt[b] = number of tiles base tile b becomes (0 past the last base tile); cnt has nb_max + 1 entries
+__global__ void fold_count_kernel(int n_rel, int64_t nb_max, int cap, const int32_t* __restrict__ bptr,
+                                  const int32_t* __restrict__ gptr, const int32_t* __restrict__ gstart,
+                                  int32_t* __restrict__ cnt) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb_max) return;
+  int32_t c = 0;
+  if (b < bptr[n_rel]) {
+    int32_t g0, pb, pe;
+    fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, g0, pb, pe);
+    c = (pe - pb + cap - 1) / cap;
+    c = c > 0 ? c : 1;
+  }
+  cnt[b] = c;
+}
+// off = exclusive scan of cnt; writes the tiles, the tile prefix per relation and the tile count
+__global__ void fold_emit_kernel(int n_rel, int64_t nb_max, int cap, const int32_t* __restrict__ bptr,
+                                 const int32_t* __restrict__ gptr, const int32_t* __restrict__ gstart,
+                                 const int32_t* __restrict__ off, int32_t* __restrict__ tiles,
+                                 int32_t* __restrict__ rel_tptr) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= n_rel) rel_tptr[b] = off[bptr[b]];
+  if (b >= bptr[n_rel]) return;
+  int32_t g0, pb, pe;
+  const int r = fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, g0, pb, pe);
+  int32_t t = off[b];
+  int32_t p = pb;
+  do {
+    const int32_t q = p + cap < pe ? p + cap : pe;
+    reinterpret_cast<int4*>(tiles)[t++] = make_int4(r, g0, p, q);
+    p = q;
+  } while (p < pe);
+}
+
 static inline unsigned blocks_for(int64_t n, int threads) {
   return (unsigned)((n + threads - 1) / threads);
 }
@@ -444,6 +511,55 @@ int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const i
   hipLaunchKernelGGL(group_ptr_kernel, dim3(blocks_for(n_rel + 1, 256)), dim3(256), 0, st, n_rel,
                      rel_ptr, (const int32_t*)ex, gptr);
   KGAT_CHECK_LAUNCH("group_ptr");
+  return KGAT_OK;
+}
+
+static int64_t fold_base_max(int64_t n_groups, int n_rel) { return n_groups / 16 + n_rel + 1; }
+
+int64_t kgat_fold_tiles_max(int64_t n_edges, int64_t n_groups, int n_rel, int cap) {
+  if (n_edges < 0 || n_groups < 0 || n_rel < 0 || cap <= 0) return 0;
+  return fold_base_max(n_groups, n_rel) + n_edges / cap + 1;
+}
+
+size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel) {
+  const size_t nb = (size_t)fold_base_max(n_groups > 0 ? n_groups : 0, n_rel > 0 ? n_rel : 0) + 1;
+  return align_up(((size_t)(n_groups > 0 ? n_groups : 0) + 1) * 4, 256) + align_up(((size_t)n_rel + 2) * 4, 256) +
+         align_up(nb * 4, 256) + align_up(scan_workspace_elems((int64_t)nb) * 4, 256);
+}
+
+int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,
+                    const int32_t* gptr, int cap, int32_t* tiles, int32_t* rel_tptr, void* workspace,
+                    size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0 && n_edges < INT32_MAX - 1 && n_rel > 0 && n_groups >= 0 && n_groups <= n_edges,
+                 "fold_tiles: bad size");
+  KGAT_CHECK_ARG(cap >= 64 && cap % 64 == 0, "fold_tiles: cap must be a positive multiple of 64");
+  KGAT_CHECK_ARG(rel_ptr && gptr && tiles && rel_tptr && workspace, "fold_tiles: null pointer");
+  KGAT_CHECK_ARG(n_edges == 0 || gid, "fold_tiles: null pointer");
+  if (workspace_bytes < kgat_fold_tiles_workspace_bytes(n_groups, n_rel)) {
+    set_error("fold_tiles: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int64_t nb_max = fold_base_max(n_groups, n_rel);
+  Carver cv(workspace);
+  int32_t* gstart = cv.take<int32_t>((size_t)n_groups + 1);
+  int32_t* bptr = cv.take<int32_t>((size_t)n_rel + 2);
+  int32_t* cnt = cv.take<int32_t>((size_t)nb_max + 1);
+  int32_t* scan_ws = cv.take<int32_t>(scan_workspace_elems(nb_max + 1));
+  hipLaunchKernelGGL(fold_gstart_kernel, dim3(blocks_for(n_edges > 0 ? n_edges : 1, 256)), dim3(256), 0, st, n_rel,
+                     rel_ptr, n_groups, gid, gstart);
+  KGAT_CHECK_LAUNCH("fold_gstart");
+  hipLaunchKernelGGL(fold_base_ptr_kernel, dim3(1), dim3(64), 0, st, n_rel, gptr, bptr);
+  KGAT_CHECK_LAUNCH("fold_base_ptr");
+  hipLaunchKernelGGL(fold_count_kernel, dim3(blocks_for(nb_max + 1, 256)), dim3(256), 0, st, n_rel, nb_max, cap,
+                     (const int32_t*)bptr, gptr, (const int32_t*)gstart, cnt);
+  KGAT_CHECK_LAUNCH("fold_count");
+  const int rc = exclusive_scan_i32(cnt, nb_max + 1, scan_ws, st);
+  if (rc != KGAT_OK) return rc;
+  const int64_t n_thr = nb_max > n_rel + 1 ? nb_max : n_rel + 1;
+  hipLaunchKernelGGL(fold_emit_kernel, dim3(blocks_for(n_thr, 256)), dim3(256), 0, st, n_rel, nb_max, cap,
+                     (const int32_t*)bptr, gptr, (const int32_t*)gstart, (const int32_t*)cnt, tiles, rel_tptr);
+  KGAT_CHECK_LAUNCH("fold_emit");
   return KGAT_OK;
 }
 

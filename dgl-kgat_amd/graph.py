@@ -434,21 +434,31 @@ class DGLGraph:
         n_rel, d, k = W_R.shape
         ent_c, W_c, rel_c = ent.detach().contiguous(), W_R.detach().contiguous(), rel.detach().contiguous()
         # head-group forms (work shared by the edges of a (head, relation) group) when the groups
-        # actually share; otherwise the one-kernel form.
-        # "folded" (default) does the whole relation-space product per group and a d-length dot
-        # per edge; "split" keeps the reference's contraction order (bit-identical to "one")
+        # actually share; otherwise the one-kernel form.  "fused" (default, d <= 64) and "folded"
+        # do the whole relation-space product per group and a d-length dot per edge (one launch
+        # with the per-group vectors in LDS / two launches with a table); "split" keeps the
+        # reference's contraction order (bit-identical to "one")
         form = os.environ.get("KGAT_ATT_FORM", "auto") if algo == "auto" else algo
         if form == "auto":
             # measured on MI355X, d = 64: folded ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges,
-            # one-kernel 0.153 ms per 1e6 edges -> folded wins below ~0.74 groups per edge
-            if 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel):
+            # one-kernel 0.153 ms per 1e6 edges -> the group forms win below ~0.74 groups per edge
+            if 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_fused_supported(st.n_nodes, d, k, n_rel):
+                form = "fused"
+            elif 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel):
                 form = "folded"
             elif 2 * groups.n_groups <= st.n_edges and ops.att_score_split_supported(st.n_nodes, d, k, n_rel):
                 form = "split"
             else:
                 form = "one"
-        grouped, folded = form in ("folded", "split"), form == "folded"
-        if grouped:
+        if form == "fused":
+            tiles = groups.g_tab.get("tiles")  # graph-static work tiles of the fused kernel
+            if tiles is None:
+                tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups)
+            _, logits_csr = ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
+                                                groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
+                                                ent_c, W_c, rel_c, want_eid=False)
+        elif form in ("folded", "split"):
+            folded = form == "folded"
             width = d if folded else k
             g_tab = groups.g_tab.get(width)  # per-group scratch table, kept with the graph
             if g_tab is None:
@@ -461,7 +471,8 @@ class DGLGraph:
             _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                           ent_c, W_c, rel_c, pos_g=groups.pos_g,
                                           algo="auto" if form == "one" else form)
-        st.last_att_form = (form if grouped else "one", groups.n_groups)
+            form = "one"
+        st.last_att_form = (form, groups.n_groups)
         _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
                                     want_out=False, want_csr=True)
         a = ops.gather(st.csr_pos(dev), a_csr)  # edge-id order: coalesced writes, cached reads

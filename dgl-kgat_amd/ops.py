@@ -235,6 +235,59 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
     return logits, logits_csr
 
 
+FOLD_TILE_CAP = 128  # measured best on MI355X (64: 0.268, 128: 0.251, 192: 0.261, 256: 0.283 ms)
+
+
+def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP):
+    """Work tiles of the fused attention kernel (kgat_fold_tiles).  Returns (tiles (T_max, 4)
+    int32, rel_tptr (R+1,) int32); rel_tptr[-1] is the number of tiles in use."""
+    lib = _lib.load()
+    rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr")
+    gptr = _need(gptr, torch.int32, "gptr", rel_ptr.shape)
+    gid = _need(gid, torch.int32, "gid")
+    n_rel = rel_ptr.numel() - 1
+    e = gid.numel()
+    t_max = int(lib.kgat_fold_tiles_max(e, int(n_groups), n_rel, int(cap)))
+    tiles = torch.zeros((max(t_max, 1), 4), dtype=torch.int32, device=gid.device)
+    rel_tptr = torch.zeros(n_rel + 1, dtype=torch.int32, device=gid.device)
+    ws = _workspace(lib.kgat_fold_tiles_workspace_bytes(int(n_groups), n_rel), gid.device)
+    check(lib.kgat_fold_tiles(e, n_rel, int(n_groups), _ptr(rel_ptr), _ptr(gid), _ptr(gptr), int(cap), _ptr(tiles),
+                              _ptr(rel_tptr), _ptr(ws), ws.numel(), _stream(gid)), "kgat_fold_tiles")
+    return tiles, rel_tptr
+
+
+def att_score_fused_supported(n_nodes, d, k, n_rel):
+    return bool(_lib.load().kgat_att_score_fused_supported(int(n_nodes), int(d), int(k), int(n_rel)))
+
+
+def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
+                    want_csr=True, want_eid=True):
+    """Attention logits, fused folded form (kgat_att_score_fused_f32).  Returns
+    (logits edge-id order or None, logits CSR order or None)."""
+    ent = _need(ent, torch.float32, "ent")
+    n_rel, d, k = W_R.shape
+    W_R = _need(W_R, torch.float32, "W_R")
+    rel = _need(rel, torch.float32, "rel", (n_rel, k))
+    perm = _need(perm, torch.int32, "perm")
+    e = perm.numel()
+    for name, t in (("src_g", src_g), ("pos_g", pos_g)):
+        _need(t, torch.int32, name, (e,))
+    _need(gid, torch.int32, "gid")
+    _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
+    _need(gptr, torch.int32, "gptr", (n_rel + 1,))
+    _need(rel_tptr, torch.int32, "rel_tptr", (n_rel + 1,))
+    _need(g_node, torch.int32, "g_node")
+    _need(tiles, torch.int32, "tiles")
+    logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
+    logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
+    with _timed("att_score", (e, d, k)):
+        check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
+                                                   _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), _ptr(tiles),
+                                                   _ptr(rel_tptr), _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits),
+                                                   _ptr(logits_csr), _stream(ent)), "kgat_att_score_fused_f32")
+    return logits, logits_csr
+
+
 def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
                  want_csr=False):
     """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
@@ -362,6 +415,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
            "KGATLibraryError"]

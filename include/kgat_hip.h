@@ -153,6 +153,28 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
                               const float* W_R, const float* rel, float* V_tab, float* logits,
                               float* logits_csr, kgat_stream_t stream);
 
+/* Fused folded form: one launch, no V table.  Work tiles (graph-static, kgat_fold_tiles): at most
+ * 16 consecutive head groups of one relation and at most `cap` grouped positions; a 16-group
+ * block with more positions appears several times with consecutive position ranges.
+ *   tiles    int32[4 * kgat_fold_tiles_max(...)]: (relation, first group, first position, end position)
+ *   rel_tptr int32[R+1]: first tile of each relation; rel_tptr[R] = number of tiles
+ * A wavefront computes a tile's V rows (as kgat_att_score_folded_f32), keeps them in LDS and
+ * takes the dot products of the tile's positions itself.  Same logits as the folded form bit
+ * for bit (same products, same order).  cap: a positive multiple of 64 (256 is the default of
+ * the host code).  Needs d == k in {16,32,64}. */
+int64_t kgat_fold_tiles_max(int64_t n_edges, int64_t n_groups, int n_rel, int cap);
+size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel);
+int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,
+                    const int32_t* gptr, int cap, int32_t* tiles, int32_t* rel_tptr, void* workspace,
+                    size_t workspace_bytes, kgat_stream_t stream);
+int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
+int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
+                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                             const float* ent, const float* W_R, const float* rel, float* logits,
+                             float* logits_csr, kgat_stream_t stream);
+
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
  *   a[e] = exp(s[e] - max_{e'->dst e} s[e']) / sum_{e'->dst e} exp(s[e'] - max)

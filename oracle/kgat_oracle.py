@@ -244,3 +244,30 @@ def dense_edge_softmax(n_nodes, dst, logits, dtype=np.float64):
         x = np.exp(s[idx] - s[idx].max())
         out[idx] = x / x.sum()
     return out
+
+
+def fold_tiles(rel_ptr, gid, gptr, cap):
+    """Work tiles of the fused attention kernel, restated (include/kgat_hip.h kgat_fold_tiles):
+    per relation, blocks of 16 consecutive head groups; a block spanning more than `cap` grouped
+    positions is cut into consecutive position ranges of `cap`.  Returns (tiles (T,4) int32 =
+    (relation, first group, first position, end position), rel_tptr (R+1,))."""
+    rel_ptr, gid, gptr = (np.asarray(x, dtype=np.int64) for x in (rel_ptr, gid, gptr))
+    n_rel, n_groups, n_scored = len(rel_ptr) - 1, int(gptr[-1]), int(rel_ptr[-1])
+    gstart = np.full(n_groups + 1, n_scored, dtype=np.int64)
+    if n_scored:
+        first = np.nonzero(np.r_[True, gid[1:n_scored] != gid[:n_scored - 1]])[0]
+        gstart[gid[first]] = first
+    tiles, rel_tptr = [], [0]
+    for r in range(n_rel):
+        for g0 in range(int(gptr[r]), int(gptr[r + 1]), 16):
+            g1 = min(g0 + 16, int(gptr[r + 1]))
+            pb, pe = int(gstart[g0]), int(gstart[g1])
+            p = pb
+            while True:
+                q = min(p + cap, pe)
+                tiles.append((r, g0, p, q))
+                p = q
+                if p >= pe:
+                    break
+        rel_tptr.append(len(tiles))
+    return np.asarray(tiles, dtype=np.int32).reshape(-1, 4), np.asarray(rel_tptr, dtype=np.int32)

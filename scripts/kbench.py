@@ -80,6 +80,13 @@ def main():
             fns["folded"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True)
             fns["folded_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True, want_eid=False)
             algos = algos + ["folded"]
+        if ops.att_score_fused_supported(n, D, D, R):
+            for cap in (64, 128, 192, 256):
+                tl, tp = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap)
+                print("fold tiles cap %d: %d (base %d)" % (cap, int(tp[-1]), (n_groups + 15) // 16))
+                fns["fused%d_csr" % cap] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False)
+            fns["fused"] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel)
+            algos = algos + ["fused"]
         if ops.att_score_split_supported(n, D, D, R):
             fns["split"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab)
             fns["split_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, want_eid=False)

@@ -306,6 +306,63 @@ def test_att_split_head_groups(K, dev, d):
             assert fold is None
 
 
+@pytest.mark.parametrize("d", [16, 32, 64])
+@pytest.mark.parametrize("cap", [64, 256])
+def test_att_fused_tiles_and_logits(K, dev, d, cap):
+    """Fused folded form: the tile table is bit-exact against the oracle's restatement, and the
+    logits equal the two-launch folded form bit for bit (same products in the same order)."""
+    from dgl_kgat_amd import ops
+    n, e, R = 700, 30000, 6
+    src, dst = random_graph(12, n, e, hub=4000, isolated_tail=20)
+    rng = np.random.default_rng(13)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)
+    et[rng.choice(e, e // 2, replace=False)] = 3
+    et[et == 1] = 2  # an empty relation in the middle
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    tiles, rel_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap)
+    o_tiles, o_tptr = orc.fold_tiles(rel_ptr.cpu().numpy(), gid.cpu().numpy(), gptr.cpu().numpy(), cap)
+    assert np.array_equal(rel_tptr.cpu().numpy(), o_tptr)
+    n_tiles = int(o_tptr[-1])
+    assert n_tiles <= tiles.shape[0] and np.array_equal(tiles.cpu().numpy()[:n_tiles], o_tiles)
+    assert np.all(o_tiles[:, 3] - o_tiles[:, 2] <= cap)
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    fold, fold_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                         tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True)
+    for want_eid in (True, False):
+        fused, fused_csr = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                               tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=want_eid)
+        assert torch.equal(fused_csr, fold_csr)
+        if want_eid:
+            assert torch.equal(fused, fold)
+    assert rel_err_inf(fused_csr.cpu().numpy(), ref[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].cpu().numpy()]) < 1e-5
+
+
+def test_att_fused_small_and_single_relation(K, dev):
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(78)
+    for n, e, R, lo in ((50, 1, 1, 0), (50, 63, 2, 0), (90, 65, 3, -1), (300, 1000, 1, 0), (300, 4097, 5, -2)):
+        src, dst = rng.integers(0, n, e).astype(np.int32), rng.integers(0, max(n // 3, 1), e).astype(np.int32)
+        et = rng.integers(lo, R, e).astype(np.int32)
+        rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+        gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+        tiles, rel_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=64)
+        d = 32
+        ent = rng.standard_normal((n, d)).astype(np.float32)
+        W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+        rel = rng.standard_normal((R, d)).astype(np.float32)
+        ref = orc.att_score(ent, W, rel, src, dst, et)
+        fused, fused_csr = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                               tf(ent, dev), tf(W, dev), tf(rel, dev))
+        _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        assert rel_err_inf(fused.cpu().numpy(), ref) < 1e-5, (n, e, R)
+        assert np.all(fused.cpu().numpy()[et < 0] == 0)
+        assert torch.equal(fused_csr, fused[eid.long()])
+
+
 def test_att_folded_d128(K, dev):
     """d = k = 128: W_r (64 KB) lives in LDS, 32 floats per lane in the per-edge dot."""
     from dgl_kgat_amd import ops
