@@ -165,6 +165,325 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-sweep form (default).  A wavefront takes 1,024 consecutive CSR positions, 16 per lane
+// (coalesced loads, transposed through a wave-private LDS patch), and finishes every destination
+// row that lies completely inside its range:
+//   * inside a lane, runs of equal row id are reduced with forward/backward sweeps over the 16
+//     registers (static indexing): run max, then run sum of exp(x - max);
+//   * across lanes, the aggregate (m, s) of a row spanning several lanes is a segmented
+//     forward scan (combine: s <- s1 e^{m1-m} + s2 e^{m2-m}) and the finished total travels
+//     back to the lanes of the row with a segmented copy scan, so that all positions of a row
+//     are normalised with the same (M, S);
+//   * the row cut by the start / the end of the wavefront's range is not finished here: its
+//     partial (m, s) goes to a carry entry.  softmax_chain_kernel combines the carries of each
+//     cut row in wavefront order (hub rows span many wavefronts) and softmax_fix_kernel
+//     normalises the positions of the cut rows.
+// No atomics, fixed combination order: bitwise reproducible, and no bound on a row's length.
+constexpr int kSmEPL = 16;                // positions per lane
+constexpr int kSmEPW = kWave * kSmEPL;    // positions per wavefront
+constexpr int kSmPad = 20;                // floats per lane in the LDS patch (16 + 4: conflict-free b128)
+constexpr float kSmNegBig = -3.0e38f;     // stands in for -inf (keeps the combine NaN-free)
+
+struct __attribute__((aligned(16))) SmCarry {
+  int32_t row;    // -1: no entry
+  int32_t count;  // positions of this wavefront that belong to the row
+  float m, s;     // partial max, partial sum of exp(x - m)
+  float M, S;     // the row's totals (written by softmax_chain_kernel)
+  int32_t ends;   // first-row entry: the row ends inside this wavefront
+  int32_t pad;
+};
+
+// exp(x) for x <= 0 on the hardware exp2: the product x*log2(e) is split into its rounded value
+// and the rounding remainder (fma), the remainder enters as a first-order factor - about 1.5 ulp,
+// against ~|x| ulp for exp2(x * log2e) alone.  Results below the normal range flush to zero.
+__device__ __forceinline__ float sm_exp(float x) {
+  x = fmaxf(x, -128.0f);  // exp2(-184) is already 0; keeps the split finite for the -3e38 stand-in
+  const float t = x * 1.44269504088896341f;
+  const float lo = fmaf(x, 1.44269504088896341f, -t) + x * 1.92596299112661746e-8f;
+  return __builtin_amdgcn_exp2f(t) * fmaf(lo, 0.693147180559945309f, 1.0f);
+}
+
+__device__ __forceinline__ void sm_combine(float& m, float& s, float m2, float s2) {
+  if (m >= m2) {
+    s = fmaf(s2, sm_exp(m2 - m), s);
+  } else {
+    s = fmaf(s, sm_exp(m - m2), s2);
+    m = m2;
+  }
+}
+
+__device__ __forceinline__ int64_t sm_wave_index() {
+  return (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+}
+
+template <bool IN_CSR>
+__global__ __launch_bounds__(256) void softmax_local_kernel(
+    int64_t e0, int64_t e1, const int32_t* __restrict__ row_of, const int32_t* __restrict__ eid,
+    const float* __restrict__ logits, float* __restrict__ out, float* __restrict__ out_csr,
+    SmCarry* __restrict__ carry) {
+  __shared__ __attribute__((aligned(16))) float s_x[256 / kWave][kWave * kSmPad];
+  __shared__ __attribute__((aligned(16))) int32_t s_r[256 / kWave][kWave * kSmPad];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const int64_t w = sm_wave_index();
+  const int64_t base = e0 + w * kSmEPW;
+  if (base >= e1) return;
+  const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
+  float* px = s_x[wv];
+  int32_t* pr = s_r[wv];
+  // striped, coalesced loads; positions past `end` repeat the last row with a huge negative logit
+  const int32_t r_last = row_of[end - 1];
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int64_t p = base + j * kWave + lane;
+    const bool valid = p < end;
+    const int32_t rr = valid ? row_of[p] : r_last;
+    const float xx = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : kSmNegBig;
+    const int idx = j * kWave + lane;  // owner lane idx / 16, slot idx % 16
+    px[(idx >> 4) * kSmPad + (idx & 15)] = xx;
+    pr[(idx >> 4) * kSmPad + (idx & 15)] = rr;
+  }
+  // neighbours of the range (is the first / last row cut?)
+  const bool cut_start = base > e0 && row_of[base - 1] == row_of[base];
+  const bool cut_end = end < e1 && row_of[end] == r_last;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float x[kSmEPL], M[kSmEPL], S[kSmEPL];
+  int32_t r[kSmEPL];
+#pragma unroll
+  for (int v = 0; v < kSmEPL / 4; ++v) {
+    const float4 a = *reinterpret_cast<const float4*>(px + lane * kSmPad + 4 * v);
+    const int4 b = *reinterpret_cast<const int4*>(pr + lane * kSmPad + 4 * v);
+    x[4 * v] = a.x; x[4 * v + 1] = a.y; x[4 * v + 2] = a.z; x[4 * v + 3] = a.w;
+    r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
+  }
+  // ---- lane-local runs
+  M[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) M[i] = r[i] == r[i - 1] ? fmaxf(M[i - 1], x[i]) : x[i];
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) M[i] = r[i] == r[i + 1] ? M[i + 1] : M[i];
+  // x[i] <- exp(x[i] - lane-local run max): the run sums use it, and so does the result
+  // (rescaled by exp(run max - row max) where the row reaches beyond the lane)
+#pragma unroll
+  for (int i = 0; i < kSmEPL; ++i) x[i] = sm_exp(x[i] - M[i]);
+  S[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) S[i] = r[i] == r[i - 1] ? S[i - 1] + x[i] : x[i];
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) S[i] = r[i] == r[i + 1] ? S[i + 1] : S[i];
+  // ---- rows spanning lanes
+  const int32_t key_f = r[0], key_l = r[kSmEPL - 1];
+  const bool multi = key_f != key_l;  // the lane's last run starts (and its first run ends) inside the lane
+  const int32_t prev_l = __shfl_up(key_l, 1, kWave), next_f = __shfl_down(key_f, 1, kWave);
+  const bool link = lane > 0 && prev_l == key_f;             // first run continues lane-1's last run
+  const bool link_n = lane < kWave - 1 && key_l == next_f;   // last run continues into lane+1
+  // I = (m, s) of the lane's last row from the row's start (inside the wavefront) to the lane's end
+  float im = M[kSmEPL - 1], is = S[kSmEPL - 1];
+  {
+    int stop = (multi || !link) ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const float m2 = __shfl_up(im, d, kWave), s2 = __shfl_up(is, d, kWave);
+      const int f2 = __shfl_up(stop, d, kWave);
+      if (lane >= d && !stop) {
+        float cm = m2, cs = s2;
+        sm_combine(cm, cs, im, is);
+        im = cm; is = cs;
+        stop = f2;
+      }
+    }
+  }
+  // the row that is the lane's FIRST run: finished total if it ends in this lane
+  float fm = M[0], fs = S[0];
+  {
+    const float pm = __shfl_up(im, 1, kWave), ps = __shfl_up(is, 1, kWave);
+    if (multi && link) {
+      float cm = pm, cs = ps;
+      sm_combine(cm, cs, fm, fs);
+      fm = cm; fs = cs;
+    }
+  }
+  // E = finished total of the row that is the lane's first run (copy scan from the lane where it ends)
+  float em = multi ? fm : im, es = multi ? fs : is;
+  {
+    int stop = (multi || !link_n) ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const float m2 = __shfl_down(em, d, kWave), s2 = __shfl_down(es, d, kWave);
+      const int f2 = __shfl_down(stop, d, kWave);
+      if (lane + d < kWave && !stop) {
+        em = m2; es = s2;
+        stop = f2;
+      }
+    }
+  }
+  const float nm = __shfl_down(em, 1, kWave), ns = __shfl_down(es, 1, kWave);
+  const float lm = multi ? (link_n ? nm : im) : em, ls = multi ? (link_n ? ns : is) : es;  // last run's row
+  // ---- the rows cut by the range
+  const int32_t R0 = __builtin_amdgcn_readfirstlane(key_f);
+  const int32_t RL = r_last;
+  int c0 = 0, cl = 0;
+#pragma unroll
+  for (int i = 0; i < kSmEPL; ++i) {
+    const bool valid = base + lane * kSmEPL + i < end;
+    c0 += (valid && r[i] == R0) ? 1 : 0;
+    cl += (valid && r[i] == RL) ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    c0 += __shfl_xor(c0, off, kWave);
+    cl += __shfl_xor(cl, off, kWave);
+  }
+  const float t0m = __shfl(em, 0, kWave), t0s = __shfl(es, 0, kWave);                 // first row, within the range
+  const float tlm = __shfl(im, kWave - 1, kWave), tls = __shfl(is, kWave - 1, kWave);  // last row, within the range
+  if (lane == 0) {
+    SmCarry a, b;
+    a.row = b.row = -1;
+    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f; a.M = b.M = 0.f; a.S = b.S = 1.f;
+    a.ends = b.ends = 1; a.pad = b.pad = 0;
+    if (R0 == RL) {  // one row fills the range
+      if (cut_start) {
+        a.row = R0; a.count = c0; a.m = tlm; a.s = tls; a.ends = cut_end ? 0 : 1;
+      } else if (cut_end) {
+        b.row = RL; b.count = cl; b.m = tlm; b.s = tls;
+      }
+    } else {
+      if (cut_start) { a.row = R0; a.count = c0; a.m = t0m; a.s = t0s; a.ends = 1; }
+      if (cut_end) { b.row = RL; b.count = cl; b.m = tlm; b.s = tls; }
+    }
+    carry[2 * w] = a;
+    carry[2 * w + 1] = b;
+  }
+  // ---- normalise the finished rows; positions of cut rows are left to softmax_fix_kernel
+  const float scale_f = sm_exp(M[0] - em) / es, scale_l = sm_exp(M[kSmEPL - 1] - lm) / ls;
+#pragma unroll
+  for (int i = 0; i < kSmEPL; ++i) {
+    const bool first = r[i] == key_f, last = r[i] == key_l;
+    x[i] = (first || last) ? x[i] * (first ? scale_f : scale_l) : x[i] / S[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int v = 0; v < kSmEPL / 4; ++v) {
+    float4 a;
+    a.x = x[4 * v]; a.y = x[4 * v + 1]; a.z = x[4 * v + 2]; a.w = x[4 * v + 3];
+    *reinterpret_cast<float4*>(px + lane * kSmPad + 4 * v) = a;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t skip_lo = cut_start ? base + c0 : base;     // [base, skip_lo) belongs to the cut first row
+  const int64_t skip_hi = cut_end ? end - cl : end;         // [skip_hi, end) belongs to the cut last row
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int64_t p = base + j * kWave + lane;
+    const int idx = j * kWave + lane;
+    const float a = px[(idx >> 4) * kSmPad + (idx & 15)];
+    if (p >= skip_lo && p < skip_hi) {
+      if (out_csr) out_csr[p] = a;
+      if (out) out[eid ? eid[p] : p] = a;
+    }
+  }
+}
+
+// One wavefront per range boundary: combines the partials of the row cut there, in wavefront
+// order, 64 carry entries per step, and writes the totals back into every entry of the chain.
+__global__ __launch_bounds__(256) void softmax_chain_kernel(int64_t n_waves, SmCarry* __restrict__ carry) {
+  const int lane = threadIdx.x % kWave;
+  const int64_t a = sm_wave_index();
+  if (a >= n_waves) return;
+  const SmCarry head = carry[2 * a + 1];
+  if (head.row < 0) return;
+  float m = head.m, s = head.s;
+  int64_t last = a;  // last wavefront of the chain
+  for (int64_t w0 = a + 1; w0 < n_waves; w0 += kWave) {
+    const int64_t w = w0 + lane;
+    const bool valid = w < n_waves;
+    SmCarry f;
+    f.row = -1; f.m = kSmNegBig; f.s = 0.f; f.ends = 1;
+    if (valid) f = carry[2 * w];
+    const bool mine = valid && f.row == head.row;
+    const unsigned long long stop = __ballot(!mine || f.ends);
+    const int n_take = stop ? __ffsll((long long)stop) : kWave;  // lanes [0, n_take) continue the row ...
+    const bool take = lane < n_take && mine;                     // ... (the stopping lane only if it is the row's end)
+    float pm = take ? f.m : kSmNegBig, ps = take ? f.s : 0.f;
+    // ordered wave reduction: lane 0's partial first
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const float m2 = __shfl_down(pm, d, kWave), s2 = __shfl_down(ps, d, kWave);
+      if ((lane & (2 * d - 1)) == 0) sm_combine(pm, ps, m2, s2);
+    }
+    pm = __shfl(pm, 0, kWave); ps = __shfl(ps, 0, kWave);
+    sm_combine(m, s, pm, ps);
+    const int n_mine = __popcll(__ballot(take));
+    last = w0 + n_mine - 1;
+    if (stop) break;
+  }
+  if (lane == 0) { carry[2 * a + 1].M = m; carry[2 * a + 1].S = s; }
+  for (int64_t w = a + 1 + lane; w <= last; w += kWave) { carry[2 * w].M = m; carry[2 * w].S = s; }
+}
+
+// positions [lo, hi) of one row, 8 x 64 per step so that the loads of a step are in flight together
+template <bool IN_CSR>
+__device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float M, float S,
+                                         const int32_t* __restrict__ eid, const float* __restrict__ logits,
+                                         float* __restrict__ out, float* __restrict__ out_csr) {
+  constexpr int U = 8;
+  for (int64_t p0 = lo; p0 < hi; p0 += U * kWave) {
+    int64_t e[U];
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = p0 + u * kWave + lane;
+      const int64_t pc = p < hi ? p : hi - 1;
+      e[u] = eid ? eid[pc] : pc;
+      x[u] = IN_CSR ? logits[pc] : logits[e[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = p0 + u * kWave + lane;
+      if (p < hi) {
+        const float a = sm_exp(x[u] - M) / S;
+        if (out_csr) out_csr[p] = a;
+        if (out) out[e[u]] = a;
+      }
+    }
+  }
+}
+
+template <bool IN_CSR>
+__global__ __launch_bounds__(256) void softmax_fix_kernel(
+    int64_t e0, int64_t e1, const int32_t* __restrict__ eid, const float* __restrict__ logits,
+    float* __restrict__ out, float* __restrict__ out_csr, const SmCarry* __restrict__ carry) {
+  const int lane = threadIdx.x % kWave;
+  const int64_t w = sm_wave_index();
+  const int64_t base = e0 + w * kSmEPW;
+  if (base >= e1) return;
+  const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
+  // the cut rows sit at the two ends of the range: their first 64 positions are requested together
+  // with the carry entries (one memory round trip for the common short case)
+  const SmCarry ca = carry[2 * w], cb = carry[2 * w + 1];
+  const int64_t pa = base + lane < end ? base + lane : end - 1;
+  const int64_t pb = end - 1 - lane >= base ? end - 1 - lane : base;
+  const int64_t ea = eid ? eid[pa] : pa, eb = eid ? eid[pb] : pb;
+  const float xa = IN_CSR ? logits[pa] : logits[ea], xb = IN_CSR ? logits[pb] : logits[eb];
+  if (ca.row >= 0) {
+    if (lane < ca.count) {
+      const float a = sm_exp(xa - ca.M) / ca.S;
+      if (out_csr) out_csr[pa] = a;
+      if (out) out[ea] = a;
+    }
+    fix_span<IN_CSR>(base + kWave, base + ca.count, lane, ca.M, ca.S, eid, logits, out, out_csr);
+  }
+  if (cb.row >= 0) {
+    if (lane < cb.count) {
+      const float a = sm_exp(xb - cb.M) / cb.S;
+      if (out_csr) out_csr[pb] = a;
+      if (out) out[eb] = a;
+    }
+    fix_span<IN_CSR>(end - cb.count, end - kWave, lane, cb.M, cb.S, eid, logits, out, out_csr);
+  }
+}
+
 // Backward (DGL 0.4.x EdgeSoftmax.backward): grad_s = a*g - a * sum_row(a*g).
 // Row sums of a*g are unbounded floats, so this path uses one subgroup per row in CSR order
 // (fixed summation order); it is not on the reference's training path (attention is computed
@@ -199,9 +518,10 @@ using namespace kgat;
 
 extern "C" {
 
-size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes) {
-  const size_t n = (size_t)(n_nodes > 0 ? n_nodes : 1);
-  return align_up(n * sizeof(float), 256) + align_up(n * sizeof(unsigned long long), 256);
+size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+  (void)n_nodes;
+  const size_t n_waves = (size_t)((n_edges > 0 ? n_edges : 0) + kSmEPW - 1) / kSmEPW;
+  return align_up((2 * n_waves + 2) * sizeof(SmCarry), 256);
 }
 
 int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
@@ -215,8 +535,52 @@ int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
   KGAT_CHECK_ARG(out || out_csr, "edge_softmax: no output requested");
   KGAT_CHECK_ARG(eid != nullptr || (logits_in_csr_order && out == nullptr),
                  "edge_softmax: edge-id ordered input/output needs eid");
-  if (workspace_bytes < kgat_edge_softmax_workspace_bytes(n_nodes)) {
+  const int64_t ne = e_end - e_begin;
+  if (workspace_bytes < kgat_edge_softmax_workspace_bytes(n_nodes, ne)) {
     set_error("edge_softmax: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  SmCarry* carry = static_cast<SmCarry*>(workspace);
+  const int64_t n_waves = (ne + kSmEPW - 1) / kSmEPW;
+  const unsigned blocks = (unsigned)((n_waves + 3) / 4);
+  if (logits_in_csr_order) {
+    hipLaunchKernelGGL(softmax_local_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, row_of, eid,
+                       logits, out, out_csr, carry);
+    hipLaunchKernelGGL(softmax_chain_kernel, dim3(blocks), dim3(256), 0, st, n_waves, carry);
+    hipLaunchKernelGGL(softmax_fix_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits, out,
+                       out_csr, (const SmCarry*)carry);
+  } else {
+    hipLaunchKernelGGL(softmax_local_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, row_of, eid,
+                       logits, out, out_csr, carry);
+    hipLaunchKernelGGL(softmax_chain_kernel, dim3(blocks), dim3(256), 0, st, n_waves, carry);
+    hipLaunchKernelGGL(softmax_fix_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits, out,
+                       out_csr, (const SmCarry*)carry);
+  }
+  KGAT_CHECK_LAUNCH("edge_softmax");
+  return KGAT_OK;
+}
+
+// The three-pass form (atomic row max / fixed-point atomic row sum / normalise) this file started
+// with; kept as an independent implementation for A/B measurements and cross-checks in the tests.
+size_t kgat_edge_softmax_3pass_workspace_bytes(int64_t n_nodes) {
+  const size_t n = (size_t)(n_nodes > 0 ? n_nodes : 1);
+  return align_up(n * sizeof(float), 256) + align_up(n * sizeof(unsigned long long), 256);
+}
+
+int kgat_edge_softmax_3pass_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
+                                const int32_t* row_of, const int32_t* eid, const float* logits,
+                                int logits_in_csr_order, float* out, float* out_csr, void* workspace,
+                                size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && e_begin >= 0 && e_end >= e_begin && e_end < INT32_MAX,
+                 "edge_softmax_3pass: bad size");
+  if (e_end == e_begin) return KGAT_OK;
+  KGAT_CHECK_ARG(row_of && logits && workspace, "edge_softmax_3pass: null pointer");
+  KGAT_CHECK_ARG(out || out_csr, "edge_softmax_3pass: no output requested");
+  KGAT_CHECK_ARG(eid != nullptr || (logits_in_csr_order && out == nullptr),
+                 "edge_softmax_3pass: edge-id ordered input/output needs eid");
+  if (workspace_bytes < kgat_edge_softmax_3pass_workspace_bytes(n_nodes)) {
+    set_error("edge_softmax_3pass: workspace too small");
     return KGAT_E_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
@@ -245,7 +609,7 @@ int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
                        row_of, eid, logits, (const float*)M, (const unsigned long long*)Z, out,
                        out_csr);
   }
-  KGAT_CHECK_LAUNCH("edge_softmax");
+  KGAT_CHECK_LAUNCH("edge_softmax_3pass");
   return KGAT_OK;
 }
 

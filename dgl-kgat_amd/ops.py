@@ -289,10 +289,11 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
 
 
 def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
-                 want_csr=False):
+                 want_csr=False, three_pass=False):
     """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
     CSR order with in_csr_order=True.  Returns (out in edge-id order, out_csr in CSR order);
-    unrequested ones are None."""
+    unrequested ones are None.  three_pass=True runs the independent three-pass implementation
+    (kgat_edge_softmax_3pass_f32)."""
     logits = _need(logits, torch.float32, "logits")
     row_of = _need(row_of, torch.int32, "row_of", logits.shape)
     eid = _need(eid, torch.int32, "eid", logits.shape)
@@ -300,11 +301,15 @@ def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None,
     e0, e1 = (0, logits.numel()) if e_range is None else e_range
     out = torch.empty_like(logits) if want_out else None
     out_csr = torch.empty_like(logits) if want_csr else None
-    ws = _workspace(lib.kgat_edge_softmax_workspace_bytes(n_nodes), logits.device)
+    if three_pass:
+        ws = _workspace(lib.kgat_edge_softmax_3pass_workspace_bytes(n_nodes), logits.device)
+        fn, name = lib.kgat_edge_softmax_3pass_f32, "kgat_edge_softmax_3pass_f32"
+    else:
+        ws = _workspace(lib.kgat_edge_softmax_workspace_bytes(n_nodes, e1 - e0), logits.device)
+        fn, name = lib.kgat_edge_softmax_f32, "kgat_edge_softmax_f32"
     with _timed("edge_softmax", (e1 - e0,)):
-        check(lib.kgat_edge_softmax_f32(n_nodes, e0, e1, _ptr(row_of), _ptr(eid), _ptr(logits),
-                                        1 if in_csr_order else 0, _ptr(out), _ptr(out_csr), _ptr(ws),
-                                        ws.numel(), _stream(logits)), "kgat_edge_softmax_f32")
+        check(fn(n_nodes, e0, e1, _ptr(row_of), _ptr(eid), _ptr(logits), 1 if in_csr_order else 0, _ptr(out),
+                 _ptr(out_csr), _ptr(ws), ws.numel(), _stream(logits)), name)
     return out, out_csr
 
 

@@ -184,12 +184,23 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
  * Input: logits in edge-id order (logits_in_csr_order = 0; read through eid) or in CSR
  * position order (1).  Outputs (either may be NULL, not both): out in edge-id order (written
  * through eid) and out_csr in CSR order.  eid = original edge id per CSR position.
- * Bitwise reproducible (integer-ordered max, fixed-point sum). */
-size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes);
+ * One sweep over the positions (rows finished inside a wavefront's 1,024-position range are
+ * normalised on the spot; the rows cut by range boundaries are combined from carry entries in
+ * range order and normalised by a short fix-up launch).  No atomics, fixed combination order:
+ * bitwise reproducible, no bound on a row's length.  Workspace: n_edges = e_end - e_begin. */
+size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
                           const int32_t* row_of, const int32_t* eid, const float* logits,
                           int logits_in_csr_order, float* out, float* out_csr, void* workspace,
                           size_t workspace_bytes, kgat_stream_t stream);
+/* The same operator as three streaming passes (integer-ordered atomic row max, row sum in 2^-40
+ * fixed point with 64-bit atomic adds, normalise): an independent implementation kept for
+ * cross-checks and A/B timing.  At most 2^24 positions per destination. */
+size_t kgat_edge_softmax_3pass_workspace_bytes(int64_t n_nodes);
+int kgat_edge_softmax_3pass_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
+                                const int32_t* row_of, const int32_t* eid, const float* logits,
+                                int logits_in_csr_order, float* out, float* out_csr, void* workspace,
+                                size_t workspace_bytes, kgat_stream_t stream);
 
 /* Backward of the above (DGL 0.4.x EdgeSoftmax.backward), rows [row0, row0 + n_rows):
  *   grad_s[e] = a[e]*g[e] - a[e] * sum_{e'->dst e} a[e']*g[e'];  arrays in edge-id order

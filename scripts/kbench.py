@@ -170,7 +170,9 @@ def main():
     else:
         logits = torch.randn(E, generator=g).to(dev)
         fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
-               "softmax_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True)}
+               "softmax_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True),
+               "3pass_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True, three_pass=True),
+               "3pass_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True, three_pass=True)}
         res = timeit(fns, args.rounds)
         b = 12 * E + 4 * n
         for a, t in res.items():

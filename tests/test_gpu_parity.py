@@ -192,6 +192,43 @@ def test_edge_softmax_vs_oracle(K, dev, name, n, e, hub, iso):
     assert np.array_equal(out4.cpu().numpy(), out)
 
 
+@pytest.mark.parametrize("e", [1, 15, 16, 17, 1023, 1024, 1025, 2048, 70001])
+def test_edge_softmax_range_boundaries_and_hubs(K, dev, e):
+    """Rows cut by the 1,024-position wavefront ranges (incl. rows spanning many ranges and a row
+    that is the whole graph), sizes around the lane / range granularity, destination-range
+    sub-ranges (shards), and agreement with the independent three-pass implementation."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(100 + e)
+    n = 300
+    for layout in ("one_row", "hubs", "short"):
+        if layout == "one_row":
+            dst = np.full(e, 7, np.int32)
+        elif layout == "hubs":  # a few rows hold almost everything, the rest are short
+            dst = rng.choice(np.array([3, 150, 299], np.int32), e, p=[0.6, 0.3, 0.1]).astype(np.int32)
+            dst[rng.random(e) < 0.05] = rng.integers(0, n, int((rng.random(e) < 0.05).sum()) or 1)[0]
+        else:
+            dst = rng.integers(0, n, e).astype(np.int32)
+        src = rng.integers(0, n, e).astype(np.int32)
+        s = (rng.standard_normal(e) * 5).astype(np.float32)
+        ref = orc.edge_softmax(n, dst, s)
+        indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        out, out_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
+        assert rel_err(out.cpu().numpy(), ref) < TOL, layout
+        assert torch.equal(out_csr, out[eid.long()])
+        old, old_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True, three_pass=True)
+        assert rel_err(out.cpu().numpy(), old.cpu().numpy()) < 1e-5, layout
+        # a destination-range shard: positions [indptr[lo], indptr[hi]) only
+        ip = indptr.cpu().numpy()
+        for lo, hi in ((0, n), (3, 151), (150, 300), (7, 8)):
+            e0, e1 = int(ip[lo]), int(ip[hi])
+            if e1 == e0:
+                continue
+            _, part_csr = ops.edge_softmax(n, row_of, eid, ops.gather(eid, tf(s, dev)), in_csr_order=True,
+                                           e_range=(e0, e1), want_out=False, want_csr=True)
+            # (other range boundaries: the cut rows are combined in another association)
+            assert rel_err(part_csr[e0:e1].cpu().numpy(), out_csr[e0:e1].cpu().numpy()) < 1e-6, (layout, lo, hi)
+
+
 def test_edge_softmax_known_answers(K, dev):
     from dgl_kgat_amd import ops
     src = np.array([1, 2, 3, 0], np.int32)
