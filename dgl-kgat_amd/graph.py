@@ -438,39 +438,63 @@ class DGLGraph:
         # do the whole relation-space product per group and a d-length dot per edge (one launch
         # with the per-group vectors in LDS / two launches with a table); "split" keeps the
         # reference's contraction order (bit-identical to "one")
+        def run(form):
+            if form == "fused":
+                tiles = groups.g_tab.get("tiles")  # graph-static work tiles of the fused kernel
+                if tiles is None:
+                    tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr,
+                                                                   groups.n_groups)
+                return ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
+                                           groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
+                                           ent_c, W_c, rel_c, want_eid=False)[1]
+            if form in ("folded", "split"):
+                folded = form == "folded"
+                width = d if folded else k
+                g_tab = groups.g_tab.get(width)  # per-group scratch table, kept with the graph
+                if g_tab is None:
+                    g_tab = groups.g_tab[width] = torch.empty((max(groups.n_groups, 1), width), dtype=torch.float32,
+                                                              device=dev)
+                return ops.att_score_split(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
+                                           groups.gid, groups.gptr, groups.g_node, groups.n_groups,
+                                           ent_c, W_c, rel_c, g_tab=g_tab, want_eid=False, folded=folded)[1]
+            return ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
+                                 ent_c, W_c, rel_c, pos_g=groups.pos_g, algo="auto" if form == "one" else form)[1]
+
         form = os.environ.get("KGAT_ATT_FORM", "auto") if algo == "auto" else algo
         if form == "auto":
+            form = groups.g_tab.get(("form", d, k))
+        if form is None:
             # measured on MI355X, d = 64: folded ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges,
             # one-kernel 0.153 ms per 1e6 edges -> the group forms win below ~0.74 groups per edge
-            if 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_fused_supported(st.n_nodes, d, k, n_rel):
-                form = "fused"
-            elif 4 * groups.n_groups <= 3 * st.n_edges and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel):
-                form = "folded"
+            shares = 4 * groups.n_groups <= 3 * st.n_edges
+            cands = [f for f, ok in (("fused", ops.att_score_fused_supported(st.n_nodes, d, k, n_rel)),
+                                     ("folded", ops.att_score_folded_supported(st.n_nodes, d, k, n_rel))) if ok and shares]
+            if len(cands) > 1:
+                # which of the two wins depends on the group-size distribution (fused: amazon-book-shaped
+                # CKG; folded: last-fm-shaped): time both once per graph and keep the faster
+                best = None
+                for f in cands:
+                    run(f)
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    for _ in range(3):
+                        run(f)
+                    t1.record()
+                    t1.synchronize()
+                    ms = t0.elapsed_time(t1)
+                    if best is None or ms < best[0]:
+                        best = (ms, f)
+                form = best[1]
+                groups.g_tab.pop("tiles" if form == "folded" else d, None)  # the loser's scratch
+            elif cands:
+                form = cands[0]
             elif 2 * groups.n_groups <= st.n_edges and ops.att_score_split_supported(st.n_nodes, d, k, n_rel):
                 form = "split"
             else:
                 form = "one"
-        if form == "fused":
-            tiles = groups.g_tab.get("tiles")  # graph-static work tiles of the fused kernel
-            if tiles is None:
-                tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups)
-            _, logits_csr = ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
-                                                groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
-                                                ent_c, W_c, rel_c, want_eid=False)
-        elif form in ("folded", "split"):
-            folded = form == "folded"
-            width = d if folded else k
-            g_tab = groups.g_tab.get(width)  # per-group scratch table, kept with the graph
-            if g_tab is None:
-                g_tab = groups.g_tab[width] = torch.empty((max(groups.n_groups, 1), width), dtype=torch.float32,
-                                                          device=dev)
-            _, logits_csr = ops.att_score_split(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
-                                                groups.gid, groups.gptr, groups.g_node, groups.n_groups,
-                                                ent_c, W_c, rel_c, g_tab=g_tab, want_eid=False, folded=folded)
-        else:
-            _, logits_csr = ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
-                                          ent_c, W_c, rel_c, pos_g=groups.pos_g,
-                                          algo="auto" if form == "one" else form)
+            groups.g_tab[("form", d, k)] = form
+        logits_csr = run(form)
+        if form not in ("fused", "folded", "split"):
             form = "one"
         st.last_att_form = (form, groups.n_groups)
         _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
