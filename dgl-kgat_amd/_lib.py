@@ -19,6 +19,7 @@ SOURCES = {
     "kgat_att.hip": [],
     "kgat_att_persistent.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "kgat_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "kgat_transr.hip": [],
 }
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "kgat_hip.h")
 
@@ -60,6 +61,10 @@ SIGNATURES = {
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _p, _sz, _u32, _i32, _p]),
     "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
+    "kgat_transr_supported": (_i32, [_i64, _i32, _i32, _i32, _i64]),
+    "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,
+                                         _p, _p, _p, _sz, _p]),
     "kgat_bi_interaction_f32": (_i32, [_i64, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64, _p]),
     "kgat_l2_normalize_rows_f32": (_i32, [_i64, _i32, _p, _p, _i64, _p]),
     "kgat_sddmm_dot_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),

@@ -104,3 +104,30 @@ def edge_softmax(graph, logits, eids=None):
     if logits.shape[0] != graph.number_of_edges():
         raise ValueError("logits has %d rows, graph has %d edges" % (logits.shape[0], graph.number_of_edges()))
     return _EdgeSoftmax.apply(logits, graph)
+
+
+class _TransRLoss(torch.autograd.Function):
+    """TransR loss of a triplet batch (reference models.py:114-133) with its gradients computed in
+    the same handful of launches (kgat_transr_loss_grad_f32); backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, ent, W_R, rel, h, r, pos_t, neg_t, reg_lambda):
+        want = any(ctx.needs_input_grad[:3])
+        loss, g_ent, g_w, g_rel = ops.transr_loss_grad(h, r, pos_t, neg_t, ent.detach(), W_R.detach(), rel.detach(),
+                                                       reg_lambda, want_grad=want)
+        if want:
+            ctx.save_for_backward(g_ent, g_w, g_rel)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_ent, g_w, g_rel = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        return (g_ent * grad_out if need[0] else None, g_w * grad_out if need[1] else None,
+                g_rel * grad_out if need[2] else None, None, None, None, None, None)
+
+
+def transr_loss(ent, W_R, rel, h, r, pos_t, neg_t, reg_lambda):
+    """Differentiable fused TransR loss; index tensors of any integer dtype."""
+    i32 = [t.to(torch.int32).contiguous() for t in (h, r, pos_t, neg_t)]
+    return _TransRLoss.apply(ent, W_R, rel, *i32, float(reg_lambda))

@@ -23,6 +23,12 @@ from . import function as fn
 from .autograd import edge_softmax, u_mul_e_sum
 
 
+def ops_transr_supported(model, h):
+    from . import ops
+    n_rel, d, k = model.W_R.shape
+    return ops.transr_supported(model.entity_embed.weight.shape[0], d, k, n_rel, h.numel())
+
+
 class _TallLinear(torch.autograd.Function):
     """``x @ W^T`` for a tall x (N ~ 10^5 rows, <= 128 columns).  Forward and grad_x are ordinary
     library GEMMs; the weight gradient ``grad^T @ x`` reduces over N into a tiny (D_out, D_in)
@@ -176,10 +182,19 @@ class KGATPropagation(nn.Module):
             off += widths[li + 1]
         return out
 
-    def transR(self, h, r, pos_t, neg_t, reg_lambda_kg=0.01):
+    def transR(self, h, r, pos_t, neg_t, reg_lambda_kg=0.01, fused=None):
         """TransR pairwise ranking loss of the KG phase (reference models.py:114-133 with
-        bmm_maybe_select :13-47).  Dense torch arithmetic only - outside the propagation path
-        (SURVEY 8f #3); kept so that this module covers the reference Model's training API."""
+        bmm_maybe_select :13-47).  On the GPU in fp32 it runs as the fused
+        loss+gradient kernels (kgat_transr_loss_grad_f32, ~1,800 of these steps per amazon-book
+        epoch); fused=False (and CPU / float64 modules, batches beyond the kernels' limits) takes
+        the torch restatement below, which is what the parity tests compare the kernels with."""
+        if fused is None:
+            fused = self.entity_embed.weight.is_cuda and self.entity_embed.weight.dtype == torch.float32 and \
+                ops_transr_supported(self, h)
+        if fused:
+            from .autograd import transr_loss
+            return transr_loss(self.entity_embed.weight, self.W_R, self.relation_embed.weight, h, r, pos_t, neg_t,
+                               reg_lambda_kg)
         W = self.W_R.index_select(0, r)  # (B, d, k)
 
         def proj(ids):

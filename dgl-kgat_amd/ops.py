@@ -288,6 +288,38 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
     return logits, logits_csr
 
 
+def transr_supported(n_nodes, d, k, n_rel, batch):
+    return bool(_lib.load().kgat_transr_supported(int(n_nodes), int(d), int(k), int(n_rel), int(batch)))
+
+
+def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=True):
+    """TransR loss of a triplet batch and, if want_grad, its gradients with respect to the entity
+    table (dense), W_R and the relation table (kgat_transr_loss_grad_f32).  Index tensors are
+    int32.  Returns (loss 0-d tensor, grad_ent, grad_W, grad_rel) - gradients None without
+    want_grad."""
+    ent = _need(ent, torch.float32, "ent")
+    n_rel, d, k = W_R.shape
+    W_R = _need(W_R, torch.float32, "W_R")
+    rel = _need(rel, torch.float32, "rel", (n_rel, k))
+    h = _need(h, torch.int32, "h")
+    b = h.numel()
+    for name, t in (("r", r), ("pos_t", pos_t), ("neg_t", neg_t)):
+        _need(t, torch.int32, name, (b,))
+    lib = _lib.load()
+    dev = ent.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    g_ent = torch.empty_like(ent) if want_grad else None
+    g_w = torch.empty_like(W_R) if want_grad else None
+    g_rel = torch.empty_like(rel) if want_grad else None
+    ws = _workspace(lib.kgat_transr_workspace_bytes(b, d, k, n_rel), dev)
+    with _timed("transr", (b, d, k)):
+        check(lib.kgat_transr_loss_grad_f32(ent.shape[0], n_rel, d, k, b, _ptr(h), _ptr(r), _ptr(pos_t), _ptr(neg_t),
+                                            _ptr(ent), _ptr(W_R), _ptr(rel), float(reg_lambda), _ptr(loss),
+                                            _ptr(g_ent), _ptr(g_w), _ptr(g_rel), _ptr(ws), ws.numel(), _stream(ent)),
+              "kgat_transr_loss_grad_f32")
+    return loss, g_ent, g_w, g_rel
+
+
 def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
                  want_csr=False, three_pass=False):
     """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
@@ -420,6 +452,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
            "KGATLibraryError"]

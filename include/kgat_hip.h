@@ -260,6 +260,25 @@ int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out
 int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t* out,
                     kgat_stream_t stream);
 
+/* ---------------------------------------------------------------- TransR KG step
+ * Loss and gradients of reference models.py:114-133 (transR; bmm_maybe_select :13-47,
+ * _L2_loss_mean :9-11) for one batch of triplets (h[b], r[b], pos_t[b], neg_t[b]):
+ *   a_x = ent[x] W_R[r],  u_x = a_x / max(|a_x|, 1e-12),  u_r = rel[r] / max(|rel[r]|, 1e-12)
+ *   loss = mean_b softplus(|u_h+u_r-u_p|^2 - |u_h+u_r-u_n|^2)
+ *          + reg_lambda * sum_{v in h,r,p,n} mean_b |u_v|^2 / 2
+ * loss: 1 float.  grad_ent (n_nodes x d, dense: rows not in the batch are zeroed, as the
+ * reference's non-sparse nn.Embedding gradient), grad_W (R x d x k), grad_rel (R x k): all three
+ * or none (NULL: loss only).  Fixed summation orders (sorted batch, no atomics): bitwise
+ * reproducible.  Needs d, k multiples of 4 and <= 128, 3*batch <= 8192, n_nodes <= 2^19
+ * (kgat_transr_supported). */
+int kgat_transr_supported(int64_t n_nodes, int d, int k, int n_rel, int64_t batch);
+size_t kgat_transr_workspace_bytes(int64_t batch, int d, int k, int n_rel);
+int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h,
+                              const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, const float* ent,
+                              const float* W_R, const float* rel, float reg_lambda, float* loss, float* grad_ent,
+                              float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
+                              kgat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def timeit(fns, rounds, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", choices=["att", "spmm", "softmax", "train"])
+    ap.add_argument("kernel", choices=["att", "spmm", "softmax", "train", "kg"])
     ap.add_argument("--algos", default=None)
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--rounds", type=int, default=20)
@@ -167,6 +167,34 @@ def main():
               % (B, dt * 1e3, 6 * E / dt / 1e9))
         for name, v in kt.summary().items():
             print("   %-14s %4d launches  avg %.4f ms" % (name, len(v), float(np.mean([m for _, m in v]))))
+    elif args.kernel == "kg":
+        # the KG step of kgat.py:116-136: TransR loss on a batch of 2048 triplets -> backward -> Adam over all parameters
+        import time
+        import dgl_kgat_amd as K
+        torch.manual_seed(0)
+        model = K.KGATPropagation(n, R, D, D, 3, D, dropout=0.1).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        B = 2048
+        idx = torch.randint(0, E, (B,), device=dev)
+        h, r, pt = dst[idx].long(), et[idx].long(), src[idx].long()
+        nt = torch.randint(0, n, (B,), device=dev)
+
+        for fused in (True, False):
+            def step():
+                loss = model.transR(h, r, pt, nt, fused=fused)
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+                return loss
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.rounds):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.rounds
+            print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, "fused kernels" if fused else "torch ops", dt * 1e3))
     else:
         logits = torch.randn(E, generator=g).to(dev)
         fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
