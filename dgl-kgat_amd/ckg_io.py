@@ -118,3 +118,77 @@ def save_ckg_files(data_dir, n_users, uv_train, uv_val, uv_test, kg):
     for name, arr in zip(UV_FILES, (uv_train, uv_val, uv_test)):
         write_table(os.path.join(data_dir, name), ["u", "v"] + (["r"] if np.asarray(arr).shape[1] == 3 else []), arr)
     write_table(os.path.join(data_dir, KG_FILE), ["h", "r", "t"], kg)
+
+
+# ---------------------------------------------------------------------------------------------
+# Raw KGAT release files -> the reference's data directory (datasets/process_kgat_data.py)
+def read_kgat_interactions(path):
+    """``train.txt`` / ``test.txt`` of the KGAT release: one line per user, ``user item item ...``
+    (process_kgat_data.py:139-149 ``read2u_v_dict``: lines with no item are skipped, repeated
+    items of a user collapse).  Returns (P, 2) int64 (user, item) pairs, users in file order and
+    each user's items ascending (the reference's order inside a user is that of a Python set -
+    unspecified)."""
+    pairs = []
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if len(tok) > 1:
+                u = int(tok[0])
+                pairs.extend((u, v) for v in sorted({int(t) for t in tok[1:]}))
+    return np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+
+
+def read_kgat_kg(path):
+    """``kg_final.txt``: ``h r t`` per line; duplicate rows dropped, first occurrence kept
+    (process_kgat_data.py:213-243 ``read_kg2pd`` without remapping: entity and relation ids must
+    already be 0..max, as in the released files)."""
+    kg = np.loadtxt(path, dtype=np.int64, ndmin=2)
+    if kg.size == 0:
+        return kg.reshape(0, 3)
+    _, first = np.unique(kg, axis=0, return_index=True)
+    kg = kg[np.sort(first)]
+    ents, rels = np.unique(kg[:, [0, 2]]), np.unique(kg[:, 1])
+    if ents.max() + 1 != ents.size or rels.max() + 1 != rels.size:
+        raise ValueError("%s: entity / relation ids are not consecutive from 0" % path)
+    return kg
+
+
+def split_validation(pairs, val_ratio=0.1, seed=0):
+    """process_kgat_data.py:179-211 ``split_val(mode="seen")``: a random ``val_ratio`` of the training
+    pairs becomes the validation split, then one pair of every user / item that lost all its
+    training pairs moves back.  Seeded numpy permutation (the reference uses the global numpy
+    state, so its exact split is not reproducible either).  Returns (train, valid)."""
+    pairs = np.asarray(pairs)
+    rng = np.random.default_rng(seed)
+    idx = rng.permutation(len(pairs))
+    n_val = int(len(pairs) * val_ratio)
+    is_val = np.zeros(len(pairs), bool)
+    is_val[idx[:n_val]] = True
+    for col in (0, 1):
+        seen = np.unique(pairs[~is_val, col])
+        lost = np.setdiff1d(np.unique(pairs[:, col]), seen)
+        if len(lost):
+            cand = np.nonzero(is_val & np.isin(pairs[:, col], lost))[0]
+            _, first = np.unique(pairs[cand, col], return_index=True)  # first validation pair of each lost id
+            is_val[cand[first]] = False
+    return pairs[~is_val], pairs[is_val]
+
+
+def convert_kgat_release(raw_dir, out_dir, val_ratio=0.1, seed=0):
+    """Raw KGAT directory (``train.txt``, ``test.txt``, ``kg_final.txt``) -> the four tables the
+    reference's DataLoader (and CKGDataset above) read.  Users / items are re-numbered in sorted
+    order over train + test as process_kgat_data.py:151-177 does; item ids of the released files
+    already coincide with their KG entity ids."""
+    train_all = read_kgat_interactions(os.path.join(raw_dir, "train.txt"))
+    test = read_kgat_interactions(os.path.join(raw_dir, "test.txt"))
+    kg = read_kgat_kg(os.path.join(raw_dir, "kg_final.txt"))
+    both = np.vstack([train_all, test])
+    users, items = np.unique(both[:, 0]), np.unique(both[:, 1])
+    if items.max() + 1 != items.size:
+        raise ValueError("item ids are not consecutive from 0: the KG entity numbering would not line up")
+
+    def remap(p):
+        return np.stack([np.searchsorted(users, p[:, 0]), np.searchsorted(items, p[:, 1])], 1)
+    train, valid = split_validation(remap(train_all), val_ratio, seed)
+    save_ckg_files(out_dir, len(users), train, valid, remap(test), kg)
+    return CKGDataset(out_dir)

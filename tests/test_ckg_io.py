@@ -70,3 +70,45 @@ def test_ranking_metrics_match_reference():
     rec, ndcg = metrics.calc_recall_ndcg(torch.as_tensor(g["metric_embedding"]), train, test, g["item_id_range"], K=5,
                                          batch_users=4)
     assert abs(rec - g["metric_recall_ndcg_at5"][0]) < 1e-12 and abs(ndcg - g["metric_recall_ndcg_at5"][1]) < 1e-12
+
+
+def test_raw_kgat_release_files(tmp_path):
+    """train.txt / test.txt / kg_final.txt of the KGAT release (process_kgat_data.py): parsing
+    rules, the "seen" validation split invariants, and the round trip into a CKGDataset."""
+    from dgl_kgat_amd import ckg_io
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    rng = np.random.default_rng(3)
+    n_users, n_items, n_ent, n_rel = 40, 30, 55, 4
+    lines, pairs = [], set()
+    for u in range(n_users):
+        its = rng.choice(n_items, rng.integers(1, 9), replace=False).tolist()
+        lines.append(" ".join(map(str, [u] + its + its[:1])))       # one repeated item per user
+        pairs |= {(u, v) for v in its}
+    lines.insert(5, "999")                                           # a user without items: skipped
+    covered = {v for _, v in pairs}
+    missing = sorted(set(range(n_items)) - covered)
+    (raw / "train.txt").write_text("\n".join(lines) + "\n")
+    (raw / "test.txt").write_text("\n".join("%d %s" % (u, " ".join(map(str, missing + [u % n_items])))
+                                            for u in range(0, n_users, 3)) + "\n")
+    kg = np.stack([rng.integers(0, n_ent, 300), rng.integers(0, n_rel, 300), rng.integers(0, n_ent, 300)], 1)
+    kg[:n_ent, 0] = np.arange(n_ent)                                 # every entity / relation id appears
+    kg[:n_rel, 1] = np.arange(n_rel)
+    kg = np.vstack([kg, kg[:20]])                                    # duplicate rows
+    np.savetxt(raw / "kg_final.txt", kg, fmt="%d")
+    got = ckg_io.read_kgat_interactions(str(raw / "train.txt"))
+    assert {tuple(p) for p in got.tolist()} == pairs and len(got) == len(pairs)
+    kg_read = ckg_io.read_kgat_kg(str(raw / "kg_final.txt"))
+    assert len(kg_read) == len({tuple(r) for r in kg.tolist()}) and np.array_equal(kg_read[:5], kg[:5])
+    train, valid = ckg_io.split_validation(got, 0.3, seed=1)
+    assert len(train) + len(valid) == len(got) and len(valid) <= int(0.3 * len(got))
+    assert set(np.unique(train[:, 0])) == set(np.unique(got[:, 0]))  # no user / item lost from training
+    assert set(np.unique(train[:, 1])) == set(np.unique(got[:, 1]))
+    t2, v2 = ckg_io.split_validation(got, 0.3, seed=1)
+    assert np.array_equal(t2, train) and np.array_equal(v2, valid)
+    ds = ckg_io.convert_kgat_release(str(raw), str(tmp_path / "out"), val_ratio=0.2, seed=2)
+    assert ds.n_users == n_users and ds.n_items == n_items
+    assert ds.n_train + ds.n_valid == len(pairs)
+    assert ds.train_KG_triplet.shape[1] == 3 and ds.n_KG_relation == n_rel + 2
+    g = ds.train_graph()
+    assert g.number_of_edges() == len(kg_read) + 2 * ds.n_train
