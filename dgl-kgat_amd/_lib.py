@@ -61,6 +61,11 @@ SIGNATURES = {
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _p, _sz, _u32, _i32, _p]),
     "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
+    "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _p, _p,
+                                             _i64, _p]),
+    "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _p,
+                                               _p]),
+    "kgat_mul2_f32": (_i32, [_i64, _p, _p, _p, _p, _p, _p]),
     "kgat_transr_supported": (_i32, [_i64, _i32, _i32, _i32, _i64]),
     "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,

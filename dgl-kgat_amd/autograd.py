@@ -131,3 +131,83 @@ def transr_loss(ent, W_R, rel, h, r, pos_t, neg_t, reg_lambda):
     """Differentiable fused TransR loss; index tensors of any integer dtype."""
     i32 = [t.to(torch.int32).contiguous() for t in (h, r, pos_t, neg_t)]
     return _TransRLoss.apply(ent, W_R, rel, *i32, float(reg_lambda))
+
+
+class _GNNTrain(torch.autograd.Function):
+    """The whole propagation stack under autograd (reference models.py:156-168 with the KGATConv of
+    :49-70 in training mode) as one differentiable unit: per layer the SpMM, one kernel for
+    (h * h_N) W2^T + LeakyReLU + dropout + the normalised copy written into its slice of the
+    readout; backward per layer one kernel for the normalise / dropout / LeakyReLU gradients, two
+    dense GEMMs, one two-product pass and the SpMM on the reversed CSR.  Gradients: the input
+    embeddings and every W2; the edge weights are constants (kgat.py:139-145)."""
+
+    @staticmethod
+    def forward(ctx, g, slope, drop_p, seed, h0, *weights):
+        st = g._st
+        dev = h0.device
+        h = h0.detach().contiguous()
+        csr = st.csr(dev)
+        w_flat = _flat_weight(g.edata["w"], st.n_edges).detach().contiguous()
+        w_csr = st.weight_in_csr_order(w_flat)
+        widths = [h.shape[1]] + [w.shape[0] for w in weights]
+        out = torch.empty((h.shape[0], sum(widths)), dtype=torch.float32, device=dev)
+        out[:, :widths[0]] = h
+        off = widths[0]
+        hs, hns = [h], []
+        for li, w in enumerate(weights):
+            hn = ops.spmm(csr.indptr, csr.col, csr.row_of, hs[-1], w_csr)
+            hs.append(ops.bi_interaction_train(hs[-1], hn, w.detach().contiguous(), slope, drop_p, seed + li,
+                                               norm_out=out[:, off:off + widths[li + 1]]))
+            hns.append(hn)
+            off += widths[li + 1]
+        ctx.g, ctx.slope, ctx.drop_p, ctx.seed, ctx.widths, ctx.w_flat = g, slope, drop_p, seed, widths, w_flat
+        ctx.save_for_backward(*hs, *hns, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        n_l = len(ctx.widths) - 1
+        saved = ctx.saved_tensors
+        hs, hns, weights = saved[:n_l + 1], saved[n_l + 1:2 * n_l + 1], saved[2 * n_l + 1:]
+        st = ctx.g._st
+        dev = grad_out.device
+        rev = st.csr_rev(dev)
+        w_rev = st.weight_in_rev_order(ctx.w_flat)
+        grad_out = grad_out.contiguous()
+        offs = [0]
+        for wd in ctx.widths:
+            offs.append(offs[-1] + wd)
+        g_a = g_b = None  # the two addends of the gradient arriving at hs[li + 1] from the layer above
+        grad_w = [None] * n_l
+        for li in range(n_l - 1, -1, -1):
+            gz = ops.bi_interaction_bwd_pre(hs[li + 1], g_a, g_b, grad_out[:, offs[li + 1]:offs[li + 2]], ctx.slope,
+                                            ctx.drop_p, ctx.seed + li)
+            if ctx.needs_input_grad[5 + li]:
+                grad_w[li] = tall_weight_grad(gz, hs[li] * hns[li])
+            gp = gz @ weights[li].detach()
+            t, g_b = ops.mul2(gp, hs[li], hns[li])          # grad_P * h (to be aggregated), grad_P * h_N
+            g_a = ops.spmm(rev.indptr, rev.col, rev.row_of, t, w_rev)
+        grad_h0 = None
+        if ctx.needs_input_grad[4]:
+            grad_h0 = grad_out[:, :ctx.widths[0]] + g_a
+            grad_h0 += g_b
+        return (None, None, None, None, grad_h0, *grad_w)
+
+
+def tall_weight_grad(grad, x, slabs=128):
+    """grad^T @ x for tall operands (N ~ 10^5 rows, <= 128 columns) reducing over N into a tiny
+    result: a batched GEMM over row slabs plus a sum (the library's single GEMM for this shape takes
+    0.45-0.5 ms at N = 159k; this takes ~30 us)."""
+    n = x.shape[0]
+    m = (n // slabs) * slabs
+    if m < 16 * slabs:
+        return grad.t() @ x
+    gw = torch.bmm(grad[:m].view(slabs, m // slabs, -1).transpose(1, 2), x[:m].view(slabs, m // slabs, -1)).sum(0)
+    if m < n:
+        gw = gw + grad[m:].t() @ x[m:]
+    return gw
+
+
+def gnn_train(g, h0, weights, slope=0.01, drop_p=0.0, seed=0):
+    """Differentiable fused propagation stack; returns the (N, sum of widths) readout."""
+    return _GNNTrain.apply(g, float(slope), float(drop_p), int(seed), h0, *weights)

@@ -29,10 +29,24 @@ __device__ __forceinline__ float row16_sum_d(float v) {
   return v;
 }
 
-template <int DI, int DO>
+// Dropout mask of the training form: a counter-based hash of (seed, element index), so the backward
+// pass recomputes the mask instead of storing it.  keep <=> hash >= p * 2^32.
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t index, uint32_t threshold) {
+  uint32_t x = (index * 0x9E3779B1u) ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x >= threshold;
+}
+
+// TRAIN: the A operand is H * HN formed while loading (P = H, second factor HN), and the
+// LeakyReLU output goes through dropout (mess_drop of reference models.py:70) before it is
+// written and normalised.
+template <int DI, int DO, bool TRAIN>
 __global__ __launch_bounds__(256) void bi_interaction_kernel(
-    int32_t n_rows, const float* __restrict__ P, const float* __restrict__ W2, float slope,
-    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride) {
+    int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
+    float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, float* __restrict__ h_out,
+    float* __restrict__ norm_out, int64_t norm_stride) {
   constexpr int KS = DI / 4, KT = DO / 16;
   // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
   // laid out in B-fragment order so that every wave then pulls its fragments with
@@ -76,6 +90,14 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       const float4 v = pa[m * 4];
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
+    if (TRAIN) {
+      const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
+#pragma unroll
+      for (int m = 0; m < DI / 16; ++m) {
+        const float4 v = pb[m * 4];
+        a[4 * m + 0] *= v.x; a[4 * m + 1] *= v.y; a[4 * m + 2] *= v.z; a[4 * m + 3] *= v.w;
+      }
+    }
   };
   auto tile = [&](int32_t t, const float (&a)[KS]) {
     const int32_t row0 = t << 4;
@@ -95,6 +117,9 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       for (int j = 0; j < 4; ++j) {
         float z = acc[c][j];
         z = z >= 0.f ? z : z * slope;
+        if (TRAIN)
+          z = drop_keep(seed, (uint32_t)(row0 + 4 * q + j) * (uint32_t)DO + (uint32_t)(16 * c + i), drop_threshold)
+                  ? z * keep_scale : 0.f;
         acc[c][j] = z;
         ss[j] = fmaf(z, z, ss[j]);
       }
@@ -141,16 +166,88 @@ __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(int64_t n_rows, 
   }
 }
 
+struct DropArgs {
+  uint32_t threshold = 0;
+  float keep_scale = 1.f;
+  uint32_t seed = 0;
+};
+
+static DropArgs drop_args(float p, uint64_t seed) {
+  DropArgs a;
+  double t = (double)p * 4294967296.0;
+  a.threshold = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  a.keep_scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  a.seed = (uint32_t)(seed ^ (seed >> 32));
+  return a;
+}
+
 template <int DI, int DO>
-static int launch_bi(int64_t n_rows, const float* P, const float* W2, float slope, float* h_out,
-                     float* norm_out, int64_t norm_stride, hipStream_t st) {
+static int launch_bi(int64_t n_rows, const float* P, const float* HN, const float* W2, float slope,
+                     const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st) {
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
   if (blocks > 2048) blocks = 2048;  // ... at most 8 blocks per CU, contiguous tile ranges
-  hipLaunchKernelGGL((bi_interaction_kernel<DI, DO>), dim3((unsigned)blocks), dim3(256), 0, st,
-                     (int32_t)n_rows, P, W2, slope, h_out, norm_out, norm_stride);
+  if (HN)
+    hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,
+                       norm_stride);
+  else
+    hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, false>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,
+                       norm_stride);
   KGAT_CHECK_LAUNCH("bi_interaction");
   return KGAT_OK;
+}
+
+// Backward head of the training layer, one 16-lane group per row.  y = the layer's (dropped)
+// output, saved by the forward.  dZ = [gA + gB + normalize_bwd(g_norm; y)] * keep/(1-p) *
+// LeakyReLU'(Z), with sign(Z) = sign(y) where kept and the mask recomputed from the hash.
+__global__ __launch_bounds__(256) void bi_bwd_pre_kernel(int64_t n_rows, int d, const float* __restrict__ y,
+                                                         const float* __restrict__ gA, const float* __restrict__ gB,
+                                                         const float* __restrict__ g_norm, int64_t g_norm_stride,
+                                                         float slope, uint32_t drop_threshold, float keep_scale,
+                                                         uint32_t seed, float* __restrict__ dZ) {
+  const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + sub; row < n_rows; row += (int64_t)gridDim.x * 16) {
+    const float* yr = y + (size_t)row * d;
+    float yv[8], gn[8];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = sl + 16 * c;
+      yv[c] = i < d ? yr[i] : 0.f;
+      gn[c] = (g_norm && i < d) ? g_norm[(size_t)row * g_norm_stride + i] : 0.f;
+      ss = fmaf(yv[c], yv[c], ss);
+      dot = fmaf(yv[c], gn[c], dot);
+    }
+    ss = row16_sum_d(ss);
+    dot = row16_sum_d(dot);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < 1e-12f;  // F.normalize: x / max(|x|, eps)
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    const float proj = clamped ? 0.f : dot * inv * inv;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = sl + 16 * c;
+      if (i < d) {
+        float g = (gn[c] - yv[c] * proj) * inv;
+        if (gA) g += gA[(size_t)row * d + i];
+        if (gB) g += gB[(size_t)row * d + i];
+        const bool keep = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)i, drop_threshold);
+        dZ[(size_t)row * d + i] = keep ? g * keep_scale * (yv[c] > 0.f ? 1.f : slope) : 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mul2_kernel(int64_t n4, const float4* __restrict__ A, const float4* __restrict__ B,
+                                                   const float4* __restrict__ C, float4* __restrict__ AB,
+                                                   float4* __restrict__ AC) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = A[i], b = B[i], c = C[i];
+    AB[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+    AC[i] = make_float4(a.x * c.x, a.y * c.y, a.z * c.z, a.w * c.w);
+  }
 }
 
 }  // namespace kgat
@@ -177,6 +274,21 @@ int kgat_bi_interaction_supported(int d_in, int d_out) {
   return ok(d_in) && ok(d_out) && (d_in / 4) * (d_out / 16) <= 128;
 }
 
+static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, const float* HN, const float* W2,
+                       float negative_slope, const DropArgs& dr, float* h_out, float* norm_out,
+                       int64_t norm_stride, hipStream_t st) {
+#define KGAT_BI_CASE(DI, DO) \
+  if (d_in == DI && d_out == DO) \
+    return launch_bi<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st);
+  KGAT_BI_CASE(16, 16) KGAT_BI_CASE(16, 32) KGAT_BI_CASE(16, 64) KGAT_BI_CASE(16, 128)
+  KGAT_BI_CASE(32, 16) KGAT_BI_CASE(32, 32) KGAT_BI_CASE(32, 64) KGAT_BI_CASE(32, 128)
+  KGAT_BI_CASE(64, 16) KGAT_BI_CASE(64, 32) KGAT_BI_CASE(64, 64) KGAT_BI_CASE(64, 128)
+  KGAT_BI_CASE(128, 16) KGAT_BI_CASE(128, 32) KGAT_BI_CASE(128, 64)
+#undef KGAT_BI_CASE
+  set_error("bi_interaction: unsupported widths %d -> %d", d_in, d_out);
+  return KGAT_E_UNSUPPORTED;
+}
+
 int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P, const float* W2,
                             float negative_slope, float* h_out, float* norm_out,
                             int64_t norm_stride, kgat_stream_t stream) {
@@ -188,16 +300,59 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
     set_error("bi_interaction: unsupported widths %d -> %d", d_in, d_out);
     return KGAT_E_UNSUPPORTED;
   }
-  hipStream_t st = as_stream(stream);
-#define KGAT_BI_CASE(DI, DO) \
-  if (d_in == DI && d_out == DO) return launch_bi<DI, DO>(n_rows, P, W2, negative_slope, h_out, norm_out, norm_stride, st);
-  KGAT_BI_CASE(16, 16) KGAT_BI_CASE(16, 32) KGAT_BI_CASE(16, 64) KGAT_BI_CASE(16, 128)
-  KGAT_BI_CASE(32, 16) KGAT_BI_CASE(32, 32) KGAT_BI_CASE(32, 64) KGAT_BI_CASE(32, 128)
-  KGAT_BI_CASE(64, 16) KGAT_BI_CASE(64, 32) KGAT_BI_CASE(64, 64) KGAT_BI_CASE(64, 128)
-  KGAT_BI_CASE(128, 16) KGAT_BI_CASE(128, 32) KGAT_BI_CASE(128, 64)
-#undef KGAT_BI_CASE
-  set_error("bi_interaction: unsupported widths %d -> %d", d_in, d_out);
-  return KGAT_E_UNSUPPORTED;
+  return bi_dispatch(n_rows, d_in, d_out, P, nullptr, W2, negative_slope, DropArgs(), h_out, norm_out, norm_stride,
+                     as_stream(stream));
+}
+
+int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
+                                  const float* W2, float negative_slope, float drop_p, uint64_t seed,
+                                  float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX && (uint64_t)n_rows * (uint64_t)d_out < (1ull << 32),
+                 "bi_interaction_train: bad row count");
+  KGAT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "bi_interaction_train: dropout probability outside [0, 1)");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(H && HN && W2 && h_out, "bi_interaction_train: null pointer");
+  KGAT_CHECK_ARG(norm_out == nullptr || norm_stride >= d_out, "bi_interaction_train: bad norm_stride");
+  if (!kgat_bi_interaction_supported(d_in, d_out)) {
+    set_error("bi_interaction_train: unsupported widths %d -> %d", d_in, d_out);
+    return KGAT_E_UNSUPPORTED;
+  }
+  return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, drop_args(drop_p, seed), h_out, norm_out,
+                     norm_stride, as_stream(stream));
+}
+
+int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,
+                                    const float* grad_b, const float* grad_norm, int64_t grad_norm_stride,
+                                    float negative_slope, float drop_p, uint64_t seed, float* grad_z,
+                                    kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && d_out > 0 && d_out <= 128 && (uint64_t)n_rows * (uint64_t)d_out < (1ull << 32),
+                 "bi_interaction_bwd_pre: bad size");
+  KGAT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "bi_interaction_bwd_pre: dropout probability outside [0, 1)");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(h_out && grad_z, "bi_interaction_bwd_pre: null pointer");
+  KGAT_CHECK_ARG(grad_norm == nullptr || grad_norm_stride >= d_out, "bi_interaction_bwd_pre: bad stride");
+  const DropArgs dr = drop_args(drop_p, seed);
+  int64_t blocks = (n_rows + 15) / 16;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bi_bwd_pre_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n_rows, d_out, h_out,
+                     grad_a, grad_b, grad_norm, grad_norm_stride, negative_slope, dr.threshold, dr.keep_scale, dr.seed,
+                     grad_z);
+  KGAT_CHECK_LAUNCH("bi_bwd_pre");
+  return KGAT_OK;
+}
+
+int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
+                  kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n >= 0 && n % 4 == 0, "mul2: length must be a multiple of 4");
+  if (n == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(a && b && c && ab && ac, "mul2: null pointer");
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mul2_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n / 4,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                     reinterpret_cast<const float4*>(c), reinterpret_cast<float4*>(ab), reinterpret_cast<float4*>(ac));
+  KGAT_CHECK_LAUNCH("mul2");
+  return KGAT_OK;
 }
 
 }  // extern "C"

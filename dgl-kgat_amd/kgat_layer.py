@@ -50,14 +50,8 @@ class _TallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = grad @ weight
         if ctx.needs_input_grad[1]:
-            n, s = x.shape[0], _TallLinear.SLABS
-            m = (n // s) * s
-            if m >= 16 * s:
-                gw = torch.bmm(grad[:m].view(s, m // s, -1).transpose(1, 2), x[:m].view(s, m // s, -1)).sum(0)
-                if m < n:
-                    gw = gw + grad[m:].t() @ x[m:]
-            else:
-                gw = grad.t() @ x
+            from .autograd import tall_weight_grad
+            gw = tall_weight_grad(grad, x, _TallLinear.SLABS)
         return gx, gw
 
 
@@ -135,10 +129,19 @@ class KGATPropagation(nn.Module):
 
     # -- propagation (models.py:156-168)
     def gnn(self, g, x=None, fused=None):
-        if fused is None:
+        auto = fused is None
+        if auto:
             fused = not torch.is_grad_enabled()
         if fused and self._can_fuse_readout():
             return self._gnn_fused(g) if g.partition is None else self._gnn_fused_sharded(g)
+        if auto and self._can_fuse_training(g):
+            # training mode (kgat.py:146-168): the whole stack as one autograd unit; the dropout mask
+            # seed comes from torch's CPU generator, so torch.manual_seed reproduces a run
+            from .autograd import gnn_train
+            p = self.layers[0].mess_drop.p if self.training else 0.0
+            seed = int(torch.empty((), dtype=torch.int64).random_()) if p > 0 else 0
+            return gnn_train(g, self._node_embeddings(g), [layer.res_fc_2.weight for layer in self.layers],
+                             0.01, p, seed)
         g = g.local_var()
         h = self._node_embeddings(g)
         node_embed_cache = [h]
@@ -146,6 +149,14 @@ class KGATPropagation(nn.Module):
             h = layer(g, h, fused=fused)
             node_embed_cache.append(F.normalize(h, p=2, dim=1))
         return torch.cat(node_embed_cache, 1)
+
+    def _can_fuse_training(self, g):
+        from . import ops
+        w = self.entity_embed.weight
+        return (g.partition is None and w.is_cuda and w.dtype == torch.float32 and "w" in g.edata and
+                not g.edata["w"].requires_grad and
+                all(ops.bi_interaction_supported(layer.res_fc_2.in_features, layer.res_fc_2.out_features) and
+                    layer.mess_drop.p < 1.0 for layer in self.layers))
 
     def _node_embeddings(self, g):
         """entity_embed(g.ndata['id']) (models.py:159); the reference's ids are arange(N)
@@ -227,7 +238,11 @@ class KGATPropagation(nn.Module):
 
     def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids):
         """BPR loss of reference models.py:170-178 (harness only)."""
-        s, p, n = embedding[src_ids], embedding[pos_dst_ids], embedding[neg_dst_ids]
+        # one gather of the three id lists (one dense zero-fill + one sorted scatter in backward
+        # instead of three), then split: the same rows as embedding[src_ids] etc.
+        b = src_ids.shape[0]
+        rows = embedding[torch.cat([src_ids, pos_dst_ids, neg_dst_ids])]
+        s, p, n = rows[:b], rows[b:2 * b], rows[2 * b:]
         pos = (s * p).sum(1)
         neg = (s * n).sum(1)
         cf = -F.logsigmoid(pos - neg).mean()

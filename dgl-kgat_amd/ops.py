@@ -428,6 +428,74 @@ def bi_interaction(P, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h
     return h_out
 
 
+def _strided_rows(t, n, d, name):
+    if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (n, d) or t.stride(1) != 1):
+        raise ValueError("%s must be an (n, %d) float32 device view with unit column stride" % (name, d))
+    return t.stride(0)
+
+
+def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None):
+    """Training form: h_out = dropout_p(leaky_relu((H * HN) @ W2^T)) and its normalised copy into
+    `norm_out` (kgat_bi_interaction_train_f32; the mask is a hash of (seed, element))."""
+    H = _need(H, torch.float32, "H")
+    HN = _need(HN, torch.float32, "HN", H.shape)
+    W2 = _need(W2, torch.float32, "W2")
+    n, d_in = H.shape
+    d_out = W2.shape[0]
+    if W2.shape[1] != d_in:
+        raise ValueError("W2 has shape %s, expected (*, %d)" % (tuple(W2.shape), d_in))
+    h_out = torch.empty((n, d_out), dtype=torch.float32, device=H.device)
+    stride = _strided_rows(norm_out, n, d_out, "norm_out") if norm_out is not None else 0
+    with _timed("bi_interaction", (n, d_in, d_out)):
+        check(_lib.load().kgat_bi_interaction_train_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2),
+                                                        float(negative_slope), float(drop_p), int(seed) & (2 ** 64 - 1),
+                                                        _ptr(h_out), _ptr(norm_out), stride, _stream(H)),
+              "kgat_bi_interaction_train_f32")
+    return h_out
+
+
+def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, drop_p, seed):
+    """grad_z of the training layer (kgat_bi_interaction_bwd_pre_f32); grad_a / grad_b / grad_norm may be None."""
+    h_out = _need(h_out, torch.float32, "h_out")
+    n, d = h_out.shape
+    for name, t in (("grad_a", grad_a), ("grad_b", grad_b)):
+        if t is not None:
+            _need(t, torch.float32, name, (n, d))
+    stride = _strided_rows(grad_norm, n, d, "grad_norm") if grad_norm is not None else 0
+    gz = torch.empty_like(h_out)
+    check(_lib.load().kgat_bi_interaction_bwd_pre_f32(n, d, _ptr(h_out), _ptr(grad_a), _ptr(grad_b), _ptr(grad_norm),
+                                                      stride, float(negative_slope), float(drop_p),
+                                                      int(seed) & (2 ** 64 - 1), _ptr(gz), _stream(h_out)),
+          "kgat_bi_interaction_bwd_pre_f32")
+    return gz
+
+
+def mul2(a, b, c):
+    """(a * b, a * c) in one pass."""
+    a = _need(a, torch.float32, "a")
+    b = _need(b, torch.float32, "b", a.shape)
+    c = _need(c, torch.float32, "c", a.shape)
+    ab, ac = torch.empty_like(a), torch.empty_like(a)
+    check(_lib.load().kgat_mul2_f32(a.numel(), _ptr(a), _ptr(b), _ptr(c), _ptr(ab), _ptr(ac), _stream(a)), "kgat_mul2_f32")
+    return ab, ac
+
+
+def dropout_keep_mask(seed, n_rows, d, drop_p):
+    """The mask kgat_bi_interaction_train_f32 applies, restated in numpy (tests): element (row, col)
+    is kept iff murmur3-finalised ((row*d + col) * 0x9E3779B1 ^ seed32) >= p * 2^32."""
+    import numpy as np
+    seed = int(seed) & (2 ** 64 - 1)
+    seed32 = np.uint32((seed ^ (seed >> 32)) & 0xFFFFFFFF)
+    x = (np.arange(n_rows * d, dtype=np.uint64) * np.uint64(0x9E3779B1)).astype(np.uint32) ^ seed32
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
+    x ^= x >> np.uint32(13)
+    x = (x.astype(np.uint64) * np.uint64(0xC2B2AE35)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    t = min(int(float(np.float32(drop_p)) * 4294967296.0), 0xFFFFFFFF)
+    return (x >= np.uint32(t)).reshape(n_rows, d)
+
+
 def l2_normalize_rows(x, out):
     """out[:, :] = x / max(||x_row||, 1e-12); `out` may be a column slice of a wider buffer."""
     x = _need(x, torch.float32, "x")
@@ -452,6 +520,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
            "KGATLibraryError"]

@@ -260,6 +260,29 @@ int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out
 int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t* out,
                     kgat_stream_t stream);
 
+/* ---------------------------------------------------------------- training form of the layer (8f #1)
+ * Forward of one KGATConv under autograd (reference models.py:63-70 with mess_drop active):
+ *   h_out = dropout_p(LeakyReLU((H * HN) W2^T)),  norm_out = F.normalize(h_out)
+ * H * HN is formed while the rows are loaded.  The dropout mask is a counter-based hash of
+ * (seed, row * d_out + column): keep <=> hash >= p * 2^32, kept values scaled by 1/(1-p); the
+ * backward recomputes it from the same seed.  Widths as kgat_bi_interaction_supported. */
+int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
+                                  const float* W2, float negative_slope, float drop_p, uint64_t seed,
+                                  float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream);
+/* Backward head of the same layer: with y = h_out saved by the forward,
+ *   grad_z = [grad_a + grad_b + normalize_bwd(grad_norm; y)] * mask/(1-p) * LeakyReLU'(z)
+ * (grad_a, grad_b: gradients arriving at h_out from the next layer, either may be NULL;
+ * grad_norm: gradient of the normalised copy, row stride grad_norm_stride, may be NULL).
+ * The rest of the backward is dense: grad_P = grad_z W2, grad_W2 = grad_z^T (H * HN), then
+ * grad_H = grad_P * HN + A^T (grad_P * H) (kgat_mul2_f32 + the SpMM on the reversed CSR). */
+int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,
+                                    const float* grad_b, const float* grad_norm, int64_t grad_norm_stride,
+                                    float negative_slope, float drop_p, uint64_t seed, float* grad_z,
+                                    kgat_stream_t stream);
+/* ab = a * b and ac = a * c elementwise in one pass (n a multiple of 4). */
+int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
+                  kgat_stream_t stream);
+
 /* ---------------------------------------------------------------- TransR KG step
  * Loss and gradients of reference models.py:114-133 (transR; bmm_maybe_select :13-47,
  * _L2_loss_mean :9-11) for one batch of triplets (h[b], r[b], pos_t[b], neg_t[b]):

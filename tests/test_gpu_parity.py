@@ -698,3 +698,75 @@ def test_transr_fused_refuses_what_it_cannot_do(K, dev):
     with pytest.raises(Exception):
         m.transR(idx, idx, idx, idx, fused=True)
     assert torch.isfinite(m.transR(idx, idx, idx, idx))  # default dispatch: torch restatement on the device
+
+
+def _train_graph_and_model(K, dev, d, hidden, p, seed=11):
+    from dgl_kgat_amd import synth
+    n, e, R = 900, 30000, 5
+    src, dst = random_graph(seed, n, e, hub=2500, isolated_tail=15)
+    rng = np.random.default_rng(seed + 1)
+    trip = np.stack([dst, rng.integers(0, R, e).astype(np.int32), src], 1).astype(np.int32)
+    g = synth.build_graph(n, trip, dev)
+    torch.manual_seed(seed)
+    m = K.KGATPropagation(n, R, d, d, 3, hidden, dropout=p).to(dev)
+    with torch.no_grad():
+        g.edata["w"] = m.compute_attention(g)
+    return g, m, n
+
+
+@pytest.mark.parametrize("d,hidden", [(64, 64), (32, 64), (16, 64)])
+def test_gnn_train_fused_matches_unfused_autograd(K, dev, d, hidden):
+    """The fused training stack (one autograd unit: kgat_bi_interaction_train_f32 /
+    _bwd_pre_f32 / kgat_mul2_f32 + the SpMMs) against the operator-by-operator autograd path
+    over the drop-in surface, dropout off: readout, gradient of the embeddings and of every W2."""
+    g, m, n = _train_graph_and_model(K, dev, d, hidden, 0.0)
+    params = [m.entity_embed.weight] + [l.res_fc_2.weight for l in m.layers]
+    probe = torch.randn(n, sum([d] + [l.res_fc_2.out_features for l in m.layers]),
+                        generator=torch.Generator().manual_seed(3)).to(dev)
+    ref = m.gnn(g, fused=False)
+    ref_g = torch.autograd.grad((ref * probe).sum(), params)
+    out = m.gnn(g)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_GNNTrain")
+    out_g = torch.autograd.grad((out * probe).sum(), params)
+    assert blocks_rel_err_inf(out.detach().cpu().numpy(), ref.detach().cpu().numpy(),
+                              [d] + [l.res_fc_2.out_features for l in m.layers]) < 1e-5
+    for a, b_, name in zip(out_g, ref_g, ["entity_embed"] + ["W2_%d" % i for i in range(3)]):
+        assert rel_err_inf(a.cpu().numpy(), b_.cpu().numpy()) < 2e-5, name
+
+
+def test_gnn_train_fused_dropout(K, dev):
+    """Dropout on: the kernel's hash mask restated in numpy (ops.dropout_keep_mask) drives a torch
+    autograd restatement of the same stack; outputs and gradients must agree, the drop rate must be
+    p, and a torch seed must reproduce the run."""
+    from dgl_kgat_amd import ops
+    from dgl_kgat_amd.autograd import gnn_train, u_mul_e_sum
+    d, hidden, p, seed = 32, 64, 0.3, 123456789012
+    g, m, n = _train_graph_and_model(K, dev, d, hidden, p)
+    weights = [l.res_fc_2.weight for l in m.layers]
+    h0 = m.entity_embed.weight
+    out = gnn_train(g, h0, weights, 0.01, p, seed)
+    h, cache, kept = h0, [h0], []
+    for li, w in enumerate(weights):
+        mask = torch.as_tensor(ops.dropout_keep_mask(seed + li, n, w.shape[0], p)).to(dev)
+        kept.append(float(mask.float().mean()))
+        hn = u_mul_e_sum(g, h, g.edata["w"])
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h * hn, w)) * mask / (1 - p)
+        cache.append(torch.nn.functional.normalize(h, p=2, dim=1))
+    ref = torch.cat(cache, 1)
+    assert all(abs(k - (1 - p)) < 0.02 for k in kept)
+    widths = [d] + [w.shape[0] for w in weights]
+    assert blocks_rel_err_inf(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), widths) < 1e-5
+    probe = torch.randn(n, sum(widths), generator=torch.Generator().manual_seed(4)).to(dev)
+    params = [h0] + weights
+    out_g = torch.autograd.grad((out * probe).sum(), params)
+    ref_g = torch.autograd.grad((ref * probe).sum(), params)
+    for a, b_ in zip(out_g, ref_g):
+        assert rel_err_inf(a.cpu().numpy(), b_.cpu().numpy()) < 2e-5
+    # through the module: training mode draws the seed from torch's generator
+    m.train()
+    torch.manual_seed(77)
+    a1 = m.gnn(g).detach()
+    torch.manual_seed(77)
+    a2 = m.gnn(g).detach()
+    a3 = m.gnn(g).detach()
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
