@@ -10,10 +10,12 @@
 // 4*(D_in + 2*D_out) bytes per row against 2*D_in*D_out FLOP).  One wavefront owns 16-row
 // tiles; W2 (<= 32 KB) is staged once per workgroup through LDS and then lives in registers as
 // fp32 MFMA B fragments for the whole launch
-// (v_mfma_f32_16x16x4_f32, exact fp32); the rows of a tile are contiguous, so the A-fragment
-// loads are fully coalesced float4 reads; the row norm is a DPP reduction over the 16 lanes
-// that hold one row's columns.
+// (v_mfma_f32_16x16x4_f32, exact fp32); the rows of a tile are contiguous, so the row-fragment
+// loads are fully coalesced float4 reads; the product is issued with the operands swapped so
+// that a lane ends up with four consecutive columns of one row (16-byte stores), and the row
+// norm is a sum over a lane's values plus two cross-lane adds.
 #include <math.h>
+#include <stdint.h>
 
 #include "kgat_common.h"
 
@@ -42,7 +44,7 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t index, uint32_
 // TRAIN: the A operand is H * HN formed while loading (P = H, second factor HN), and the
 // LeakyReLU output goes through dropout (mess_drop of reference models.py:70) before it is
 // written and normalised.
-template <int DI, int DO, bool TRAIN>
+template <int DI, int DO, bool TRAIN, bool VEC_NORM>
 __global__ __launch_bounds__(256) void bi_interaction_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
     float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, float* __restrict__ h_out,
@@ -104,13 +106,16 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     floatx4_d acc[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){0.f, 0.f, 0.f, 0.f};
+    // operands swapped (A = W2 fragment, B = the tile's rows): the accumulators hold Z^T, i.e.
+    // acc[c][j] = Z[row0 + i][16c + 4q + j] - four consecutive columns per lane, so the results
+    // leave as 16-byte stores (a quarter of the store instructions of the row-major result)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < KT; ++c)
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wreg[s][c], acc[c], 0, 0, 0);
-    // acc[c][j] = Z[row0 + 4q + j][16c + i]
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][c], a[s], acc[c], 0, 0, 0);
+    const int32_t row = row0 + i;
+    float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < KT; ++c)
 #pragma unroll
@@ -118,21 +123,27 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         float z = acc[c][j];
         z = z >= 0.f ? z : z * slope;
         if (TRAIN)
-          z = drop_keep(seed, (uint32_t)(row0 + 4 * q + j) * (uint32_t)DO + (uint32_t)(16 * c + i), drop_threshold)
+          z = drop_keep(seed, (uint32_t)row * (uint32_t)DO + (uint32_t)(16 * c + 4 * q + j), drop_threshold)
                   ? z * keep_scale : 0.f;
         acc[c][j] = z;
-        ss[j] = fmaf(z, z, ss[j]);
+        ss = fmaf(z, z, ss);
       }
+    // the four lanes (i, q = 0..3) of a row hold its 4 x KT column groups
+    ss += __shfl_xor(ss, 16, kWave);
+    ss += __shfl_xor(ss, 32, kWave);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    if (row < n_rows) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int32_t row = row0 + 4 * q + j;
-      const float nrm = fmaxf(sqrtf(row16_sum_d(ss[j])), 1e-12f);
-      if (row < n_rows) {
-#pragma unroll
-        for (int c = 0; c < KT; ++c) {
-          const float z = acc[c][j];
-          if (h_out) h_out[(size_t)row * DO + 16 * c + i] = z;
-          if (norm_out) norm_out[(size_t)row * norm_stride + 16 * c + i] = z / nrm;
+      for (int c = 0; c < KT; ++c) {
+        const float z0 = acc[c][0], z1 = acc[c][1], z2 = acc[c][2], z3 = acc[c][3];
+        if (h_out) *reinterpret_cast<float4*>(h_out + (size_t)row * DO + 16 * c + 4 * q) = make_float4(z0, z1, z2, z3);
+        if (norm_out) {
+          float* dst = norm_out + (size_t)row * norm_stride + 16 * c + 4 * q;
+          if (VEC_NORM) {
+            *reinterpret_cast<float4*>(dst) = make_float4(z0 / nrm, z1 / nrm, z2 / nrm, z3 / nrm);
+          } else {
+            dst[0] = z0 / nrm; dst[1] = z1 / nrm; dst[2] = z2 / nrm; dst[3] = z3 / nrm;
+          }
         }
       }
     }
@@ -187,14 +198,19 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
   if (blocks > 2048) blocks = 2048;  // ... at most 8 blocks per CU, contiguous tile ranges
-  if (HN)
-    hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, true>), dim3((unsigned)blocks), dim3(256), 0, st,
-                       (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,
-                       norm_stride);
-  else
-    hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, false>), dim3((unsigned)blocks), dim3(256), 0, st,
-                       (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,
-                       norm_stride);
+  // 16-byte stores into the normalised copy need its slice 16-byte aligned with a row stride that keeps it so
+  const bool vec = norm_out == nullptr ||
+                   ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);
+#define KGAT_BI_LAUNCH(TR, VEC)                                                                                     \
+  hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, TR, VEC>), dim3((unsigned)blocks), dim3(256), 0, st,            \
+                     (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,      \
+                     norm_stride)
+  if (HN) {
+    if (vec) KGAT_BI_LAUNCH(true, true); else KGAT_BI_LAUNCH(true, false);
+  } else {
+    if (vec) KGAT_BI_LAUNCH(false, true); else KGAT_BI_LAUNCH(false, false);
+  }
+#undef KGAT_BI_LAUNCH
   KGAT_CHECK_LAUNCH("bi_interaction");
   return KGAT_OK;
 }
