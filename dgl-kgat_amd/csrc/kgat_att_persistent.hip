@@ -914,7 +914,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       int32_t p = p0 + lane;
       p = p < d.w ? p : d.w - 1;
       CIdx c;
-      c.row_off = src_g[p] * (D_ * 4);
+      c.row_off = (int32_t)((uint32_t)src_g[p] * (uint32_t)(D_ * 4));  // byte offset, < 4 GiB (checked by the caller)
       c.lg = gid[p] - d.y;
       c.oe = LOGITS_EID ? perm[p] : 0;
       c.op = pos_or_perm[p];
