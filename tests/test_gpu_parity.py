@@ -632,6 +632,40 @@ def test_full_size_properties(K, dev):
         assert np.max(np.abs(mh[v] - ref)) < 1e-4 * max(np.abs(ref).max(), 1e-3 * scale)
 
 
+def test_full_size_attention_forms(K, dev):
+    """amazon-book-sized CKG: the attention forms against each other (fused == folded bit for bit;
+    split == one-kernel bit for bit; the two families within fp32 rounding), an oracle spot check
+    on a sample of edges, and the end-to-end attention (all forms) summing to one per destination."""
+    from dgl_kgat_amd import ops, synth
+    n, trip, R = synth.amazon_book_ckg()
+    e, d = len(trip), 64
+    g = synth.build_graph(n, trip, dev)
+    torch.manual_seed(3)
+    m = K.KGATPropagation(n, R, d, d, 3, d, dropout=0.0).to(dev)
+    ent, W, rel = m.entity_embed.weight.detach(), m.W_R.detach(), m.relation_embed.weight.detach()
+    st = g._st
+    groups = st.rel_groups(g.edata["type"], R)
+    args = (n, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g, groups.gid, groups.gptr, groups.g_node)
+    tiles, tptr = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups)
+    assert int(tptr[-1]) <= tiles.shape[0] and int(tptr[-1]) >= (groups.n_groups + 15) // 16
+    fused, _ = ops.att_score_fused(*args, tiles, tptr, ent, W, rel, want_csr=False)
+    folded, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False, folded=True)
+    split, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False)
+    one, _ = ops.att_score(n, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g, ent, W, rel)
+    assert torch.equal(fused, folded) and torch.equal(split, one)
+    scale = float(one.abs().max())
+    assert float((fused - one).abs().max()) < 1e-5 * scale
+    idx = np.random.default_rng(4).choice(e, 5000, replace=False)
+    ref = orc.att_score(ent.cpu().numpy(), W.cpu().numpy(), rel.cpu().numpy(), trip[idx, 2], trip[idx, 0], trip[idx, 1])
+    assert np.abs(fused.cpu().numpy()[idx] - ref).max() < 1e-5 * scale
+    deg = torch.as_tensor(np.bincount(trip[:, 0], minlength=n) > 0, device=dev)
+    for form in ("fused", "folded", "split", "one"):
+        with torch.no_grad():
+            a = g.kgat_attention(ent, W, rel, algo=form)
+        sums = torch.zeros(n, device=dev).index_add_(0, torch.as_tensor(trip[:, 0].astype(np.int64), device=dev), a.reshape(-1))
+        assert float((sums[deg] - 1).abs().max()) < 1e-4 and torch.all(sums[~deg] == 0), form
+
+
 def test_training_harness_end_to_end(K, dev):
     """examples/train_kgat.py: reference-format files -> CKGDataset -> KG phase / attention refresh /
     CF phase / recall@20 + ndcg@20, the epoch structure of kgat.py:114-196, on the kernels."""
