@@ -91,7 +91,8 @@ def main():
         ds.n_users, ds.n_items, ds.n_KG_entity, ds.n_KG_relation, len(ds.train_KG_triplet)))
     model = K.KGATPropagation(ds.n_KG_entity, ds.n_KG_relation, args.entity_embed_dim, args.relation_embed_dim,
                               args.gnn_num_layer, args.gnn_hidden_size, args.dropout_rate).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    # one Adam over all parameters (kgat.py:85); torch's single-kernel implementation of the same update
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, fused=dev.type == "cuda")
     train_g, test_g = ds.train_graph(dev), ds.test_graph(dev)
     trip = torch.as_tensor(ds.train_KG_triplet.astype(np.int64), device=dev)
     pairs = torch.as_tensor(ds.train_pairs.astype(np.int64), device=dev)

@@ -179,9 +179,11 @@ def main():
         h, r, pt = dst[idx].long(), et[idx].long(), src[idx].long()
         nt = torch.randint(0, n, (B,), device=dev)
 
-        for fused in (True, False):
+        for fused in (True, False, "fused+fusedAdam"):
+            if fused == "fused+fusedAdam":
+                opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)
             def step():
-                loss = model.transR(h, r, pt, nt, fused=fused)
+                loss = model.transR(h, r, pt, nt, fused=bool(fused))
                 loss.backward()
                 opt.step()
                 opt.zero_grad()
@@ -194,7 +196,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.rounds
-            print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, "fused kernels" if fused else "torch ops", dt * 1e3))
+            print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, {True: "fused kernels", False: "torch ops"}.get(fused, "fused kernels + torch's fused Adam"), dt * 1e3))
     else:
         logits = torch.randn(E, generator=g).to(dev)
         fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
