@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
     const int32_t* __restrict__ gid,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g, const float* __restrict__ ent,
     const float* __restrict__ V_tab, float* __restrict__ logits, float* __restrict__ logits_csr) {
-  constexpr int LPE = D_ / 4 < 16 ? D_ / 4 : 16;  // lanes per edge
-  constexpr int VPL = D_ / (4 * LPE);              // float4 pieces per lane (2 at d = 128)
+  constexpr int LPE = kTailLanesPerEdge<D_>();  // lanes per edge
+  constexpr int VPL = D_ / (4 * LPE);           // float4 pieces per lane
   const int64_t n_scored = rel_ptr[n_rel];
   const int lane = threadIdx.x % kWave;
   const int li = lane % LPE;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
   const char* eb = reinterpret_cast<const char*>(ent) + v_off_lo;
   const char* vb = reinterpret_cast<const char*>(V_tab) + v_off_lo;
   float mine = 0.f;
-  constexpr int U = (LPE < 4 ? LPE : 4) / (VPL > 1 ? 2 : 1);
+  constexpr int U = (8 / VPL < 1 ? 1 : 8 / VPL) < LPE ? (8 / VPL < 1 ? 1 : 8 / VPL) : LPE;  // steps whose loads (<= 16 float4 per lane) are in flight together
 #pragma unroll
   for (int s0 = 0; s0 < LPE; s0 += U) {
     float4 a[U][VPL], b[U][VPL];

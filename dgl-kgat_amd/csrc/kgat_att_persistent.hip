@@ -844,7 +844,8 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr) {
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFusedThreads / kWave;
-  constexpr int LPE = D_ / 4 < 16 ? D_ / 4 : 16;  // lanes per edge in the edge phase
+  constexpr int LPE = kFusedLanesPerEdge<D_>();    // lanes per edge in the edge phase
+  constexpr int VPL = D_ / (4 * LPE);             // float4 pieces of a row per lane
   constexpr int LDV = D_ + 4;
   static_assert(D_ <= 64, "one float4 per lane per row");
   __shared__ __attribute__((aligned(16))) float s_w[D_ * LD];
@@ -930,13 +931,14 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
       }
     };
-    struct EBuf { float4 r[LPE]; };
+    struct EBuf { float4 r[LPE][VPL]; };
     const char* eb = reinterpret_cast<const char*>(ent) + li * 16;
     auto load_edges = [&](EBuf& e, const CIdx& c) {
 #pragma unroll
       for (int s = 0; s < LPE; ++s) {
         const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.row_off);
-        e.r[s] = *reinterpret_cast<const float4*>(eb + eo);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) e.r[s][v] = *reinterpret_cast<const float4*>(eb + eo + v * (LPE * 16));
       }
     };
     auto mfma_phase = [&](const HBuf& f) {
@@ -985,11 +987,15 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
 #pragma unroll
       for (int s = 0; s < LPE; ++s) {
         const int32_t lg = __builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.lg);
-        const float4 b = *reinterpret_cast<const float4*>(vrow + lg * LDV + 4 * li);
-        float d = e.r[s].x * b.x;
-        d = fmaf(e.r[s].y, b.y, d);
-        d = fmaf(e.r[s].z, b.z, d);
-        d = fmaf(e.r[s].w, b.w, d);
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const float4 b = *reinterpret_cast<const float4*>(vrow + lg * LDV + 4 * li + v * (LPE * 4));
+          d = v == 0 ? e.r[s][v].x * b.x : fmaf(e.r[s][v].x, b.x, d);
+          d = fmaf(e.r[s][v].y, b.y, d);
+          d = fmaf(e.r[s][v].z, b.z, d);
+          d = fmaf(e.r[s][v].w, b.w, d);
+        }
         d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
         d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
         if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));

@@ -159,9 +159,9 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
  *   tiles    int32[4 * kgat_fold_tiles_max(...)]: (relation, first group, first position, end position)
  *   rel_tptr int32[R+1]: first tile of each relation; rel_tptr[R] = number of tiles
  * A wavefront computes a tile's V rows (as kgat_att_score_folded_f32), keeps them in LDS and
- * takes the dot products of the tile's positions itself.  Same logits as the folded form bit
- * for bit (same products, same order).  cap: a positive multiple of 64 (256 is the default of
- * the host code).  Needs d == k in {16,32,64}. */
+ * takes the dot products of the tile's positions itself.  Same logits as the folded form up to
+ * the summation order of the d-length dot product (fp32 rounding).  cap: a positive multiple of
+ * 64 (128 is the default of the host code).  Needs d == k in {16,32,64}. */
 int64_t kgat_fold_tiles_max(int64_t n_edges, int64_t n_groups, int n_rel, int cap);
 size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel);
 int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,

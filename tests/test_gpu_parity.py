@@ -347,7 +347,7 @@ def test_att_split_head_groups(K, dev, d):
 @pytest.mark.parametrize("cap", [64, 256])
 def test_att_fused_tiles_and_logits(K, dev, d, cap):
     """Fused folded form: the tile table is bit-exact against the oracle's restatement, and the
-    logits equal the two-launch folded form bit for bit (same products in the same order)."""
+    logits agree with the two-launch folded form to fp32 rounding and with the fp64 oracle."""
     from dgl_kgat_amd import ops
     n, e, R = 700, 30000, 6
     src, dst = random_graph(12, n, e, hub=4000, isolated_tail=20)
@@ -372,9 +372,10 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
     for want_eid in (True, False):
         fused, fused_csr = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
                                                tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=want_eid)
-        assert torch.equal(fused_csr, fold_csr)
+        # (another lane split of the d-length dot product than the two-launch form: fp32 rounding apart)
+        assert rel_err_inf(fused_csr.cpu().numpy(), fold_csr.cpu().numpy()) < 2e-6
         if want_eid:
-            assert torch.equal(fused, fold)
+            assert torch.equal(fused_csr, fused[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].long()])
     assert rel_err_inf(fused_csr.cpu().numpy(), ref[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].cpu().numpy()]) < 1e-5
 
 
@@ -633,8 +634,8 @@ def test_full_size_properties(K, dev):
 
 
 def test_full_size_attention_forms(K, dev):
-    """amazon-book-sized CKG: the attention forms against each other (fused == folded bit for bit;
-    split == one-kernel bit for bit; the two families within fp32 rounding), an oracle spot check
+    """amazon-book-sized CKG: the attention forms against each other (split == one-kernel bit for
+    bit; fused, folded and that family within fp32 rounding of each other), an oracle spot check
     on a sample of edges, and the end-to-end attention (all forms) summing to one per destination."""
     from dgl_kgat_amd import ops, synth
     n, trip, R = synth.amazon_book_ckg()
@@ -652,8 +653,9 @@ def test_full_size_attention_forms(K, dev):
     folded, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False, folded=True)
     split, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False)
     one, _ = ops.att_score(n, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g, ent, W, rel)
-    assert torch.equal(fused, folded) and torch.equal(split, one)
+    assert torch.equal(split, one)
     scale = float(one.abs().max())
+    assert float((fused - folded).abs().max()) < 2e-6 * scale
     assert float((fused - one).abs().max()) < 1e-5 * scale
     idx = np.random.default_rng(4).choice(e, 5000, replace=False)
     ref = orc.att_score(ent.cpu().numpy(), W.cpu().numpy(), rel.cpu().numpy(), trip[idx, 2], trip[idx, 0], trip[idx, 1])
