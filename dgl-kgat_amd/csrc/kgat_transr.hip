@@ -185,13 +185,16 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
 
 // ---- per-sample kernel: projections, loss head, its backward, grad_a W_r^T
 // One wavefront per (relation-sorted) sample s; b = order[s] is the sample's place in the batch.
-// Row rho = 3 b + {0,1,2} of GA / DX belongs to (head, positive tail, negative tail) of sample b.
+// Row 3 b + {0,1,2} of DX belongs to (head, positive tail, negative tail) of batch sample b; GA, GR
+// and XS (the gathered entity rows) are written in relation-sorted order (rows 3 s + v, s) for the
+// W-gradient kernel, which then reads contiguous memory only.
 template <bool GRAD>
 __global__ __launch_bounds__(256) void transr_sample_kernel(
     int32_t batch, int d, int k, const int32_t* __restrict__ order, const int32_t* __restrict__ h,
     const int32_t* __restrict__ r, const int32_t* __restrict__ pt, const int32_t* __restrict__ nt,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel, float lambda,
-    float* __restrict__ losses, float* __restrict__ GA, float* __restrict__ GR, float* __restrict__ DX) {
+    float* __restrict__ losses, float* __restrict__ GA, float* __restrict__ GR, float* __restrict__ DX,
+    float* __restrict__ XS) {
   __shared__ float s_x[256 / kWave][3][kTrMaxDim];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   const int32_t s = blockIdx.x * (256 / kWave) + wv;
@@ -203,7 +206,11 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
   float(*sx)[kTrMaxDim] = s_x[wv];
 #pragma unroll
   for (int v = 0; v < 3; ++v)
-    for (int i = lane; i < d; i += kWave) sx[v][i] = ent[(size_t)ids[v] * d + i];
+    for (int i = lane; i < d; i += kWave) {
+      const float x = ent[(size_t)ids[v] * d + i];
+      sx[v][i] = x;
+      if (GRAD) XS[((size_t)3 * s + v) * d + i] = x;  // the rows again, in relation-sorted order, for the W gradient
+    }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   constexpr int JV = kTrMaxDim / kWave;  // column slots per lane
@@ -276,15 +283,15 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
 #pragma unroll
     for (int c = 0; c < JV; ++c) g[v][c] = (g[v][c] - u[v][c] * dot) / nrm[v];
   }
-  // grad wrt the projections (rows 3b..3b+2 of GA) and the relation row (row b of GR)
+  // grad wrt the projections (rows 3s..3s+2 of GA) and the relation row (row s of GR), relation-sorted
 #pragma unroll
   for (int c = 0; c < JV; ++c) {
     const int j = lane + c * kWave;
     if (j < k) {
-      GA[((size_t)3 * b + 0) * k + j] = g[0][c];
-      GA[((size_t)3 * b + 1) * k + j] = g[1][c];
-      GA[((size_t)3 * b + 2) * k + j] = g[2][c];
-      GR[(size_t)b * k + j] = g[3][c];
+      GA[((size_t)3 * s + 0) * k + j] = g[0][c];
+      GA[((size_t)3 * s + 1) * k + j] = g[1][c];
+      GA[((size_t)3 * s + 2) * k + j] = g[2][c];
+      GR[(size_t)s * k + j] = g[3][c];
     }
   }
   // grad wrt the entity rows: dx[i] = sum_j ga[j] W[i][j]; ga goes through the wave's LDS patch
@@ -320,10 +327,9 @@ constexpr int kTrStage = 16;  // samples staged through LDS per step of the part
 // Thread t owns 4 x 4 blocks of the d x k outer-product sum: block index t, t + 256, ... over
 // (d/4) x (k/4) blocks, so a sample costs two 16-byte LDS reads per 16 fmas.  d, k multiples of 4.
 __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
-    int d, int k, int n_rel, const int32_t* __restrict__ seg, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ h, const int32_t* __restrict__ pt, const int32_t* __restrict__ nt,
-    const float* __restrict__ ent, const float* __restrict__ GA, const float* __restrict__ GR,
-    const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part) {
+    int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
+    const float* __restrict__ GA, const float* __restrict__ GR, const int32_t* __restrict__ chunk_ptr,
+    const int2* __restrict__ chunks, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float s_x[kTrStage][3][kTrMaxDim];
   __shared__ __attribute__((aligned(16))) float s_g[kTrStage][3][kTrMaxDim];
   __shared__ float s_r[kTrStage][kTrMaxDim];
@@ -349,17 +355,11 @@ __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
   for (int32_t s0 = beg; s0 < end; s0 += kTrStage) {
     const int ns = end - s0 < kTrStage ? end - s0 : kTrStage;
     __syncthreads();
-    for (int t = threadIdx.x; t < ns * 3 * d; t += 256) {
-      const int q = t / (3 * d), v = (t / d) % 3, i = t % d;
-      const int32_t b = order[s0 + q];
-      const int32_t id = v == 0 ? h[b] : (v == 1 ? pt[b] : nt[b]);
-      s_x[q][v][i] = ent[(size_t)id * d + i];
-    }
-    for (int t = threadIdx.x; t < ns * 3 * k; t += 256) {
-      const int q = t / (3 * k), v = (t / k) % 3, j = t % k;
-      s_g[q][v][j] = GA[((size_t)3 * order[s0 + q] + v) * k + j];
-    }
-    for (int t = threadIdx.x; t < ns * k; t += 256) s_r[t / k][t % k] = GR[(size_t)order[s0 + t / k] * k + t % k];
+    for (int t = threadIdx.x; t < ns * 3 * d; t += 256)
+      s_x[t / (3 * d)][(t / d) % 3][t % d] = XS[(size_t)3 * s0 * d + t];
+    for (int t = threadIdx.x; t < ns * 3 * k; t += 256)
+      s_g[t / (3 * k)][(t / k) % 3][t % k] = GA[(size_t)3 * s0 * k + t];
+    for (int t = threadIdx.x; t < ns * k; t += 256) s_r[t / k][t % k] = GR[(size_t)s0 * k + t];
     __syncthreads();
     for (int q = 0; q < ns; ++q) {
 #pragma unroll
@@ -500,7 +500,7 @@ size_t kgat_transr_workspace_bytes(int64_t batch, int d, int k, int n_rel) {
   w += align_up(b * 4, 256);                       // losses
   w += align_up(3 * b * (size_t)k * 4, 256);       // GA
   w += align_up(b * (size_t)k * 4, 256);           // GR
-  w += align_up(3 * b * (size_t)d * 4, 256);       // DX
+  w += 2 * align_up(3 * b * (size_t)d * 4, 256);   // DX, XS
   w += align_up(n_part * ((size_t)d * k + k) * 4, 256);  // W / relation gradient partials
   w += 2 * align_up(3 * b * 4, 256);               // sorted ids, row order
   return w;
@@ -535,6 +535,7 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   float* GA = cv.take<float>((size_t)3 * B * k);
   float* GR = cv.take<float>((size_t)B * k);
   float* DX = cv.take<float>((size_t)3 * B * d);
+  float* XS = cv.take<float>((size_t)3 * B * d);
   float* part = cv.take<float>((size_t)n_part * ((size_t)d * k + k));
   int32_t* sorted_ids = cv.take<int32_t>((size_t)3 * B);
   int32_t* row_order = cv.take<int32_t>((size_t)3 * B);
@@ -548,7 +549,7 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   const unsigned sb = (unsigned)((B + 3) / 4);
   if (!want_grad) {
     hipLaunchKernelGGL(transr_sample_kernel<false>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
-                       pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX);
+                       pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
     KGAT_CHECK_LAUNCH("transr_sample");
     hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
                        (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss);
@@ -556,11 +557,11 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
     return KGAT_OK;
   }
   hipLaunchKernelGGL(transr_sample_kernel<true>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
-                     pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX);
+                     pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
   KGAT_CHECK_LAUNCH("transr_sample");
   hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part), dim3(256), 0, st, d, k, n_rel,
-                     (const int32_t*)seg, (const int32_t*)order, h, pos_t, neg_t, ent, (const float*)GA,
-                     (const float*)GR, (const int32_t*)chunk_ptr, (const int2*)chunks, part);
+                     (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
+                     (const int32_t*)chunk_ptr, (const int2*)chunks, part);
   KGAT_CHECK_LAUNCH("transr_wgrad_partial");
   hipLaunchKernelGGL(transr_reduce_kernel, dim3((unsigned)n_rel + 1), dim3(256), 0, st, B, d, k, n_rel,
                      (const int32_t*)chunk_ptr, (const float*)part, (const float*)losses, grad_W, grad_rel, loss);
