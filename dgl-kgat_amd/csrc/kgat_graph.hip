@@ -243,16 +243,18 @@ __global__ void invert_perm_kernel(int64_t n, const int32_t* __restrict__ perm,
 }
 
 // offsets[v] = first sorted position whose key is >= v, for v in [0, n_keys]; keys sorted.
-// Thread p owns the boundary between sorted positions p-1 and p.
+// One thread per v, binary search: the cost does not depend on how the keys are distributed (a
+// destination shard has no edges for most rows - a thread per boundary would walk those gaps).
 __global__ void offsets_from_sorted_kernel(int64_t n, const int32_t* __restrict__ keys,
                                            int32_t n_keys, int32_t* __restrict__ offsets) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > n) return;
-  int32_t prev = (p == 0) ? -1 : keys[p - 1];
-  int32_t cur = (p == n) ? n_keys : keys[p];
-  if (cur > n_keys) cur = n_keys;
-  if (prev > n_keys) prev = n_keys;
-  for (int32_t v = prev + 1; v <= cur; ++v) offsets[v] = (int32_t)p;
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > n_keys) return;
+  int64_t lo = 0, hi = n;  // first p in [0, n] with keys[p] >= v
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (int32_t)v) lo = mid + 1; else hi = mid;
+  }
+  offsets[v] = (int32_t)lo;
 }
 
 __global__ void relation_key_kernel(int64_t n, int n_rel, const int32_t* __restrict__ etype,
@@ -422,7 +424,7 @@ int kgat_csr_from_coo(int64_t n_nodes, int64_t n_edges, const int32_t* src, cons
       }
     }
   }
-  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_nodes + 1, 256)), dim3(256), 0,
                      st, n_edges, sorted, (int32_t)n_nodes, indptr);
   KGAT_CHECK_LAUNCH("csr offsets");
   return KGAT_OK;
@@ -460,7 +462,7 @@ int kgat_group_by_relation(int64_t n_edges, int n_rel, const int32_t* etype, int
     if (rc != KGAT_OK) return rc;
   }
   // offs[v] for v in [0, n_rel+1]; rel_ptr is its first n_rel+1 entries
-  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(offsets_from_sorted_kernel, dim3(blocks_for(n_rel + 2, 256)), dim3(256), 0,
                      st, n_edges, sorted, (int32_t)(n_rel + 1), offs);
   KGAT_CHECK_LAUNCH("relation offsets");
   hipError_t e = hipMemcpyAsync(rel_ptr, offs, sizeof(int32_t) * ((size_t)n_rel + 1),
