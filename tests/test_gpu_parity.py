@@ -668,6 +668,36 @@ def test_full_size_attention_forms(K, dev):
         assert float((sums[deg] - 1).abs().max()) < 1e-4 and torch.all(sums[~deg] == 0), form
 
 
+def test_attention_forms_degenerate_graphs(K, dev):
+    """Every attention form end to end (logits + softmax + propagation) on graphs where a structure
+    is empty or trivial: no scored relation at all, a single edge, no edges, one hub group."""
+    from dgl_kgat_amd import synth
+    rng = np.random.default_rng(0)
+    cases = [("all unscored", 50, np.stack([rng.integers(0, 50, 300), np.full(300, 7), rng.integers(0, 50, 300)], 1)),
+             ("one edge", 5, np.array([[1, 0, 2]])),
+             ("no edges", 5, np.zeros((0, 3), np.int64)),
+             ("one hub group", 40, np.stack([np.full(5000, 3), np.zeros(5000, np.int64), rng.integers(0, 40, 5000)], 1))]
+    for name, n, trip in cases:
+        trip = trip.astype(np.int32)
+        g = synth.build_graph(n, trip, dev)
+        torch.manual_seed(0)
+        m = K.KGATPropagation(n, 3, 16, 16, 2, 16, dropout=0.0).to(dev)
+        ref = None
+        for form in ("one", "split", "folded", "fused", "auto"):
+            with torch.no_grad():
+                a = g.kgat_attention(m.entity_embed.weight, m.W_R, m.relation_embed.weight, algo=form)
+                g.edata["w"] = a
+                out = m.gnn(g)
+            assert a.shape == (len(trip), 1) and torch.isfinite(out).all(), (name, form)
+            sums = torch.zeros(n, device=dev)
+            if len(trip):
+                sums.index_add_(0, torch.as_tensor(trip[:, 0].astype(np.int64), device=dev), a.reshape(-1))
+            assert bool((((sums - 1).abs() < 1e-5) | (sums == 0)).all()), (name, form)
+            if ref is None:
+                ref = a
+            assert float((a - ref).abs().max()) < 1e-6 if len(trip) else True, (name, form)
+
+
 def test_training_harness_end_to_end(K, dev):
     """examples/train_kgat.py: reference-format files -> CKGDataset -> KG phase / attention refresh /
     CF phase / recall@20 + ndcg@20, the epoch structure of kgat.py:114-196, on the kernels."""
