@@ -77,11 +77,17 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
   if (t_begin >= t_end) return;
 
-  float wreg[KS][KT];
+  // W2's fragments live in registers for the whole launch - except at 128 x 128, where they would
+  // need 256 VGPRs: there every MFMA takes its fragment from the LDS copy (one conflict-free
+  // ds_read_b32 each)
+  constexpr bool W_IN_LDS = KS * KT > 128;
+  float wreg[W_IN_LDS ? 1 : KS][W_IN_LDS ? 1 : KT];
+  if (!W_IN_LDS) {
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-    for (int c = 0; c < KT; ++c) wreg[s][c] = s_w[(s * KT + c) * kWave + lane];
+      for (int c = 0; c < KT; ++c) wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c] = s_w[(s * KT + c) * kWave + lane];
+  }
 
   auto load_a = [&](int32_t t, float (&a)[KS]) {
     int32_t ra = (t << 4) + i;
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < KT; ++c)
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][c], a[s], acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+            W_IN_LDS ? s_w[(s * KT + c) * kWave + lane] : wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c], a[s], acc[c], 0, 0, 0);
     const int32_t row = row0 + i;
     float ss = 0.f;
 #pragma unroll
@@ -287,7 +294,7 @@ int kgat_l2_normalize_rows_f32(int64_t n_rows, int d, const float* x, float* out
 
 int kgat_bi_interaction_supported(int d_in, int d_out) {
   auto ok = [](int d) { return d == 16 || d == 32 || d == 64 || d == 128; };
-  return ok(d_in) && ok(d_out) && (d_in / 4) * (d_out / 16) <= 128;
+  return ok(d_in) && ok(d_out);
 }
 
 static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, const float* HN, const float* W2,
@@ -299,7 +306,7 @@ static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, cons
   KGAT_BI_CASE(16, 16) KGAT_BI_CASE(16, 32) KGAT_BI_CASE(16, 64) KGAT_BI_CASE(16, 128)
   KGAT_BI_CASE(32, 16) KGAT_BI_CASE(32, 32) KGAT_BI_CASE(32, 64) KGAT_BI_CASE(32, 128)
   KGAT_BI_CASE(64, 16) KGAT_BI_CASE(64, 32) KGAT_BI_CASE(64, 64) KGAT_BI_CASE(64, 128)
-  KGAT_BI_CASE(128, 16) KGAT_BI_CASE(128, 32) KGAT_BI_CASE(128, 64)
+  KGAT_BI_CASE(128, 16) KGAT_BI_CASE(128, 32) KGAT_BI_CASE(128, 64) KGAT_BI_CASE(128, 128)
 #undef KGAT_BI_CASE
   set_error("bi_interaction: unsupported widths %d -> %d", d_in, d_out);
   return KGAT_E_UNSUPPORTED;

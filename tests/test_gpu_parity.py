@@ -488,7 +488,7 @@ def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
     assert "att_w" not in graph.edata and "h_neighbor" not in graph.ndata  # local_var did not leak
 
 
-@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (16, 16), (128, 64), (16, 128)])
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (16, 16), (128, 64), (16, 128), (128, 128)])
 def test_bi_interaction_vs_oracle(K, dev, d_in, d_out):
     from dgl_kgat_amd import ops
     rng = np.random.default_rng(d_in + d_out)
@@ -503,7 +503,7 @@ def test_bi_interaction_vs_oracle(K, dev, d_in, d_out):
         assert rel_err_inf(wide[:, 8:8 + d_out].cpu().numpy(), orc.l2_normalize(ref)) < 1e-5
         assert torch.all(wide[:, :8] == 9.0) and torch.all(wide[:, 8 + d_out:] == 9.0)
         assert np.all(np.isfinite(wide.cpu().numpy()))
-    assert not ops.bi_interaction_supported(128, 128) and not ops.bi_interaction_supported(8, 8)
+    assert ops.bi_interaction_supported(128, 128) and not ops.bi_interaction_supported(8, 8)
 
 
 def test_autograd_matches_oracle(K, dev):
@@ -780,7 +780,7 @@ def _train_graph_and_model(K, dev, d, hidden, p, seed=11):
     return g, m, n
 
 
-@pytest.mark.parametrize("d,hidden", [(64, 64), (32, 64), (16, 64)])
+@pytest.mark.parametrize("d,hidden", [(64, 64), (32, 64), (16, 64), (128, 128)])
 def test_gnn_train_fused_matches_unfused_autograd(K, dev, d, hidden):
     """The fused training stack (one autograd unit: kgat_bi_interaction_train_f32 /
     _bwd_pre_f32 / kgat_mul2_f32 + the SpMMs) against the operator-by-operator autograd path
