@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
         d = fmaf(a[u][v].z, b[u][v].z, d);
         d = fmaf(a[u][v].w, b[u][v].w, d);
       }
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
-      d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+      if (LPE >= 2) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+      if (LPE >= 4) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
       if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
       if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
       mine = li == s0 + u ? d : mine;
@@ -275,6 +275,77 @@ __global__ __launch_bounds__(256) void att_fold_tail_kernel(
     if (LOGITS_EID) logits[oe] = 0.f;
     if (logits_csr) logits_csr[op] = 0.f;
   }
+}
+
+// Folded head kernel for small widths without an MFMA tile shape (d, k <= 32, d and k independent;
+// BASELINE configs[0] runs d = k = 8): one THREAD per (head, relation) group, W_r (<= 4 KB) in LDS,
+// V[g] = W_r tanh(W_r^T e_h + e_r) in two register loops.  A workgroup owns a contiguous range of
+// groups and reloads W_r when its range crosses into the next relation.
+constexpr int kSmallMaxDim = 32;
+
+__global__ __launch_bounds__(256) void att_fold_head_small_kernel(
+    int d, int k, int n_rel, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ V_tab) {
+  __shared__ float s_w[kSmallMaxDim * kSmallMaxDim];
+  __shared__ float s_r[kSmallMaxDim];
+  const int32_t n_groups = gptr[n_rel];
+  const int32_t g_begin = (int32_t)((int64_t)n_groups * blockIdx.x / gridDim.x);
+  const int32_t g_end = (int32_t)((int64_t)n_groups * (blockIdx.x + 1) / gridDim.x);
+  int32_t g0 = g_begin;
+  while (g0 < g_end) {  // workgroup-uniform loop over relation segments
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (gptr[mid] <= g0) lo = mid; else hi = mid;
+    }
+    // (empty relations share their gptr value with the next one: take the last of them)
+    while (lo + 1 < n_rel && gptr[lo + 1] <= g0) ++lo;
+    const int r = lo;
+    const int32_t seg_end = gptr[r + 1] < g_end ? gptr[r + 1] : g_end;
+    __syncthreads();
+    for (int t = threadIdx.x; t < d * k; t += 256) s_w[t] = W_R[(size_t)r * d * k + t];
+    for (int t = threadIdx.x; t < k; t += 256) s_r[t] = rel[(size_t)r * k + t];
+    __syncthreads();
+    for (int32_t g = g0 + threadIdx.x; g < seg_end; g += 256) {
+      const float* eh = ent + (size_t)g_node[g] * d;
+      float x[kSmallMaxDim], tt[kSmallMaxDim];
+#pragma unroll
+      for (int i = 0; i < kSmallMaxDim; ++i) x[i] = i < d ? eh[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < kSmallMaxDim; ++j) {
+        float acc = 0.f;
+        if (j < k) {
+#pragma unroll
+          for (int i = 0; i < kSmallMaxDim; ++i)
+            if (i < d) acc = fmaf(x[i], s_w[i * k + j], acc);
+          acc = att_tanh<0>(acc + s_r[j]);
+        }
+        tt[j] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < kSmallMaxDim; ++i) {
+        if (i < d) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < kSmallMaxDim; ++j)
+            if (j < k) acc = fmaf(s_w[i * k + j], tt[j], acc);
+          V_tab[(size_t)g * d + i] = acc;
+        }
+      }
+    }
+    g0 = seg_end;
+  }
+}
+
+static int launch_att_fold_head_small(int d, int k, const AttArgs& a, int64_t n_groups) {
+  int64_t blocks = (n_groups + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(att_fold_head_small_kernel, dim3((unsigned)blocks), dim3(256), 0, a.st, d, k, a.n_rel, a.gptr,
+                     a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
+  KGAT_CHECK_LAUNCH("att_fold_head_small");
+  return KGAT_OK;
 }
 
 template <int D_>
@@ -400,8 +471,13 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   return launch_att_split_any(d, a);
 }
 
+static bool fold_small(int d, int k) {
+  return (d == 8 || d == 16 || d == 32) && k >= 1 && k <= kSmallMaxDim && !(d == k && d >= 16);
+}
+
 int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel) {
-  return d == k && (d == 16 || d == 32 || d == 64 || d == 128) && n_rel > 0 && n_rel <= kAttMaxRelLds &&
+  const bool mfma = d == k && (d == 16 || d == 32 || d == 64 || d == 128);
+  return (mfma || fold_small(d, k)) && n_rel > 0 && n_rel <= kAttMaxRelLds &&
          (unsigned long long)n_nodes * (unsigned long long)d * 4ull < (1ull << 32);
 }
 
@@ -415,7 +491,7 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
                  "att_score_folded: bad size");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_folded_supported(n_nodes, d, k, n_rel)) {
-    set_error("att_score_folded: needs d == k in {16,32,64,128}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+    set_error("att_score_folded: needs d == k in {16,32,64,128} or d in {8,16,32} with k <= 32, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
               kAttMaxRelLds, d, k, n_rel);
     return KGAT_E_UNSUPPORTED;
   }
@@ -434,10 +510,11 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
   a.n_edges = n_edges;
   a.gid = gid; a.gptr = gptr; a.g_node = g_node; a.G_tab = V_tab;
   if (n_groups > 0) {
-    const int rc = launch_att_fold_head_any(d, a);
+    const int rc = fold_small(d, k) ? launch_att_fold_head_small(d, k, a, n_groups) : launch_att_fold_head_any(d, a);
     if (rc != KGAT_OK) return rc;
   }
   switch (d) {
+    case 8: return launch_att_fold_tail<8>(a);
     case 16: return launch_att_fold_tail<16>(a);
     case 32: return launch_att_fold_tail<32>(a);
     case 64: return launch_att_fold_tail<64>(a);

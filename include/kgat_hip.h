@@ -144,7 +144,8 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
  * (n_groups x d floats, caller scratch) and an edge costs one d-length dot product.  Same
  * inputs and outputs as kgat_att_score_split_f32; the contraction order differs from the
  * reference's, so the results agree with the other forms to fp32 rounding (~1e-6 relative to
- * sum_j |t_j T_j|), not bit for bit. */
+ * sum_j |t_j T_j|), not bit for bit.  Widths: d == k in {16,32,64,128} (MFMA), or d in {8,16,32}
+ * with any k <= 32 (one thread per group; BASELINE configs[0] has d = k = 8). */
 int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel);
 int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                               const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,

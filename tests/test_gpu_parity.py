@@ -426,6 +426,33 @@ def test_att_folded_d128(K, dev):
     assert rel_err_inf(fold.cpu().numpy(), full.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("d,k", [(8, 8), (16, 32), (32, 8), (8, 5), (16, 17)])
+def test_att_folded_small_widths(K, dev, d, k):
+    """Folded form without an MFMA tile shape (one thread per group): d in {8,16,32}, any k <= 32 -
+    BASELINE configs[0] is d = k = 8 - against the fp64 oracle and the generic per-edge kernel."""
+    from dgl_kgat_amd import ops
+    n, e, R = 600, 20000, 6
+    src, dst = random_graph(41, n, e, hub=3000, isolated_tail=10)
+    rng = np.random.default_rng(42)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)
+    et[et == 4] = 3  # an empty relation
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = ((rng.random((R, d, k)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, k)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    assert ops.att_score_folded_supported(n, d, k, R)
+    fold, fold_csr = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups,
+                                         tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True)
+    _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    assert rel_err_inf(fold.cpu().numpy(), ref) < 1e-5
+    assert np.all(fold.cpu().numpy()[(et < 0) | (et >= R)] == 0)
+    assert torch.equal(fold_csr, fold[eid.long()])
+    gen, _ = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent, dev), tf(W, dev), tf(rel, dev), algo="generic")
+    assert rel_err_inf(fold.cpu().numpy(), gen.cpu().numpy()) < 1e-5
+
+
 def test_att_folded_ragged_tail_positions(K, dev):
     """Folded form on edge counts that are not multiples of the 64-position wavefront chunk, with
     and without an unscored tail, and one relation only."""
