@@ -308,10 +308,17 @@ class DGLGraph:
     def is_readonly(self):
         return self._st.readonly
 
-    def edges(self, form="uv"):
+    def edges(self, form="uv", order=None):
+        """DGLGraph.edges / all_edges: endpoints (and ids) of all edges, in edge-id order
+        (order=None / 'eid') or sorted by (src, dst) (order='srcdst')."""
         src = torch.as_tensor(self._st._src)
         dst = torch.as_tensor(self._st._dst)
         eid = torch.arange(len(src))
+        if order == "srcdst":
+            perm = torch.as_tensor(np.lexsort((self._st._dst, self._st._src)))
+            src, dst, eid = src[perm], dst[perm], eid[perm]
+        elif order not in (None, "eid"):
+            raise DGLError("unknown edge order %r" % (order,))
         return {"uv": (src, dst), "eid": eid, "all": (src, dst, eid)}[form]
 
     all_edges = edges

@@ -287,3 +287,15 @@ def test_tall_linear_gradients_match_torch():
         x.grad = w.grad = None
         torch.nn.functional.linear(x, w).backward(g)
         assert torch.allclose(gx, x.grad, rtol=1e-12, atol=1e-12) and torch.allclose(gw, w.grad, rtol=1e-11, atol=1e-11)
+
+
+def test_all_edges_orders():
+    g = K.DGLGraph()
+    g.add_nodes(4)
+    g.add_edges([2, 0, 2, 1], [1, 3, 0, 1])
+    u, v = g.all_edges(order="eid")
+    assert u.tolist() == [2, 0, 2, 1] and v.tolist() == [1, 3, 0, 1]
+    u, v, e = g.all_edges(form="all", order="srcdst")
+    assert list(zip(u.tolist(), v.tolist())) == [(0, 3), (1, 1), (2, 0), (2, 1)] and e.tolist() == [1, 3, 2, 0]
+    with pytest.raises(Exception):
+        g.all_edges(order="random")
