@@ -241,9 +241,17 @@ def main():
             flops = ref_flops
             kern = "kgat_att_score_f32 (att_score_persistent_kernel)"
         tf_ = flops / (att_ms * 1e-3) / 1e12
+        att_traffic = None
+        try:  # committed PMC measurement of the identical launch (see the SpMM's `traffic` above)
+            pmc_att = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_att_traffic.json"))
+            if pmc_att and form == "fused" and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
+                with open(os.path.join(ROOT, "profiles", pmc_att[-1])) as f:
+                    att_traffic = int(json.load(f)["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            att_traffic = None
         roofline_att = {"bound": "mfma", "kernel": kern, "form": form, "head_groups": int(n_groups),
                         "achieved": round(tf_, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf_ / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                        "frac": round(tf_ / FP32_MFMA_PEAK_TF, 4), "traffic": att_traffic,
                         "avg_ms": round(att_ms, 4), "min_ms": round(att_min, 4),
                         "reference_flops_rate": round(ref_flops / (att_ms * 1e-3) / 1e12, 2),
                         "note": "achieved = FLOPs this form executes / time (both launches); reference_flops_rate = the "
