@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     // the four lanes (i, q = 0..3) of a row hold its 4 x KT column groups
     ss += __shfl_xor(ss, 16, kWave);
     ss += __shfl_xor(ss, 32, kWave);
-    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // one division per row; the 4 x KT values are scaled by it
     if (row < n_rows) {
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         if (norm_out) {
           float* dst = norm_out + (size_t)row * norm_stride + 16 * c + 4 * q;
           if (VEC_NORM) {
-            *reinterpret_cast<float4*>(dst) = make_float4(z0 / nrm, z1 / nrm, z2 / nrm, z3 / nrm);
+            *reinterpret_cast<float4*>(dst) = make_float4(z0 * inv, z1 * inv, z2 * inv, z3 * inv);
           } else {
-            dst[0] = z0 / nrm; dst[1] = z1 / nrm; dst[2] = z2 / nrm; dst[3] = z3 / nrm;
+            dst[0] = z0 * inv; dst[1] = z1 * inv; dst[2] = z2 * inv; dst[3] = z3 * inv;
           }
         }
       }
