@@ -133,6 +133,21 @@ def main():
         for a, t in res.items():
             print("spmm %-13s median %.4f ms  min %.4f ms -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), %.2f G edges/s"
                   % (a, np.median(t), t.min(), b / np.median(t) / 1e6, b / np.median(t) / 1e6 / 80, E / np.median(t) / 1e6))
+        # cold-cache variant: a 1 GiB write between launches evicts X, the indices and the
+        # weights from L2 and the 256 MiB Infinity Cache, so the launch starts from HBM
+        flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        cold = []
+        for _ in range(args.rounds):
+            flush.fill_(1.0)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            fns[algos[0]]()
+            eb.record()
+            cold.append((ea, eb))
+        torch.cuda.synchronize()
+        tc = np.array([x.elapsed_time(y) for x, y in cold])
+        print("spmm %-13s cold caches: median %.4f ms  min %.4f ms -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s)"
+              % (algos[0], np.median(tc), tc.min(), b / np.median(tc) / 1e6, b / np.median(tc) / 1e6 / 80))
     elif args.kernel == "train":
         # the CF step of kgat.py:146-168: gnn (all layers, full graph) -> BPR loss -> backward -> Adam
         import time
