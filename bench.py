@@ -195,8 +195,9 @@ def main():
     # measurement of the identical launch (same graph, D, kernel), or null when none matches.
     traffic = None
     try:
-        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_spmm_traffic.json"))
-        if pmc_files and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
+        suffix = {"amazon-book": "pmc_spmm_traffic.json", "power-law": "pmc_spmm_traffic_powerlaw.json"}.get(args.workload, "-")
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+        if pmc_files and world == 1 and args.scale == 1.0 and D == 64:
             with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as f:
                 traffic = int(json.load(f)["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
