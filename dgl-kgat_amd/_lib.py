@@ -2,6 +2,7 @@
 kernel of the path.  There is no fallback: if the library is missing, does not load, or
 lacks a declared symbol, importing the op layer fails loudly."""
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -29,6 +30,7 @@ _i64, _i32, _u32, _sz, _p = C.c_int64, C.c_int, C.c_uint, C.c_size_t, C.c_void_p
 SIGNATURES = {
     "kgat_version": (_i32, []),
     "kgat_last_error": (C.c_char_p, []),
+    "kgat_build_hash": (C.c_char_p, []),
     "kgat_csr_from_coo_workspace_bytes": (_sz, [_i64, _i64]),
     "kgat_csr_from_coo": (_i32, [_i64, _i64, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "kgat_group_by_relation_workspace_bytes": (_sz, [_i64, _i32]),
@@ -93,27 +95,79 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
+ABI_VERSION = 2
+
+
+def source_hash():
+    """sha256[:16] over everything the library is built from: csrc/*, the public header, the
+    compiler flags.  Embedded in the library at build time (kgat_build_hash) and compared at load
+    time - file times do not survive a copy to another machine, content does."""
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    with open(HEADER, "rb") as fh:
+        h.update(fh.read())
+    h.update(repr((BASE_FLAGS, sorted(SOURCES.items()))).encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """The hash embedded in the library on disk (read from the file, no dlopen), or None."""
+    try:
+        with open(SO_PATH, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    tag = b"kgat-src-hash:"
+    i = blob.find(tag)
+    return blob[i + len(tag):i + len(tag) + 16].decode("ascii", "replace") if i >= 0 else None
+
+
 def needs_build():
-    if not os.path.exists(SO_PATH):
-        return True
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER, os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > os.path.getmtime(SO_PATH) for d in deps)
+    return built_hash() != source_hash()
+
+
+def _unit_hash(src, flags):
+    """Key of one object file: its source, every header it may include, its flags."""
+    h = hashlib.sha256()
+    for f in [src] + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(HEADER, "rb") as fh:
+        h.update(fh.read())
+    h.update(repr(flags).encode())
+    return h.hexdigest()
 
 
 def build(force=False):
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU): one
-    object per source (per-file flags), then one shared library."""
+    object per source (per-file flags; an object whose inputs did not change is kept), then one
+    shared library.  The source hash is compiled into kgat_graph.hip (kgat_build_hash)."""
     if not (force or needs_build()):
         return SO_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     procs, objs = [], []
+    tag = '-DKGAT_BUILD_HASH="kgat-src-hash:%s"' % source_hash()
     for src, extra in SOURCES.items():
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        procs.append(subprocess.Popen([_hipcc()] + BASE_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]))
-    for p in procs:
+        flags = BASE_FLAGS + extra + ([tag] if src == "kgat_graph.hip" else [])
+        key = _unit_hash(src, flags)
+        try:
+            with open(obj + ".key") as fh:
+                fresh = os.path.exists(obj) and fh.read() == key
+        except OSError:
+            fresh = False
+        if fresh and not force:
+            continue
+        procs.append((subprocess.Popen([_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]), obj, key))
+    for p, obj, key in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, p.args)
+        with open(obj + ".key", "w") as fh:
+            fh.write(key)
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs)
     return SO_PATH
 
@@ -121,20 +175,21 @@ def build(force=False):
 def load():
     """dlopen libkgat_hip.so and bind every declared symbol.  `import torch` must have
     happened first so that libamdhip64 resolves to the runtime torch already loaded (one HIP
-    runtime per process - streams and pointers are shared with torch)."""
+    runtime per process - streams and pointers are shared with torch).  A library that is
+    missing or was built from other sources than the ones beside it is rebuilt (hipcc
+    cross-compiles); if that fails, loading fails - there is no fallback."""
     global _lib
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  (loads torch's libamdhip64.so first)
-    if not os.path.exists(SO_PATH):
-        try:  # a source checkout without the built library: compile it (hipcc cross-compiles)
+    if needs_build():
+        try:
             build()
-        except (OSError, subprocess.CalledProcessError):
-            pass
-    if not os.path.exists(SO_PATH):
-        raise KGATLibraryError(
-            "libkgat_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
-            "g.build()'`; there is no CPU or PyTorch fallback for this path." % SO_PATH)
+        except (OSError, subprocess.CalledProcessError) as e:
+            raise KGATLibraryError(
+                "libkgat_hip.so (%s) is %s and rebuilding it failed (%s). Run `python -c 'import "
+                "__graft_entry__ as g; g.build()'`; there is no CPU or PyTorch fallback for this path."
+                % (SO_PATH, "missing" if not os.path.exists(SO_PATH) else "stale (built from other sources)", e)) from e
     try:
         lib = C.CDLL(SO_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:
@@ -145,8 +200,12 @@ def load():
         except AttributeError as e:
             raise KGATLibraryError("libkgat_hip.so lacks symbol %s" % name) from e
         fn.restype, fn.argtypes = res, args
-    if lib.kgat_version() != 1:
-        raise KGATLibraryError("libkgat_hip.so ABI version %d != 1" % lib.kgat_version())
+    if lib.kgat_version() != ABI_VERSION:
+        raise KGATLibraryError("libkgat_hip.so ABI version %d != %d" % (lib.kgat_version(), ABI_VERSION))
+    got = lib.kgat_build_hash().decode()
+    if got != "kgat-src-hash:" + source_hash():
+        raise KGATLibraryError("libkgat_hip.so was built from other sources (%s) than the ones beside it (%s)"
+                               % (got, source_hash()))
     _lib = lib
     return lib
 

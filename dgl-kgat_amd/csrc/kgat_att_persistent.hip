@@ -196,11 +196,7 @@ static int launch_att_persistent(const AttArgs& a) {
   // one resident workgroup per CU slot the kernel's register budget admits: the tile ranges
   // are split evenly over exactly the wavefronts that run concurrently
   static int blocks_per_cu = 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cu_count();
   if (blocks_per_cu == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_score_persistent_kernel<D_, ACC_TANH>,
@@ -446,11 +442,7 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
 template <int D_, int MODE, bool LOGITS_EID>
 static int launch_att_split(const AttArgs& a, const int32_t* seg_ptr, const int32_t* row_idx) {
   static int blocks_per_cu = 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cu_count();
   if (blocks_per_cu == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_split_kernel<D_, MODE, LOGITS_EID>, kAttThreads,
@@ -644,11 +636,7 @@ __global__ __launch_bounds__(kAttThreads) void att_fold_head_kernel(
 template <int D_>
 static int launch_att_fold_head(const AttArgs& a) {
   static int blocks_per_cu = 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cu_count();
   if (blocks_per_cu == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, att_fold_head_kernel<D_>, kAttThreads, 0) != hipSuccess ||
@@ -811,11 +799,7 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
 
 template <int D_>
 static int launch_att_fold_head_lds(const AttArgs& a) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cu_count();
   hipLaunchKernelGGL((att_fold_head_lds_kernel<D_>), dim3((unsigned)cus), dim3(kFoldLdsThreads), 0, a.st, a.n_rel,
                      a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
   KGAT_CHECK_LAUNCH("att_fold_head_lds");
@@ -1065,11 +1049,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
 
 template <int D_>
 static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cu_count();
   if (a.logits)
     hipLaunchKernelGGL((att_fold_fused_kernel<D_, true>), dim3((unsigned)cus), dim3(kFusedThreads), 0, a.st, a.n_rel,
                        a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
@@ -1092,12 +1072,10 @@ int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, 
 }
 
 int launch_att_fold_head_any(int d, const AttArgs& a) {
-  // A/B switch for measurements: the LDS-resident-W kernel at d = 64 (default: W_r in registers)
-  static const bool lds64 = getenv("KGAT_FOLD_HEAD_LDS") != nullptr;
   switch (d) {
     case 16: return launch_att_fold_head<16>(a);
     case 32: return launch_att_fold_head<32>(a);
-    case 64: return lds64 ? launch_att_fold_head_lds<64>(a) : launch_att_fold_head<64>(a);
+    case 64: return launch_att_fold_head<64>(a);
     case 128: return launch_att_fold_head_lds<128>(a);
     default: return KGAT_E_UNSUPPORTED;
   }

@@ -29,6 +29,18 @@ struct Carver {
   }
 };
 
+// Compute units of the current device; the attribute query is made once per device ordinal.
+inline int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int v = 0;
+    cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cached[dev];
+}
+
 // Device-side primitives implemented in kgat_graph.hip, reused by other translation units.
 size_t scan_workspace_elems(int64_t n);
 // In-place exclusive scan of int32 data[n]; ws has scan_workspace_elems(n) int32.

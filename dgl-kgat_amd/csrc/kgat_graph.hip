@@ -393,6 +393,11 @@ int kgat_version(void) { return KGAT_ABI_VERSION; }
 
 const char* kgat_last_error(void) { return kgat::g_err; }
 
+#ifndef KGAT_BUILD_HASH
+#define KGAT_BUILD_HASH "unhashed"
+#endif
+const char* kgat_build_hash(void) { return KGAT_BUILD_HASH; }
+
 size_t kgat_csr_from_coo_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
   (void)n_nodes;
   return radix_sort_workspace_bytes(n_edges);

@@ -54,6 +54,7 @@ class Frame(MutableMapping):
         self._n = num_rows_fn
         self._what = what
         self._cols = dict(cols) if cols else {}
+        self._owned = set()  # columns this frame allocated itself (no other view can alias them)
 
     def __getitem__(self, key):
         return self._cols[key]
@@ -66,9 +67,11 @@ class Frame(MutableMapping):
                            "instead." % (self._what, self._what,
                                          val.shape[0] if val.dim() else 0, self._n()))
         self._cols[key] = val
+        self._owned.discard(key)
 
     def __delitem__(self, key):
         del self._cols[key]
+        self._owned.discard(key)
 
     def __iter__(self):
         return iter(self._cols)
@@ -167,23 +170,25 @@ class _Structure:
             c["order"] = ops.row_order_by_degree(self.csr(device).indptr)
         return c["order"]
 
-    def rel_groups(self, etype, n_rel, k=None):
+    def rel_groups(self, etype, n_rel, device=None):
         """Edges grouped by relation and, inside a relation, sorted by destination (the CSR-ordered
         edge list grouped stably by relation, kgat_group_by_relation), with the grouped endpoint
         arrays, the CSR position of every grouped position, and the (head, relation) groups the
-        split attention kernels share projections over (kgat_head_groups)."""
-        c = self._cache(etype.device)
-        key = ("rel", etype.data_ptr(), etype._version, int(n_rel))
+        split attention kernels share projections over (kgat_head_groups).  Cached per device on
+        the identity + version of the `etype` tensor handed in (kept alive by the cache, so its
+        identity cannot be recycled); a CPU-resident `etype` is copied to the device once."""
+        dev = torch.device(device) if device is not None else etype.device
+        c = self._cache(dev)
         hit = c.get("rel_groups")
-        if hit is None or hit[0] != key:
-            dev = etype.device
+        if hit is None or hit[2] is not etype or hit[0] != (etype._version, int(n_rel)):
             csr = self.csr(dev)
-            et32 = (etype if etype.dtype == torch.int32 else etype.to(torch.int32)).contiguous()
+            et32 = etype.to(device=dev, dtype=torch.int32).contiguous()
             rel_ptr, idx = ops.group_by_relation(ops.gather(csr.eid, et32), int(n_rel))
             dst_g = ops.gather(idx, csr.row_of)
             gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
-            hit = (key, RelGroups(rel_ptr, ops.gather(idx, csr.eid), ops.gather(idx, csr.col), dst_g, idx,
-                                  gid, gptr, g_node, n_groups, {}), etype)
+            hit = ((etype._version, int(n_rel)),
+                   RelGroups(rel_ptr, ops.gather(idx, csr.eid), ops.gather(idx, csr.col), dst_g, idx,
+                             gid, gptr, g_node, n_groups, {}), etype)
             c["rel_groups"] = hit
         return hit[1]
 
@@ -396,6 +401,13 @@ class DGLGraph:
             if eids is None:
                 self._edge_frame[key] = val
                 continue
+            tracked = torch.is_grad_enabled() and val.requires_grad
+            if key in self._edge_frame._owned and not tracked:
+                # the column was zero-initialised by an earlier partial write through this very
+                # view (the per-relation loop of models.py:149-152): nothing else can see it, so
+                # the next relation's slice goes in place instead of through an E-sized copy
+                self._edge_frame[key].index_copy_(0, eids.to(val.device), val)
+                continue
             if key in self._edge_frame:
                 col = self._edge_frame[key].clone()
             else:
@@ -403,6 +415,8 @@ class DGLGraph:
                                   device=val.device)
             col.index_copy_(0, eids.to(val.device), val)
             self._edge_frame[key] = col
+            if not tracked:
+                self._edge_frame._owned.add(key)
 
     # ---- the aggregation (models.py:63)
     def update_all(self, message_func, reduce_func, apply_node_func=None):
@@ -426,6 +440,53 @@ class DGLGraph:
         if apply_node_func is not None:
             raise NotImplementedError("apply_node_func is outside the KGAT path")
 
+    def _pick_attention_form(self, groups, n_rel, d, k, race_run=None):
+        """Attention form as a function of the graph's statistics only (so that every process, and
+        every rank of a sharded job, takes the same arithmetic path and produces the same bits).
+        Head-group forms when the groups actually share work (measured on MI355X, d = 64: folded
+        ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges, one-kernel 0.153 ms per 1e6 edges -> the
+        group forms win below ~0.74 groups per edge).  Between the two folded forms: the fused
+        kernel recomputes a 16-group block's vectors once per `cap` positions, so it wins while its
+        tile count stays near the minimum ceil(n_groups / 16) (amazon-book-shaped CKG: 1.16x,
+        fused 0.25 vs 0.29 ms) and loses when large groups inflate it (last-fm-shaped: ~4x, folded
+        0.155 vs 0.195 ms); the threshold is 2x.  ``KGAT_ATT_FORM=race`` times the two instead
+        (opt-in: a wall-clock race is not reproducible across processes)."""
+        st = self._st
+        shares = 4 * groups.n_groups <= 3 * st.n_edges
+        fused_ok = shares and ops.att_score_fused_supported(st.n_nodes, d, k, n_rel)
+        folded_ok = shares and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel)
+        if fused_ok and folded_ok:
+            if race_run is not None:
+                best = None
+                for f in ("fused", "folded"):
+                    race_run(f)
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    for _ in range(3):
+                        race_run(f)
+                    t1.record()
+                    t1.synchronize()
+                    ms = t0.elapsed_time(t1)
+                    if best is None or ms < best[0]:
+                        best = (ms, f)
+                form = best[1]
+            else:
+                tiles = groups.g_tab.get("tiles")
+                if tiles is None:
+                    tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr,
+                                                                   groups.n_groups)
+                n_tiles = int(tiles[1][-1])
+                form = "fused" if n_tiles <= 2 * ((groups.n_groups + 15) // 16) else "folded"
+            groups.g_tab.pop("tiles" if form == "folded" else d, None)  # the other form's scratch
+            return form
+        if fused_ok:
+            return "fused"
+        if folded_ok:
+            return "folded"
+        if 2 * groups.n_groups <= st.n_edges and ops.att_score_split_supported(st.n_nodes, d, k, n_rel):
+            return "split"
+        return "one"
+
     # ---- fused fast path (not part of the DGL surface)
     def kgat_attention(self, ent, W_R, rel, etype=None, algo="auto"):
         """compute_attention (models.py:146-154) in two launches: relation-grouped attention
@@ -437,7 +498,7 @@ class DGLGraph:
         st = self._st
         dev = ent.device
         csr = st.csr(dev)
-        groups = st.rel_groups(etype.to(dev), W_R.shape[0])
+        groups = st.rel_groups(etype, W_R.shape[0], dev)
         n_rel, d, k = W_R.shape
         ent_c, W_c, rel_c = ent.detach().contiguous(), W_R.detach().contiguous(), rel.detach().contiguous()
         # head-group forms (work shared by the edges of a (head, relation) group) when the groups
@@ -468,37 +529,11 @@ class DGLGraph:
                                  ent_c, W_c, rel_c, pos_g=groups.pos_g, algo="auto" if form == "one" else form)[1]
 
         form = os.environ.get("KGAT_ATT_FORM", "auto") if algo == "auto" else algo
-        if form == "auto":
+        race = form == "race"
+        if form in ("auto", "race"):
             form = groups.g_tab.get(("form", d, k))
         if form is None:
-            # measured on MI355X, d = 64: folded ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges,
-            # one-kernel 0.153 ms per 1e6 edges -> the group forms win below ~0.74 groups per edge
-            shares = 4 * groups.n_groups <= 3 * st.n_edges
-            cands = [f for f, ok in (("fused", ops.att_score_fused_supported(st.n_nodes, d, k, n_rel)),
-                                     ("folded", ops.att_score_folded_supported(st.n_nodes, d, k, n_rel))) if ok and shares]
-            if len(cands) > 1:
-                # which of the two wins depends on the group-size distribution (fused: amazon-book-shaped
-                # CKG; folded: last-fm-shaped): time both once per graph and keep the faster
-                best = None
-                for f in cands:
-                    run(f)
-                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    t0.record()
-                    for _ in range(3):
-                        run(f)
-                    t1.record()
-                    t1.synchronize()
-                    ms = t0.elapsed_time(t1)
-                    if best is None or ms < best[0]:
-                        best = (ms, f)
-                form = best[1]
-                groups.g_tab.pop("tiles" if form == "folded" else d, None)  # the loser's scratch
-            elif cands:
-                form = cands[0]
-            elif 2 * groups.n_groups <= st.n_edges and ops.att_score_split_supported(st.n_nodes, d, k, n_rel):
-                form = "split"
-            else:
-                form = "one"
+            form = self._pick_attention_form(groups, n_rel, d, k, run if race else None)
             groups.g_tab[("form", d, k)] = form
         logits_csr = run(form)
         if form not in ("fused", "folded", "split"):

@@ -72,6 +72,12 @@ class KGATConv(nn.Module):
         if fused is None:
             fused = not (torch.is_grad_enabled() and nfeat.requires_grad)
         if part is not None:
+            if torch.is_grad_enabled() and (nfeat.requires_grad or self.res_fc_2.weight.requires_grad):
+                # the shard's aggregation runs on detached rows and the exchange is an in-place
+                # collective autograd does not see: gradients would be silently wrong
+                raise NotImplementedError(
+                    "KGATConv on a destination-range shard is forward-only (SURVEY 8e: the reference trains on one "
+                    "device); run it under torch.no_grad() or train on the unsharded graph")
             out = part.propagate(g, nfeat, self.res_fc_2.weight)
         elif fused:
             # h * h_N formed in the SpMM epilogue (models.py:63 + the th.mul of :66)
@@ -162,12 +168,14 @@ class KGATPropagation(nn.Module):
         """entity_embed(g.ndata['id']) (models.py:159); the reference's ids are arange(N)
         (dataset.py:118), in which case the lookup is the table itself."""
         ids = g.ndata["id"]
-        key = (ids.data_ptr(), ids._version, ids.numel())
-        if getattr(self, "_ids_key", None) != key:
-            self._ids_key = key
-            self._ids_identity = (ids.numel() == self._n_entities and
-                                  bool(torch.equal(ids, torch.arange(ids.numel(), device=ids.device, dtype=ids.dtype))))
-        return self.entity_embed.weight if self._ids_identity else self.entity_embed(ids)
+        # cached on the tensor object itself (held here, so its identity cannot be recycled by the
+        # allocator for another graph's ids) and its version counter
+        hit = getattr(self, "_ids_hit", None)
+        if hit is None or hit[0] is not ids or hit[1] != ids._version:
+            same = (ids.numel() == self._n_entities and
+                    bool(torch.equal(ids, torch.arange(ids.numel(), device=ids.device, dtype=ids.dtype))))
+            hit = self._ids_hit = (ids, ids._version, same)
+        return self.entity_embed.weight if hit[2] else self.entity_embed(ids)
 
     def _can_fuse_readout(self):
         from . import ops

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 1
+#define KGAT_ABI_VERSION 2
 
 enum {
   KGAT_OK = 0,
@@ -65,6 +65,10 @@ typedef void* kgat_stream_t; /* hipStream_t */
 
 int kgat_version(void);
 const char* kgat_last_error(void);
+/* sha256[:16] of the sources (csrc/ + this header + compiler flags) the library was built from,
+ * as the build recipe passed it in; the loader refuses a library whose hash is not the hash of
+ * the sources beside it (a stale build would otherwise be called with other argument lists). */
+const char* kgat_build_hash(void);
 
 /* ---------------------------------------------------------------- graph structure (G0)
  * Replaces DGL's COO -> in-CSR conversion that runs on the first kernel call on a graph

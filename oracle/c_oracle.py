@@ -85,6 +85,18 @@ def att_score(ent, W_R, rel, src, dst, etype):
     return out
 
 
+def att_score_fast(ent, W_R, rel, src, dst, etype):
+    """kgat_oracle_att_score_fast_f32: the vectorised twin of att_score (bench.py's timed leg)."""
+    ent, W_R, rel = _f32(ent), _f32(W_R), _f32(rel)
+    src, dst, etype = _i32(src), _i32(dst), _i32(etype)
+    e = src.shape[0]
+    out = np.zeros(e, np.float32)
+    lib().kgat_oracle_att_score_fast_f32(C.c_int64(e), C.c_int(ent.shape[1]), C.c_int(W_R.shape[2]),
+                                         C.c_int(W_R.shape[0]), _p(src), _p(dst), _p(etype), _p(ent),
+                                         _p(W_R), _p(rel), _p(out))
+    return out
+
+
 def edge_softmax(n, indptr, eid, logits):
     logits = _f32(logits).reshape(-1)
     out = np.zeros_like(logits)

@@ -91,3 +91,27 @@ def sum_err(x, y, abs_sum):
         return float("inf")
     nz = a > 0
     return float(np.max(np.abs(x - y)[nz] / a[nz])) if nz.any() else 0.0
+
+
+def parity_8c(name, gpu, c32, ref64, tol=1e-4, factor=2.0):
+    """The SURVEY 8c metric, measured instead of argued: ``rel_err`` (elementwise, floor 1e-3 of
+    the tensor's max) of the device result AND of the C/OpenMP fp32 oracle, both against the fp64
+    oracle.  The device passes when it is within `tol`, or no further from fp64 than `factor` x what
+    a CPU fp32 forward shows under the same metric ("matches the DGL-CPU forward": fp32 sums of
+    thousands of terms cannot meet an elementwise 1e-4 on elements that nearly cancel, on any
+    machine).  Prints both numbers; returns them."""
+    e_gpu, e_c = rel_err(gpu, ref64), rel_err(c32, ref64)
+    print("[8c] %-34s gpu %.3e   c-fp32 %.3e   (rel_err vs fp64; bar max(%.0e, %gx c-fp32))"
+          % (name, e_gpu, e_c, tol, factor))
+    assert e_gpu <= max(tol, factor * e_c), (name, e_gpu, e_c)
+    return e_gpu, e_c
+
+
+def blocks(x, widths):
+    """Column blocks of a Model.gnn output [h0 | n(h1) | n(h2) | ...]."""
+    out, o = [], 0
+    for w in widths:
+        out.append(x[:, o:o + w])
+        o += w
+    assert o == x.shape[1]
+    return out

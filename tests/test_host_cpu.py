@@ -25,7 +25,8 @@ def test_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libkgat_hip.so lacks %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kgat_version() == 1
+    assert lib.kgat_version() == 2 == _lib.ABI_VERSION
+    assert lib.kgat_build_hash().decode() == "kgat-src-hash:" + _lib.source_hash() and not _lib.needs_build()
     # argument validation happens before any device work: callable without a GPU
     assert lib.kgat_spmm_umule_sum_f32(-1, 0, 0, 0, 64, None, None, None, None, None, None, None, None, None,
                                        0, 0, 0, None) == -1
@@ -107,6 +108,19 @@ def test_filter_and_apply_edges_semantics():
     assert lv.edata["att_w"].reshape(-1).tolist() == [-1.0, 2.5, 0, 0, 2.5]
     with pytest.raises(K.DGLError):
         lv.apply_edges(lambda edges: {"x": torch.zeros(3)}, e1)
+    # partial writes go in place only into a column this view allocated itself: a column that came
+    # from the parent (or was assigned by the caller) is never written through
+    g.edata["keep"] = torch.ones(5, 1)
+    lv2 = g.local_var()
+    lv2.apply_edges(lambda edges: {"keep": torch.full((len(edges), 1), 7.0)}, torch.tensor([2]))
+    assert g.edata["keep"].reshape(-1).tolist() == [1, 1, 1, 1, 1] and lv2.edata["keep"].reshape(-1).tolist() == [1, 1, 7, 1, 1]
+    mine = torch.zeros(5, 1)
+    lv2.edata["att_w"] = mine
+    lv2.apply_edges(lambda edges: {"att_w": torch.full((len(edges), 1), 3.0)}, torch.tensor([1]))
+    assert mine.reshape(-1).tolist() == [0, 0, 0, 0, 0] and lv2.edata["att_w"].reshape(-1).tolist() == [0, 3, 0, 0, 0]
+    lv3 = lv2.local_var()  # a view of a view starts without owned columns
+    lv3.apply_edges(lambda edges: {"att_w": torch.full((len(edges), 1), 9.0)}, torch.tensor([0]))
+    assert lv2.edata["att_w"].reshape(-1).tolist() == [0, 3, 0, 0, 0] and lv3.edata["att_w"].reshape(-1).tolist() == [9, 3, 0, 0, 0]
 
 
 def test_sparse_ops_refuse_cpu_tensors():
@@ -178,6 +192,34 @@ def test_balanced_bounds_and_shards_cover_graph():
             assert torch.equal(sg.edata["w"], g.edata["w"][torch.as_tensor(keep)])
             seen.append(keep)
         assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(len(trip)))
+
+
+def test_shard_layer_refuses_autograd():
+    """A destination-range shard is forward-only: under autograd the layer raises instead of
+    returning a result whose gradients would silently miss the aggregation and the exchange."""
+    n, trip, R = synth.amazon_book_ckg(scale=0.002)
+    g = synth.build_graph(n, trip)
+    g.edata["w"] = torch.rand(len(trip), 1)
+    sg, _ = partition.shard_graph(g, 0, 2)
+    m = K.KGATPropagation(n, R, 16, 16, 1, 16, dropout=0.0)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        m.layers[0](sg, m.entity_embed.weight)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        m.gnn(sg)
+
+
+def test_identity_id_cache_is_keyed_on_the_tensor_object():
+    n = 40
+    m = K.KGATPropagation(n, 2, 8, 8, 1, 8, dropout=0.0)
+    g1, g2 = K.DGLGraph(), K.DGLGraph()
+    for g in (g1, g2):
+        g.add_nodes(n)
+    g1.ndata["id"] = torch.arange(n)
+    assert m._node_embeddings(g1) is m.entity_embed.weight
+    g2.ndata["id"] = torch.arange(n).flip(0)
+    assert torch.equal(m._node_embeddings(g2), m.entity_embed.weight.flip(0))
+    g1.ndata["id"][0] = 3  # in-place edit of a cached tensor: the version counter invalidates the hit
+    assert torch.equal(m._node_embeddings(g1)[0], m.entity_embed.weight[3])
 
 
 _WORKER = r"""
