@@ -121,19 +121,28 @@ def hbm_resident_spmm_leg(args, dev):
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
 
-    def launch():
-        ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True, workspace=ws)
+    def launch(mul_self=False):
+        ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=mul_self, workspace=ws)
     event_times(launch, 20)
     t = event_times(launch, args.hbm_launches)
+    t_epi = event_times(lambda: launch(True), max(args.hbm_launches // 5, 5))
+    # same-run calibration of this box's HBM: a 4 GiB device-to-device copy (torch's copy kernel)
+    a_ = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
+    b_ = torch.empty_like(a_)
+    t_copy = event_times(lambda: b_.copy_(a_), 10)
+    copy_gbs = 2 * a_.numel() * 4 / (float(np.median(t_copy)) * 1e-3) / 1e9
+    del a_, b_
     b = e * (4 * D + 8) + n * (4 * D + 4)
     med = float(np.median(t))
     ach = b / (med * 1e-3) / 1e9
     traffic, tfile = committed_traffic("pmc_spmm_traffic_powerlaw.json", ("kgat_spmm.hip", "kgat_common.h"))
     if (n, e) != (10_000_000, 200_000_000):
         traffic, tfile = None, None
-    return {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge2_kernel + spmm_finish_kernel), D=%d, h*h_N epilogue" % D,
-            "workload": "power-law CKG drawn on the device: N=%d E=%d, in-degree shifted Zipf(1.1) capped near 1e6 "
-                        "(max %d), sources uniform; X = %.2f GB" % (n, e, max_deg, n * D * 4 / 1e9),
+    return {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge2_kernel + spmm_finish_kernel), D=%d: "
+                                      "update_all(u_mul_e, sum) itself, no epilogue" % D,
+            "workload": "power-law CKG drawn on the device (BASELINE configs[4] on one GPU): N=%d E=%d, in-degree "
+                        "Zipf(1.1) with the hubs capped near 1e6 (max %d) and their excess re-drawn uniformly, sources "
+                        "uniform; X = %.2f GB" % (n, e, max_deg, n * D * 4 / 1e9),
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "frac_of_copy_ceiling_6290": round(ach / 6290.0, 4),
             "traffic": traffic, "traffic_source": tfile,
@@ -141,8 +150,15 @@ def hbm_resident_spmm_leg(args, dev):
             "avg_ms": round(float(t.mean()), 4), "launches": int(len(t)), "warm_launches": 20,
             "edges_per_s": round(e / (med * 1e-3), 1), "graph_build_s": round(build_s, 2),
             "cache_served": False,
+            "with_hmul_epilogue": {"median_ms": round(float(np.median(t_epi)), 4),
+                                   "frac": round(b / (float(np.median(t_epi)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "KGAT_SPMM_MUL_SELF (out[v] *= X[v], models.py:66): N*4D more bytes read than the "
+                                           "byte model counts"},
+            "same_run_device_copy_GBs": round(copy_gbs, 1),
             "note": "achieved = algorithmic bytes E(4D+8)+N(4D+4) / median launch time; 6.29 TB/s is the measured "
-                    "streaming-copy ceiling of this part (MI355X_MICROARCH.md), i.e. frac <= 0.786 for any kernel"}
+                    "streaming-copy ceiling of this part (MI355X_MICROARCH.md), i.e. frac <= 0.786 for any kernel; "
+                    "same_run_device_copy_GBs (read+write of a 4 GiB torch copy_, this box, this run) calibrates the "
+                    "box: HBM-bound kernels measured 10-12 % apart between boxes of this pool"}
 
 
 def make_workload(args):
@@ -305,6 +321,22 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
+    # informational: the same step with the edge-id-ordered copy of the attention written eagerly
+    # (the default hands back a lazy tensor whose values nothing on the path reads, lazy.py)
+    def step_eager():
+        with torch.no_grad():
+            a_ = g.kgat_attention(model.entity_embed.weight, model.W_R, model.relation_embed.weight, lazy=False)
+            g.edata["w"] = a_
+            return model.gnn(g)
+    step_eager()
+    sync()
+    t_e = time.perf_counter()
+    for _ in range(args.steps):
+        step_eager()
+    sync()
+    eager_ms = (time.perf_counter() - t_e) / args.steps * 1e3
+    out, a = step()  # leave the graph in the default (lazy) state for what follows
+
     # informational: the propagation layers alone (attention fixed, as in the 54 CF batches per
     # epoch of kgat.py:146-168 that reuse one attention refresh); not the headline value
     sync()
@@ -354,9 +386,9 @@ def main():
     # weights from L2 and the Infinity Cache, so the launch starts from HBM
     cold_ms = None
     if world == 1 and spmm_ms and "w" in g.edata:
-        st_, a_flat = g._st, g.edata["w"].detach().reshape(-1).contiguous()
+        st_ = g._st
         csr_ = st_.csr(dev)
-        w_csr_ = st_.weight_in_csr_order(a_flat)
+        w_csr_ = st_.csr_weights(g.edata["w"])
         x_ = model.entity_embed.weight.detach()
         if x_.shape[1] == D:
             flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
@@ -438,7 +470,10 @@ def main():
                                "edge_softmax + %dx(u_mul_e_sum + bi-interaction) + normalize/concat"
                                % (name, n, E, n_rel, args.layers, D, args.layers),
                    "partition": "none" if world == 1 else "dst-range x%d, all-reduce of layer outputs" % world,
-                   "edges_counted_per_step": args.layers * E},
+                   "edges_counted_per_step": args.layers * E,
+                   "edge_id_order_attention": "returned as a lazy tensor (values written on first read; the step's "
+                                              "update_all reads the CSR-ordered copy); eager variant: %.4f ms per step"
+                                              % eager_ms},
         "propagation_only": {"ms_per_pass": round(gnn_dt * 1e3, 4), "edges_per_s": round(args.layers * E / gnn_dt, 1),
                              "note": "3 propagation layers with the attention weights held fixed (rank-local clock)"},
         "roofline": roofline,

@@ -11,15 +11,6 @@ import torch
 from . import ops
 
 
-def _flat_weight(w, n_edges):
-    if w.dim() == 2 and w.shape[1] == 1:
-        return w.reshape(-1)
-    if w.dim() == 1:
-        return w
-    raise NotImplementedError("u_mul_e on the KGAT path takes an (E,1) or (E,) edge weight; got %s"
-                              % (tuple(w.shape),))
-
-
 class _UMulESum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, g, mul_self):
@@ -29,20 +20,19 @@ class _UMulESum(torch.autograd.Function):
         x2 = x2.contiguous()
         if x2.dtype != torch.float32:
             raise TypeError("node features must be float32, got %s" % x2.dtype)
-        w_flat = _flat_weight(w, st.n_edges).contiguous()
         csr = st.csr(dev)
-        w_csr = st.weight_in_csr_order(w_flat.detach())
+        w_csr = st.csr_weights(w)  # a pending lazy attention tensor is served from its CSR copy
         # (a destination-range shard is an ordinary graph holding only its local edges: rows it
         # does not own come out as zeros and the caller exchanges them, partition.py)
         out = ops.spmm(csr.indptr, csr.col, csr.row_of, x2.detach(), w_csr, mul_self=mul_self)
         ctx.g, ctx.mul_self, ctx.squeeze = g, mul_self, x.dim() == 1
         ctx.w_shape = w.shape
-        ctx.save_for_backward(x2, w_flat, out if mul_self else None)
+        ctx.save_for_backward(x2, w, out if mul_self else None)
         return out.squeeze(1) if x.dim() == 1 else out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x2, w_flat, _ = ctx.saved_tensors
+        x2, w, _ = ctx.saved_tensors
         st = ctx.g._st
         dev = grad_out.device
         if ctx.mul_self:
@@ -51,7 +41,7 @@ class _UMulESum(torch.autograd.Function):
         grad_x = grad_w = None
         if ctx.needs_input_grad[0]:
             rev = st.csr_rev(dev)
-            grad_x = ops.spmm(rev.indptr, rev.col, rev.row_of, go, st.weight_in_rev_order(w_flat.detach()))
+            grad_x = ops.spmm(rev.indptr, rev.col, rev.row_of, go, st.rev_weights(w))
             if ctx.squeeze:
                 grad_x = grad_x.squeeze(1)
         if ctx.needs_input_grad[1]:
@@ -81,7 +71,7 @@ class _EdgeSoftmax(torch.autograd.Function):
         if flat.dtype != torch.float32:
             raise TypeError("logits must be float32, got %s" % flat.dtype)
         csr = st.csr(flat.device)
-        _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, flat, want_out=False, want_csr=True)
+        _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, flat, want_out=False, want_csr=True)
         a = ops.gather(st.csr_pos(flat.device), a_csr)  # back to edge-id order
         st.remember_weight(a, a_csr)
         ctx.g = g
@@ -147,8 +137,8 @@ class _GNNTrain(torch.autograd.Function):
         dev = h0.device
         h = h0.detach().contiguous()
         csr = st.csr(dev)
-        w_flat = _flat_weight(g.edata["w"], st.n_edges).detach().contiguous()
-        w_csr = st.weight_in_csr_order(w_flat)
+        ew = g.edata["w"]
+        w_csr = st.csr_weights(ew)
         widths = [h.shape[1]] + [w.shape[0] for w in weights]
         out = torch.empty((h.shape[0], sum(widths)), dtype=torch.float32, device=dev)
         out[:, :widths[0]] = h
@@ -160,7 +150,7 @@ class _GNNTrain(torch.autograd.Function):
                                                norm_out=out[:, off:off + widths[li + 1]]))
             hns.append(hn)
             off += widths[li + 1]
-        ctx.g, ctx.slope, ctx.drop_p, ctx.seed, ctx.widths, ctx.w_flat = g, slope, drop_p, seed, widths, w_flat
+        ctx.g, ctx.slope, ctx.drop_p, ctx.seed, ctx.widths, ctx.ew = g, slope, drop_p, seed, widths, ew
         ctx.save_for_backward(*hs, *hns, *weights)
         return out
 
@@ -172,7 +162,7 @@ class _GNNTrain(torch.autograd.Function):
         st = ctx.g._st
         dev = grad_out.device
         rev = st.csr_rev(dev)
-        w_rev = st.weight_in_rev_order(ctx.w_flat)
+        w_rev = st.rev_weights(ctx.ew)
         grad_out = grad_out.contiguous()
         offs = [0]
         for wd in ctx.widths:

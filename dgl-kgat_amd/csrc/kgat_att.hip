@@ -530,6 +530,7 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                             const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
                              float* logits_csr, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
@@ -543,8 +544,11 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                  "att_score_fused: null pointer");
   KGAT_CHECK_ARG(logits || logits_csr, "att_score_fused: no output requested");
   KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_fused: logits_csr needs pos_g");
+  KGAT_CHECK_ARG((part_tptr == nullptr) == (n_parts == 0) && n_parts >= 0 && n_parts <= 65536,
+                 "att_score_fused: part_tptr and n_parts go together");
   AttArgs a;
-  a.grid = 0;
+  a.grid = (unsigned)n_parts;
+  a.part_tptr = part_tptr;
   a.st = as_stream(stream);
   a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;

@@ -97,6 +97,7 @@ struct AttArgs {
   unsigned long long table_bytes = 0;
   int64_t n_edges = 0;
   bool needs_memset = true;
+  const int32_t* part_tptr = nullptr;  // fused form: tile range per workgroup (grid = number of parts)
 };
 
 

@@ -819,16 +819,31 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
 // registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
 constexpr int kFusedThreads = 512;
 
+#ifdef KGAT_ATT_STAMPS
+// Diagnostic build only (-DKGAT_ATT_STAMPS, scripts/micro/att_stamps.py): start / end s_memtime of
+// every workgroup of the fused kernel.  Never compiled into the shipped library.
+__device__ unsigned long long* g_att_stamps = nullptr;
+#define KGAT_ATT_STAMP(k)                                                               \
+  do {                                                                                  \
+    if (g_att_stamps && threadIdx.x == 0)                                               \
+      g_att_stamps[(size_t)blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+#else
+#define KGAT_ATT_STAMP(k) do { } while (0)
+#endif
+
 template <int D_, bool LOGITS_EID>
 __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
     const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
     const int32_t* __restrict__ gid, const int32_t* __restrict__ src_g, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ pos_g, const float* __restrict__ ent, const float* __restrict__ W_R,
-    const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr) {
+    const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr,
+    const int32_t* __restrict__ part_tptr) {
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFusedThreads / kWave;
   constexpr int LPE = kFusedLanesPerEdge<D_>();    // lanes per edge in the edge phase
+  KGAT_ATT_STAMP(0);
   constexpr int VPL = D_ / (4 * LPE);             // float4 pieces of a row per lane
   constexpr int LDV = D_ + 4;
   static_assert(D_ <= 64, "one float4 per lane per row");
@@ -850,8 +865,10 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     }
   }
   const int32_t n_tiles = rel_tptr[n_rel];
-  const int32_t t_begin = (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
-  const int32_t t_end = (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  // the workgroup's contiguous tile range: cost balanced (kgat_fold_tile_parts) or equal counts
+  const int32_t t_begin = part_tptr ? part_tptr[blockIdx.x] : (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
+  const int32_t t_end = part_tptr ? part_tptr[blockIdx.x + 1]
+                                  : (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
   float* vrow = s_v[w];
 
   int32_t t = t_begin;
@@ -1045,22 +1062,32 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     }
     t = seg_end;
   }
+#ifdef KGAT_ATT_STAMPS
+  __syncthreads();
+  KGAT_ATT_STAMP(1);
+#endif
 }
 
 template <int D_>
 static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
-  const int cus = device_cu_count();
+  const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
   if (a.logits)
-    hipLaunchKernelGGL((att_fold_fused_kernel<D_, true>), dim3((unsigned)cus), dim3(kFusedThreads), 0, a.st, a.n_rel,
+    hipLaunchKernelGGL((att_fold_fused_kernel<D_, true>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
                        a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
-                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr);
+                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
   else
-    hipLaunchKernelGGL((att_fold_fused_kernel<D_, false>), dim3((unsigned)cus), dim3(kFusedThreads), 0, a.st, a.n_rel,
+    hipLaunchKernelGGL((att_fold_fused_kernel<D_, false>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
                        a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
-                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr);
+                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
   KGAT_CHECK_LAUNCH("att_fold_fused");
   return KGAT_OK;
 }
+
+#ifdef KGAT_ATT_STAMPS
+extern "C" int kgat_debug_set_att_stamps(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
   switch (d) {

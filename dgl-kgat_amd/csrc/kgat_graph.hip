@@ -223,17 +223,73 @@ int radix_sort_index(const int32_t* keys_in, int64_t n, int key_bits, int32_t* v
   return KGAT_OK;
 }
 
+// ---- cost-balanced split of the fused attention kernel's tiles over its workgroups
+// cost[t] = c_tile + (c_first * min(P, 64) + c_later * max(P - 64, 0)) / 64, P = positions of tile t
+__global__ void fold_tile_cost_kernel(int64_t t_max, int n_rel, const int32_t* __restrict__ rel_tptr,
+                                      const int4* __restrict__ tiles, int c_tile, int c_first, int c_later,
+                                      int32_t* __restrict__ cost) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > t_max) return;
+  int32_t c = 0;
+  if (t < rel_tptr[n_rel]) {
+    const int4 d = tiles[t];
+    const int32_t P = d.w - d.z;
+    const int32_t first = P < 64 ? P : 64;
+    c = c_tile + (c_first * first + c_later * (P - first)) / 64;
+  }
+  cost[t] = c;
+}
+// prefix = exclusive scan of cost (t_max + 1 entries: prefix[t_max] = total of the tiles in use);
+// part b starts at the first tile whose prefix reaches total * b / n_parts
+__global__ void fold_parts_kernel(int n_rel, int64_t t_max, const int32_t* __restrict__ rel_tptr,
+                                  const int32_t* __restrict__ prefix, int n_parts, int32_t* __restrict__ part_tptr) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_parts) return;
+  const int32_t n_tiles = rel_tptr[n_rel];
+  if (b == n_parts) { part_tptr[b] = n_tiles; return; }
+  const int64_t total = prefix[t_max];
+  const int64_t target = total * b / n_parts;
+  int32_t lo = 0, hi = n_tiles;  // first t in [0, n_tiles] with prefix[t] >= target
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if ((int64_t)prefix[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  part_tptr[b] = lo;
+}
+
 // ------------------------------------------------------------------ small helpers
-__global__ void gather_i32_kernel(int64_t n, const int32_t* __restrict__ index,
-                                  const int32_t* __restrict__ in, int32_t* __restrict__ out) {
+// out[i] = in[index[i]]: a permutation / gather of 4-byte items.  Four consecutive outputs per
+// thread: one 16-byte index load, four independent gathers in flight, one 16-byte store (the
+// one-item-per-thread form spent its time on issue slots and launch granularity, not on the
+// gathered sectors).  Pointers with 16-byte alignment take the vector path.
+template <typename T>
+__global__ __launch_bounds__(256) void gather4_kernel(int64_t n, const int32_t* __restrict__ index,
+                                                      const T* __restrict__ in, T* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const int4 ix = *reinterpret_cast<const int4*>(index + i);
+    const T a = in[ix.x], b = in[ix.y], c = in[ix.z], d = in[ix.w];
+    T v[4] = {a, b, c, d};
+    *reinterpret_cast<int4*>(out + i) = *reinterpret_cast<const int4*>(v);
+  } else {
+    for (int64_t k = i; k < n; ++k) out[k] = in[index[k]];
+  }
+}
+
+template <typename T>
+__global__ void gather1_kernel(int64_t n, const int32_t* __restrict__ index, const T* __restrict__ in,
+                               T* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[index[i]];
 }
 
-__global__ void gather_f32_kernel(int64_t n, const int32_t* __restrict__ index,
-                                  const float* __restrict__ in, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[index[i]];
+template <typename T>
+static void launch_gather(int64_t n, const int32_t* index, const T* in, T* out, hipStream_t st) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(index) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (aligned)
+    hipLaunchKernelGGL(gather4_kernel<T>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, n, index, in, out);
+  else
+    hipLaunchKernelGGL(gather1_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, index, in, out);
 }
 
 __global__ void invert_perm_kernel(int64_t n, const int32_t* __restrict__ perm,
@@ -417,8 +473,7 @@ int kgat_csr_from_coo(int64_t n_nodes, int64_t n_edges, const int32_t* src, cons
     int rc = radix_sort_index(dst, n_edges, bits_for(n_nodes > 0 ? n_nodes - 1 : 0), eid, &sorted,
                               workspace, workspace_bytes, st);
     if (rc != KGAT_OK) return rc;
-    hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st,
-                       n_edges, (const int32_t*)eid, src, col);
+    launch_gather<int32_t>(n_edges, (const int32_t*)eid, src, col, st);
     KGAT_CHECK_LAUNCH("csr gather col");
     if (row_of) {
       hipError_t e = hipMemcpyAsync(row_of, sorted, sizeof(int32_t) * (size_t)n_edges,
@@ -570,6 +625,37 @@ int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t*
   return KGAT_OK;
 }
 
+size_t kgat_fold_tile_parts_workspace_bytes(int64_t t_max) {
+  const size_t n = (size_t)(t_max > 0 ? t_max : 0) + 1;
+  return align_up(n * 4, 256) + align_up(scan_workspace_elems((int64_t)n) * 4, 256);
+}
+
+int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const int32_t* rel_tptr, int n_parts,
+                         int cost_tile, int cost_first, int cost_later, int32_t* part_tptr, void* workspace,
+                         size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(t_max >= 0 && t_max < INT32_MAX - 1 && n_rel > 0 && n_parts > 0, "fold_tile_parts: bad size");
+  KGAT_CHECK_ARG(cost_tile > 0 && cost_first >= 0 && cost_later >= 0 && cost_tile <= 4096 && cost_first <= 4096 &&
+                 cost_later <= 4096, "fold_tile_parts: cost coefficients must lie in [0, 4096], cost_tile > 0");
+  KGAT_CHECK_ARG(tiles && rel_tptr && part_tptr && workspace, "fold_tile_parts: null pointer");
+  if (workspace_bytes < kgat_fold_tile_parts_workspace_bytes(t_max)) {
+    set_error("fold_tile_parts: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver cv(workspace);
+  int32_t* cost = cv.take<int32_t>((size_t)t_max + 1);
+  int32_t* scan_ws = cv.take<int32_t>(scan_workspace_elems(t_max + 1));
+  hipLaunchKernelGGL(fold_tile_cost_kernel, dim3(blocks_for(t_max + 1, 256)), dim3(256), 0, st, t_max, n_rel, rel_tptr,
+                     reinterpret_cast<const int4*>(tiles), cost_tile, cost_first, cost_later, cost);
+  KGAT_CHECK_LAUNCH("fold_tile_cost");
+  const int rc = exclusive_scan_i32(cost, t_max + 1, scan_ws, st);
+  if (rc != KGAT_OK) return rc;
+  hipLaunchKernelGGL(fold_parts_kernel, dim3(blocks_for(n_parts + 1, 256)), dim3(256), 0, st, n_rel, t_max, rel_tptr,
+                     (const int32_t*)cost, n_parts, part_tptr);
+  KGAT_CHECK_LAUNCH("fold_parts");
+  return KGAT_OK;
+}
+
 int kgat_invert_permutation(int64_t n, const int32_t* perm, int32_t* inv, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n >= 0, "invert_permutation: negative size");
   if (n == 0) return KGAT_OK;
@@ -608,8 +694,7 @@ int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t*
   KGAT_CHECK_ARG(n >= 0, "gather: negative size");
   if (n == 0) return KGAT_OK;
   KGAT_CHECK_ARG(index && in && out, "gather: null pointer");
-  hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream),
-                     n, index, in, out);
+  launch_gather<int32_t>(n, index, in, out, as_stream(stream));
   KGAT_CHECK_LAUNCH("gather_i32");
   return KGAT_OK;
 }
@@ -619,8 +704,7 @@ int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out
   KGAT_CHECK_ARG(n >= 0, "gather: negative size");
   if (n == 0) return KGAT_OK;
   KGAT_CHECK_ARG(index && in && out, "gather: null pointer");
-  hipLaunchKernelGGL(gather_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream),
-                     n, index, in, out);
+  launch_gather<float>(n, index, in, out, as_stream(stream));
   KGAT_CHECK_LAUNCH("gather_f32");
   return KGAT_OK;
 }

@@ -4,18 +4,16 @@
 // five E-sized temporaries):
 //   a[e] = exp(s[e] - M[dst e]) / Z[dst e],  M[v] = max_{e->v} s[e],  Z[v] = sum_{e->v} exp(s[e]-M[v])
 //
-// Design (HBM bound, ~24-36 B/edge over three streaming passes, no per-row launch shape):
-//  * Work is split by EDGE over the destination-sorted edge array, one lane per CSR
-//    position, so hub destinations (10^5..10^6 in-edges) cost the same per edge as leaves.
-//  * Inside a wavefront the lanes of one destination form a contiguous segment; a segmented
-//    shuffle scan reduces them and only the last lane of each segment touches global memory.
-//  * Pass 1: row max via integer-ordered atomic max (order independent).
-//    Pass 2: row sum of exp(s - M): per-wave partials in fp32 (fixed order), combined across
-//            waves in 2^-40 fixed point with 64-bit integer atomic adds - integer addition is
-//            associative, so the sum does not depend on arrival order and the result is bitwise
-//            reproducible (a float atomic add would not be).  A partial is <= 64, so 2^18
-//            waves (2^24 edges) per destination fit in 64 bits.
-//    Pass 3: normalise, write in CSR order (consumed by the SpMM) and/or edge-id order.
+// Design (HBM bound; algorithmic bytes 12E + 4N): ONE sweep over the destination-sorted edge
+// array plus a short second launch for the rows the sweep's ranges cut (default,
+// kgat_edge_softmax_f32: softmax_local_kernel + softmax_cut_rows_kernel, described above those
+// kernels).  No atomics, fixed combination order, no bound on a row's length.
+//
+// The operator's first implementation - three streaming passes (integer-ordered atomic row max;
+// row sums in 2^-40 fixed point with 64-bit integer atomic adds, associative and therefore order
+// independent; normalise), one lane per CSR position with segmented wave scans - is kept below as
+// kgat_edge_softmax_3pass_f32: an independently written second implementation the tests
+// cross-check the sweep against.
 #include <math.h>
 
 #include "kgat_common.h"
@@ -176,10 +174,17 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
 //     back to the lanes of the row with a segmented copy scan, so that all positions of a row
 //     are normalised with the same (M, S);
 //   * the row cut by the start / the end of the wavefront's range is not finished here: its
-//     partial (m, s) goes to a carry entry.  softmax_chain_kernel combines the carries of each
-//     cut row in wavefront order (hub rows span many wavefronts) and softmax_fix_kernel
-//     normalises the positions of the cut rows.
+//     partial (m, s) goes to a carry entry together with the indices of the first and the last
+//     wavefront the row touches (from indptr).  softmax_cut_rows_kernel then lets every
+//     wavefront combine, for each of its (at most two) cut rows, the carries of the row's whole
+//     chain - head entry first, then the followers in blocks of 64 with an ordered tree, the same
+//     sequence in every wavefront of the chain, hence the same bits - and normalise its own
+//     positions of that row.  (Until round 2 a separate one-wave-per-boundary chain launch wrote
+//     the totals back into the entries; three dependent launches of 5-23 us were latency.)
 // No atomics, fixed combination order: bitwise reproducible, and no bound on a row's length.
+// LDS: one 5 KB patch per wavefront, used for the logits, then the row ids, then the results
+// (40 KB per workgroup with two patches limited a CU to 3 workgroups = 768 of the benchmark
+// graph's 895: a second, almost empty round doubled the kernel's time).
 constexpr int kSmEPL = 16;                // positions per lane
 constexpr int kSmEPW = kWave * kSmEPL;    // positions per wavefront
 constexpr int kSmPad = 20;                // floats per lane in the LDS patch (16 + 4: conflict-free b128)
@@ -189,9 +194,9 @@ struct __attribute__((aligned(16))) SmCarry {
   int32_t row;    // -1: no entry
   int32_t count;  // positions of this wavefront that belong to the row
   float m, s;     // partial max, partial sum of exp(x - m)
-  float M, S;     // the row's totals (written by softmax_chain_kernel)
-  int32_t ends;   // first-row entry: the row ends inside this wavefront
-  int32_t pad;
+  int32_t head;   // wavefront in which the row starts (its `b` entry heads the chain)
+  int32_t last;   // wavefront in which the row ends
+  int32_t pad0, pad1;
 };
 
 // exp(x) for x <= 0 on the hardware exp2: the product x*log2(e) is split into its rounded value
@@ -217,44 +222,65 @@ __device__ __forceinline__ int64_t sm_wave_index() {
   return (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
 }
 
+__device__ __forceinline__ void sm_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool IN_CSR>
 __global__ __launch_bounds__(256) void softmax_local_kernel(
-    int64_t e0, int64_t e1, const int32_t* __restrict__ row_of, const int32_t* __restrict__ eid,
-    const float* __restrict__ logits, float* __restrict__ out, float* __restrict__ out_csr,
-    SmCarry* __restrict__ carry) {
-  __shared__ __attribute__((aligned(16))) float s_x[256 / kWave][kWave * kSmPad];
-  __shared__ __attribute__((aligned(16))) int32_t s_r[256 / kWave][kWave * kSmPad];
+    int64_t e0, int64_t e1, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
+    const int32_t* __restrict__ eid, const float* __restrict__ logits, float* __restrict__ out,
+    float* __restrict__ out_csr, SmCarry* __restrict__ carry) {
+  __shared__ __attribute__((aligned(16))) float s_patch[256 / kWave][kWave * kSmPad];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   const int64_t w = sm_wave_index();
   const int64_t base = e0 + w * kSmEPW;
   if (base >= e1) return;
   const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
-  float* px = s_x[wv];
-  int32_t* pr = s_r[wv];
+  float* px = s_patch[wv];
+  int32_t* pr = reinterpret_cast<int32_t*>(s_patch[wv]);
   // striped, coalesced loads; positions past `end` repeat the last row with a huge negative logit
   const int32_t r_last = row_of[end - 1];
+  int32_t rs[kSmEPL];
+  float xs[kSmEPL];
 #pragma unroll
   for (int j = 0; j < kSmEPL; ++j) {
     const int64_t p = base + j * kWave + lane;
     const bool valid = p < end;
-    const int32_t rr = valid ? row_of[p] : r_last;
-    const float xx = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : kSmNegBig;
-    const int idx = j * kWave + lane;  // owner lane idx / 16, slot idx % 16
-    px[(idx >> 4) * kSmPad + (idx & 15)] = xx;
-    pr[(idx >> 4) * kSmPad + (idx & 15)] = rr;
+    rs[j] = valid ? row_of[p] : r_last;
+    xs[j] = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : kSmNegBig;
   }
-  // neighbours of the range (is the first / last row cut?)
-  const bool cut_start = base > e0 && row_of[base - 1] == row_of[base];
+  // neighbours of the range (is the first / last row cut?) and the extent of the two rows at its ends
+  const int32_t r_first = row_of[base];
+  const bool cut_start = base > e0 && row_of[base - 1] == r_first;
   const bool cut_end = end < e1 && row_of[end] == r_last;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  const int64_t first_beg = indptr[r_first], first_end = indptr[r_first + 1];
+  const int64_t last_beg = indptr[r_last], last_end = indptr[r_last + 1];
   float x[kSmEPL], M[kSmEPL], S[kSmEPL];
   int32_t r[kSmEPL];
+  // transpose through the wave's patch: the logits, then (same patch) the row ids
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int idx = j * kWave + lane;  // owner lane idx / 16, slot idx % 16
+    px[(idx >> 4) * kSmPad + (idx & 15)] = xs[j];
+  }
+  sm_wave_sync();
 #pragma unroll
   for (int v = 0; v < kSmEPL / 4; ++v) {
     const float4 a = *reinterpret_cast<const float4*>(px + lane * kSmPad + 4 * v);
-    const int4 b = *reinterpret_cast<const int4*>(pr + lane * kSmPad + 4 * v);
     x[4 * v] = a.x; x[4 * v + 1] = a.y; x[4 * v + 2] = a.z; x[4 * v + 3] = a.w;
+  }
+  sm_wave_sync();
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int idx = j * kWave + lane;
+    pr[(idx >> 4) * kSmPad + (idx & 15)] = rs[j];
+  }
+  sm_wave_sync();
+#pragma unroll
+  for (int v = 0; v < kSmEPL / 4; ++v) {
+    const int4 b = *reinterpret_cast<const int4*>(pr + lane * kSmPad + 4 * v);
     r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
   }
   // ---- lane-local runs
@@ -320,57 +346,45 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   }
   const float nm = __shfl_down(em, 1, kWave), ns = __shfl_down(es, 1, kWave);
   const float lm = multi ? (link_n ? nm : im) : em, ls = multi ? (link_n ? ns : is) : es;  // last run's row
-  // ---- the rows cut by the range
-  const int32_t R0 = __builtin_amdgcn_readfirstlane(key_f);
-  const int32_t RL = r_last;
-  int c0 = 0, cl = 0;
-#pragma unroll
-  for (int i = 0; i < kSmEPL; ++i) {
-    const bool valid = base + lane * kSmEPL + i < end;
-    c0 += (valid && r[i] == R0) ? 1 : 0;
-    cl += (valid && r[i] == RL) ? 1 : 0;
-  }
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    c0 += __shfl_xor(c0, off, kWave);
-    cl += __shfl_xor(cl, off, kWave);
-  }
+  // ---- the rows cut by the range: their positions inside it follow from indptr
+  const int32_t R0 = r_first, RL = r_last;
+  const int c0 = (int)((first_end < end ? first_end : end) - base);
+  const int cl = (int)(end - (last_beg > base ? last_beg : base));
   const float t0m = __shfl(em, 0, kWave), t0s = __shfl(es, 0, kWave);                 // first row, within the range
   const float tlm = __shfl(im, kWave - 1, kWave), tls = __shfl(is, kWave - 1, kWave);  // last row, within the range
   if (lane == 0) {
     SmCarry a, b;
     a.row = b.row = -1;
-    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f; a.M = b.M = 0.f; a.S = b.S = 1.f;
-    a.ends = b.ends = 1; a.pad = b.pad = 0;
-    if (R0 == RL) {  // one row fills the range
-      if (cut_start) {
-        a.row = R0; a.count = c0; a.m = tlm; a.s = tls; a.ends = cut_end ? 0 : 1;
-      } else if (cut_end) {
-        b.row = RL; b.count = cl; b.m = tlm; b.s = tls;
-      }
-    } else {
-      if (cut_start) { a.row = R0; a.count = c0; a.m = t0m; a.s = t0s; a.ends = 1; }
-      if (cut_end) { b.row = RL; b.count = cl; b.m = tlm; b.s = tls; }
+    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f;
+    a.head = b.head = a.last = b.last = 0; a.pad0 = a.pad1 = b.pad0 = b.pad1 = 0;
+    const int64_t fb = first_beg > e0 ? first_beg : e0, fe = first_end < e1 ? first_end : e1;
+    const int64_t lb = last_beg > e0 ? last_beg : e0, le = last_end < e1 ? last_end : e1;
+    if (cut_start) {  // a follower entry of the first row's chain (the row may also fill the whole range)
+      a.row = R0; a.count = c0; a.m = R0 == RL ? tlm : t0m; a.s = R0 == RL ? tls : t0s;
+      a.head = (int32_t)((fb - e0) / kSmEPW); a.last = (int32_t)((fe - 1 - e0) / kSmEPW);
+    }
+    if (cut_end && !(cut_start && R0 == RL)) {  // the head entry of the last row's chain
+      b.row = RL; b.count = cl; b.m = tlm; b.s = tls;
+      b.head = (int32_t)((lb - e0) / kSmEPW); b.last = (int32_t)((le - 1 - e0) / kSmEPW);
     }
     carry[2 * w] = a;
     carry[2 * w + 1] = b;
   }
-  // ---- normalise the finished rows; positions of cut rows are left to softmax_fix_kernel
+  // ---- normalise the finished rows; positions of cut rows are left to softmax_cut_rows_kernel
   const float scale_f = sm_exp(M[0] - em) / es, scale_l = sm_exp(M[kSmEPL - 1] - lm) / ls;
 #pragma unroll
   for (int i = 0; i < kSmEPL; ++i) {
     const bool first = r[i] == key_f, last = r[i] == key_l;
     x[i] = (first || last) ? x[i] * (first ? scale_f : scale_l) : x[i] / S[i];
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  sm_wave_sync();
 #pragma unroll
   for (int v = 0; v < kSmEPL / 4; ++v) {
     float4 a;
     a.x = x[4 * v]; a.y = x[4 * v + 1]; a.z = x[4 * v + 2]; a.w = x[4 * v + 3];
     *reinterpret_cast<float4*>(px + lane * kSmPad + 4 * v) = a;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  sm_wave_sync();
   const int64_t skip_lo = cut_start ? base + c0 : base;     // [base, skip_lo) belongs to the cut first row
   const int64_t skip_hi = cut_end ? end - cl : end;         // [skip_hi, end) belongs to the cut last row
 #pragma unroll
@@ -385,28 +399,20 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   }
 }
 
-// One wavefront per range boundary: combines the partials of the row cut there, in wavefront
-// order, 64 carry entries per step, and writes the totals back into every entry of the chain.
-__global__ __launch_bounds__(256) void softmax_chain_kernel(int64_t n_waves, SmCarry* __restrict__ carry) {
-  const int lane = threadIdx.x % kWave;
-  const int64_t a = sm_wave_index();
-  if (a >= n_waves) return;
-  const SmCarry head = carry[2 * a + 1];
-  if (head.row < 0) return;
-  float m = head.m, s = head.s;
-  int64_t last = a;  // last wavefront of the chain
-  for (int64_t w0 = a + 1; w0 < n_waves; w0 += kWave) {
-    const int64_t w = w0 + lane;
-    const bool valid = w < n_waves;
-    SmCarry f;
-    f.row = -1; f.m = kSmNegBig; f.s = 0.f; f.ends = 1;
-    if (valid) f = carry[2 * w];
-    const bool mine = valid && f.row == head.row;
-    const unsigned long long stop = __ballot(!mine || f.ends);
-    const int n_take = stop ? __ffsll((long long)stop) : kWave;  // lanes [0, n_take) continue the row ...
-    const bool take = lane < n_take && mine;                     // ... (the stopping lane only if it is the row's end)
-    float pm = take ? f.m : kSmNegBig, ps = take ? f.s : 0.f;
-    // ordered wave reduction: lane 0's partial first
+// (M, S) of a cut row from the carries of its chain: the head wavefront's `b` entry, then the `a`
+// entries of the followers head+1 .. last in blocks of 64 (ordered tree inside a block).  Every
+// wavefront of the chain runs exactly this sequence, so all of them normalise with the same bits.
+__device__ __forceinline__ void sm_chain_total(const SmCarry* __restrict__ carry, int32_t head, int32_t last,
+                                               int lane, float& M, float& S) {
+  const SmCarry h = carry[2 * (int64_t)head + 1];
+  float m = h.m, s = h.s;
+  for (int64_t j0 = (int64_t)head + 1; j0 <= last; j0 += kWave) {
+    const int64_t j = j0 + lane;
+    float pm = kSmNegBig, ps = 0.f;
+    if (j <= last) {
+      const SmCarry f = carry[2 * j];
+      pm = f.m; ps = f.s;
+    }
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
       const float m2 = __shfl_down(pm, d, kWave), s2 = __shfl_down(ps, d, kWave);
@@ -414,12 +420,8 @@ __global__ __launch_bounds__(256) void softmax_chain_kernel(int64_t n_waves, SmC
     }
     pm = __shfl(pm, 0, kWave); ps = __shfl(ps, 0, kWave);
     sm_combine(m, s, pm, ps);
-    const int n_mine = __popcll(__ballot(take));
-    last = w0 + n_mine - 1;
-    if (stop) break;
   }
-  if (lane == 0) { carry[2 * a + 1].M = m; carry[2 * a + 1].S = s; }
-  for (int64_t w = a + 1 + lane; w <= last; w += kWave) { carry[2 * w].M = m; carry[2 * w].S = s; }
+  M = m; S = s;
 }
 
 // positions [lo, hi) of one row, 8 x 64 per step so that the loads of a step are in flight together
@@ -451,7 +453,7 @@ __device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float
 }
 
 template <bool IN_CSR>
-__global__ __launch_bounds__(256) void softmax_fix_kernel(
+__global__ __launch_bounds__(256) void softmax_cut_rows_kernel(
     int64_t e0, int64_t e1, const int32_t* __restrict__ eid, const float* __restrict__ logits,
     float* __restrict__ out, float* __restrict__ out_csr, const SmCarry* __restrict__ carry) {
   const int lane = threadIdx.x % kWave;
@@ -467,20 +469,24 @@ __global__ __launch_bounds__(256) void softmax_fix_kernel(
   const int64_t ea = eid ? eid[pa] : pa, eb = eid ? eid[pb] : pb;
   const float xa = IN_CSR ? logits[pa] : logits[ea], xb = IN_CSR ? logits[pb] : logits[eb];
   if (ca.row >= 0) {
+    float M, S;
+    sm_chain_total(carry, ca.head, ca.last, lane, M, S);
     if (lane < ca.count) {
-      const float a = sm_exp(xa - ca.M) / ca.S;
+      const float a = sm_exp(xa - M) / S;
       if (out_csr) out_csr[pa] = a;
       if (out) out[ea] = a;
     }
-    fix_span<IN_CSR>(base + kWave, base + ca.count, lane, ca.M, ca.S, eid, logits, out, out_csr);
+    fix_span<IN_CSR>(base + kWave, base + ca.count, lane, M, S, eid, logits, out, out_csr);
   }
   if (cb.row >= 0) {
+    float M, S;
+    sm_chain_total(carry, cb.head, cb.last, lane, M, S);
     if (lane < cb.count) {
-      const float a = sm_exp(xb - cb.M) / cb.S;
+      const float a = sm_exp(xb - M) / S;
       if (out_csr) out_csr[pb] = a;
       if (out) out[eb] = a;
     }
-    fix_span<IN_CSR>(end - cb.count, end - kWave, lane, cb.M, cb.S, eid, logits, out, out_csr);
+    fix_span<IN_CSR>(end - cb.count, end - kWave, lane, M, S, eid, logits, out, out_csr);
   }
 }
 
@@ -524,14 +530,14 @@ size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
   return align_up((2 * n_waves + 2) * sizeof(SmCarry), 256);
 }
 
-int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
+int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end, const int32_t* indptr,
                           const int32_t* row_of, const int32_t* eid, const float* logits,
                           int logits_in_csr_order, float* out, float* out_csr, void* workspace,
                           size_t workspace_bytes, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && e_begin >= 0 && e_end >= e_begin && e_end < INT32_MAX,
                  "edge_softmax: bad size");
   if (e_end == e_begin) return KGAT_OK;
-  KGAT_CHECK_ARG(row_of && logits && workspace, "edge_softmax: null pointer");
+  KGAT_CHECK_ARG(indptr && row_of && logits && workspace, "edge_softmax: null pointer");
   KGAT_CHECK_ARG(out || out_csr, "edge_softmax: no output requested");
   KGAT_CHECK_ARG(eid != nullptr || (logits_in_csr_order && out == nullptr),
                  "edge_softmax: edge-id ordered input/output needs eid");
@@ -545,17 +551,15 @@ int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
   const int64_t n_waves = (ne + kSmEPW - 1) / kSmEPW;
   const unsigned blocks = (unsigned)((n_waves + 3) / 4);
   if (logits_in_csr_order) {
-    hipLaunchKernelGGL(softmax_local_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, row_of, eid,
-                       logits, out, out_csr, carry);
-    hipLaunchKernelGGL(softmax_chain_kernel, dim3(blocks), dim3(256), 0, st, n_waves, carry);
-    hipLaunchKernelGGL(softmax_fix_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits, out,
-                       out_csr, (const SmCarry*)carry);
+    hipLaunchKernelGGL(softmax_local_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
+                       eid, logits, out, out_csr, carry);
+    hipLaunchKernelGGL(softmax_cut_rows_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
+                       out, out_csr, (const SmCarry*)carry);
   } else {
-    hipLaunchKernelGGL(softmax_local_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, row_of, eid,
-                       logits, out, out_csr, carry);
-    hipLaunchKernelGGL(softmax_chain_kernel, dim3(blocks), dim3(256), 0, st, n_waves, carry);
-    hipLaunchKernelGGL(softmax_fix_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits, out,
-                       out_csr, (const SmCarry*)carry);
+    hipLaunchKernelGGL(softmax_local_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
+                       eid, logits, out, out_csr, carry);
+    hipLaunchKernelGGL(softmax_cut_rows_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
+                       out, out_csr, (const SmCarry*)carry);
   }
   KGAT_CHECK_LAUNCH("edge_softmax");
   return KGAT_OK;

@@ -377,7 +377,15 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
 }
 
 // Finish: (a) rows that are first/last in some tile: sum their tile partials in tile order;
-// (b) rows without in-edges: write zeros.  One wavefront per (tile, slot) item for (a).
+// (b) rows without in-edges: write zeros.  For (a) every lane group (LPR lanes) examines one
+// (tile, slot) item - is this tile the first one of the slot's row, i.e. its owner? - and sums a
+// short chain of partials (the common case: the tail of one tile + the head of the next) by
+// itself, so the items of a wavefront proceed in parallel; the chains of hub rows (8 tiles and
+// more) are then summed one after the other by the whole wavefront, its lane groups striding over
+// the chain's tiles.  Both orders are fixed by the graph alone.  (One wavefront per item, the
+// first form, spent 0.3 ms of a 200 M-edge launch on waves that returned at once; one item per
+// LANE, tried next, serialised up to 64 latency-bound chains in a wave: 9 -> 30 us on the
+// amazon-book graph.)
 template <int LPR, int C, bool MUL_SELF>
 __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
     int64_t e0, int64_t e1, int32_t row0, int32_t n_rows, int32_t n_tiles,
@@ -388,40 +396,60 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
   constexpr int TE = NSUB * C;
   constexpr int SPW = kWave / LPR >= 1 ? kWave / LPR : 1;  // subgroups per wave
   constexpr int WPB = kSpmmThreads / kWave;
+  constexpr int kLongChain = 8;
   const int tid = threadIdx.x;
   if ((int32_t)blockIdx.x < fix_blocks) {
     if (LPR > kWave) return;  // not instantiated
     const int wave = tid / kWave, lane = tid % kWave;
     const int q = lane / LPR, sl = lane % LPR;
-    const int64_t item = (int64_t)blockIdx.x * WPB + wave;
+    const int64_t item = ((int64_t)blockIdx.x * WPB + wave) * SPW + q;
     const int32_t b = (int32_t)(item >> 1);
     const int s = (int)(item & 1);
-    if (b >= n_tiles) return;
-    const int64_t t0 = e0 + (int64_t)b * TE;
-    const int64_t t1 = (t0 + TE < e1) ? t0 + TE : e1;
-    const int32_t fr = row_of[t0], lr = row_of[t1 - 1];
-    if (s == 1 && lr == fr) return;
-    const int32_t r = s == 0 ? fr : lr;
-    const int64_t rb = indptr[r], re = indptr[r + 1];
-    const int32_t bf = (int32_t)((rb - e0) / TE);
-    if (bf != b) return;  // another tile owns this row's fix-up
-    const int32_t bl = (int32_t)((re - 1 - e0) / TE);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int32_t bb = b + q; bb <= bl; bb += SPW) {
-      const int slot = (bb == b) ? s : 0;
-      acc = add4(acc, bpart[((size_t)bb * 2 + slot) * LPR + sl]);
+    int32_t my_row = -1, my_bl = 0;
+    if (b < n_tiles) {
+      const int64_t t0 = e0 + (int64_t)b * TE;
+      const int64_t t1 = (t0 + TE < e1) ? t0 + TE : e1;
+      const int32_t fr = row_of[t0], lr = row_of[t1 - 1];
+      if (!(s == 1 && lr == fr)) {
+        const int32_t r = s == 0 ? fr : lr;
+        const int64_t rb = indptr[r], re = indptr[r + 1];
+        if ((int32_t)((rb - e0) / TE) == b) {  // this tile owns the row's fix-up
+          my_row = r;
+          my_bl = (int32_t)((re - 1 - e0) / TE);
+        }
+      }
     }
-    // fixed-order reduction across the wave's subgroups
+    const bool is_long = my_row >= 0 && my_bl - b >= kLongChain;
+    if (my_row >= 0 && !is_long) {
+      float4 acc = bpart[((size_t)b * 2 + s) * LPR + sl];
+      for (int32_t bb = b + 1; bb <= my_bl; ++bb) acc = add4(acc, bpart[((size_t)bb * 2) * LPR + sl]);
+      store_row<LPR, MUL_SELF>(out, X, my_row, row0, sl, acc);
+    }
+    unsigned long long todo = __ballot(is_long && sl == 0);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int32_t r = __shfl(my_row, src, kWave);
+      const int32_t bl = __shfl(my_bl, src, kWave);
+      const int32_t bo = __shfl(b, src, kWave);
+      const int so = __shfl(s, src, kWave);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int32_t bb = bo + q; bb <= bl; bb += SPW) {
+        const int slot = (bb == bo) ? so : 0;
+        acc = add4(acc, bpart[((size_t)bb * 2 + slot) * LPR + sl]);
+      }
+      // fixed-order reduction across the wave's subgroups
 #pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) {
-      float4 o;
-      o.x = __shfl_xor(acc.x, off, kWave);
-      o.y = __shfl_xor(acc.y, off, kWave);
-      o.z = __shfl_xor(acc.z, off, kWave);
-      o.w = __shfl_xor(acc.w, off, kWave);
-      acc = add4(acc, o);
+      for (int off = LPR; off < kWave; off <<= 1) {
+        float4 o;
+        o.x = __shfl_xor(acc.x, off, kWave);
+        o.y = __shfl_xor(acc.y, off, kWave);
+        o.z = __shfl_xor(acc.z, off, kWave);
+        o.w = __shfl_xor(acc.w, off, kWave);
+        acc = add4(acc, o);
+      }
+      if (q == 0) store_row<LPR, MUL_SELF>(out, X, r, row0, sl, acc);
     }
-    if (q == 0) store_row<LPR, MUL_SELF>(out, X, r, row0, sl, acc);
   } else {
     const int sub = tid / LPR, sl = tid % LPR;
     const int32_t nz_blocks = gridDim.x - fix_blocks;
@@ -550,7 +578,8 @@ static int launch_merge(const SpmmArgs& a) {
     }
     KGAT_CHECK_LAUNCH("spmm_merge");
   }
-  const int32_t fix_blocks = (int32_t)((tiles * 2 + 3) / 4);
+  constexpr int kItemsPerBlock = (kSpmmThreads / kWave) * (kWave / LPR >= 1 ? kWave / LPR : 1);  // one per lane group
+  const int32_t fix_blocks = (int32_t)((tiles * 2 + kItemsPerBlock - 1) / kItemsPerBlock);
   int64_t nz_blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;

@@ -26,6 +26,7 @@ import torch
 
 from . import ops
 from .function import BuiltinMessage, BuiltinReduce
+from .lazy import LazyEdgeWeights, pending_csr_weights
 
 ALL = "__ALL__"
 
@@ -213,6 +214,38 @@ class _Structure:
         if hit is None or hit[0] != key:
             hit = (key, ops.gather(self.csr_rev(w_flat.device).eid, w_flat), w_flat)
             c["w_rev"] = hit
+        return hit[1]
+
+    @staticmethod
+    def _flat(w):
+        if w.dim() == 2 and w.shape[1] == 1:
+            return w.reshape(-1)
+        if w.dim() == 1:
+            return w
+        raise NotImplementedError("u_mul_e on the KGAT path takes an (E,1) or (E,) edge weight; got %s"
+                                  % (tuple(w.shape),))
+
+    def csr_weights(self, w):
+        """The edge weights `w` (edge-id order, (E,) or (E,1)) in CSR order.  A still-pending
+        LazyEdgeWeights of this graph is answered from the CSR copy it stands for, without touching
+        (and thereby materialising) it."""
+        hit = pending_csr_weights(w, self)
+        if hit is not None:
+            return hit
+        return self.weight_in_csr_order(self._flat(w).detach().contiguous())
+
+    def rev_weights(self, w):
+        """The same weights in the reversed graph's CSR order (SpMM backward); a pending
+        LazyEdgeWeights is served from its CSR copy through the composed position map."""
+        w_csr = pending_csr_weights(w, self)
+        if w_csr is None:
+            return self.weight_in_rev_order(self._flat(w).detach().contiguous())
+        c = self._cache(w_csr.device)
+        hit = c.get("w_rev_of_csr")
+        if hit is None or hit[0] is not w_csr:
+            if "rev_from_csr" not in c:  # CSR position of the edge at every reversed-CSR position
+                c["rev_from_csr"] = ops.gather(self.csr_rev(w_csr.device).eid, self.csr_pos(w_csr.device))
+            hit = c["w_rev_of_csr"] = (w_csr, ops.gather(c["rev_from_csr"], w_csr))
         return hit[1]
 
     def remember_weight(self, w_flat, w_csr):
@@ -488,11 +521,13 @@ class DGLGraph:
         return "one"
 
     # ---- fused fast path (not part of the DGL surface)
-    def kgat_attention(self, ent, W_R, rel, etype=None, algo="auto"):
-        """compute_attention (models.py:146-154) in two launches: relation-grouped attention
-        logits + destination softmax.  Returns (E,1) weights in edge-id order and remembers
-        their CSR-ordered copy so that a following ``edata['w'] = result`` +
-        ``update_all`` streams them without a permutation pass."""
+    def kgat_attention(self, ent, W_R, rel, etype=None, algo="auto", lazy=None):
+        """compute_attention (models.py:146-154): relation-grouped attention logits + destination
+        softmax.  Returns the (E,1) weights in edge-id order; the graph keeps their CSR-ordered
+        copy, so a following ``edata['w'] = result`` + ``update_all`` streams them without a
+        permutation pass.  By default (``lazy=None``: on unless ``KGAT_EAGER_EDGE_WEIGHTS`` is set)
+        the result is a `lazy.LazyEdgeWeights`: real storage whose edge-id-ordered values are
+        written by the first operation that looks at them - nothing on the path does."""
         if etype is None:
             etype = self._edge_frame["type"]
         st = self._st
@@ -514,7 +549,7 @@ class DGLGraph:
                                                                    groups.n_groups)
                 return ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
                                            groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
-                                           ent_c, W_c, rel_c, want_eid=False)[1]
+                                           ent_c, W_c, rel_c, want_eid=False, part_tptr=tiles[2])[1]
             if form in ("folded", "split"):
                 folded = form == "folded"
                 width = d if folded else k
@@ -539,8 +574,17 @@ class DGLGraph:
         if form not in ("fused", "folded", "split"):
             form = "one"
         st.last_att_form = (form, groups.n_groups)
-        _, a_csr = ops.edge_softmax(st.n_nodes, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
+        _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
                                     want_out=False, want_csr=True)
-        a = ops.gather(st.csr_pos(dev), a_csr)  # edge-id order: coalesced writes, cached reads
-        st.remember_weight(a, a_csr)
-        return a.unsqueeze(1)
+        if lazy is None:
+            lazy = not os.environ.get("KGAT_EAGER_EDGE_WEIGHTS")
+        a = torch.empty((st.n_edges, 1), dtype=torch.float32, device=dev)
+        a_flat = a.view(-1)
+
+        def fill():  # edge-id order: coalesced writes, cached reads
+            ops.gather(st.csr_pos(dev), a_csr, out=a_flat)
+            st.remember_weight(a_flat, a_csr)
+        if not lazy:
+            fill()
+            return a
+        return LazyEdgeWeights(a, fill, st, a_csr)

@@ -3,7 +3,9 @@
 Same definitions, including the reference's quirks: training items are masked by setting their
 score to 0.0 (not -inf), and the ideal DCG of a user is the DCG of that user's *own* hit list
 sorted (``one_ndcg_at_k``), not the DCG of min(|positives|, K) leading ones.  Users are scored
-in batches with one matmul + top-K instead of one sort per user.
+in batches with one matmul + one stable descending sort per batch instead of one sort per user
+(the reference's ``th.sort`` is stable on the CPU: among equal scores - the masked zeros - the
+lower item index ranks first; a top-K primitive would break such ties its own way).
 """
 import numpy as np
 import torch
@@ -33,7 +35,7 @@ def calc_recall_ndcg(embedding, train_user_dict, test_user_dict, all_item_id_ran
             score[torch.as_tensor(np.concatenate(rows), device=dev), torch.as_tensor(np.concatenate(cols), device=dev)] = 0.0
             pos = torch.zeros((len(ub), n_items), dtype=torch.bool, device=dev)
             pos[torch.as_tensor(np.concatenate(prow), device=dev), torch.as_tensor(np.concatenate(pcol), device=dev)] = True
-            top = torch.topk(score, K, dim=1).indices
+            top = torch.sort(score, dim=1, descending=True, stable=True).indices[:, :K]
             hits = pos.gather(1, top).to(torch.float64)  # (B, K) binary_rank_K
             n_pos = torch.as_tensor([len(test_user_dict[u]) for u in ub], device=dev, dtype=torch.float64)
             recall_sum += float((hits.sum(1) / n_pos.clamp(min=1)).where(n_pos > 0, torch.zeros_like(n_pos)).sum())

@@ -65,6 +65,8 @@ class _timed:
 def _need(t, dtype, name, shape=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
+    if type(t) is not torch.Tensor and hasattr(t, "materialize"):
+        t.materialize()  # lazy.LazyEdgeWeights: the kernels read through the raw pointer
     if not t.is_cuda:
         raise KGATLibraryError("%s is on %s: the KGAT propagation path only runs on a HIP device "
                                "(no CPU implementation exists in this package)" % (name, t.device))
@@ -133,18 +135,18 @@ def row_order_by_degree(indptr):
     return order
 
 
-def gather(index, values):
+def gather(index, values, out=None):
+    """out[i] = values[index[i]] (float32 or int32 values); `out` may be a preallocated flat tensor."""
     index = _need(index, torch.int32, "index")
-    if values.dtype == torch.float32:
-        values = _need(values, torch.float32, "values")
-        out = torch.empty(index.numel(), dtype=torch.float32, device=index.device)
-        check(_lib.load().kgat_gather_f32(index.numel(), _ptr(index), _ptr(values), _ptr(out),
-                                          _stream(index)), "kgat_gather_f32")
+    dtype = torch.float32 if values.dtype == torch.float32 else torch.int32
+    values = _need(values, dtype, "values")
+    if out is None:
+        out = torch.empty(index.numel(), dtype=dtype, device=index.device)
     else:
-        values = _need(values, torch.int32, "values")
-        out = torch.empty(index.numel(), dtype=torch.int32, device=index.device)
-        check(_lib.load().kgat_gather_i32(index.numel(), _ptr(index), _ptr(values), _ptr(out),
-                                          _stream(index)), "kgat_gather_i32")
+        out = _need(out, dtype, "out", (index.numel(),))
+    fn = _lib.load().kgat_gather_f32 if dtype == torch.float32 else _lib.load().kgat_gather_i32
+    with _timed("gather", (index.numel(),)):
+        check(fn(index.numel(), _ptr(index), _ptr(values), _ptr(out), _stream(index)), "kgat_gather")
     return out
 
 
@@ -236,24 +238,38 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
 
 
 FOLD_TILE_CAP = 128  # measured best on MI355X (64: 0.268, 128: 0.251, 192: 0.261, 256: 0.283 ms)
+# per-tile cost model of the fused kernel, in units of ~90 shader cycles: the MFMA phase of a tile
+# (~5,800 cycles), its first 64 positions (rows requested before the MFMA phase: ~10 cycles each),
+# positions past the first 64 (no row look-ahead: ~50 cycles each)
+FOLD_TILE_COST = (64, 8, 32)
 
 
-def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP):
-    """Work tiles of the fused attention kernel (kgat_fold_tiles).  Returns (tiles (T_max, 4)
-    int32, rel_tptr (R+1,) int32); rel_tptr[-1] is the number of tiles in use."""
+def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, cost=FOLD_TILE_COST):
+    """Work tiles of the fused attention kernel (kgat_fold_tiles) and their cost-balanced split
+    over `n_parts` workgroups (kgat_fold_tile_parts; default: one per compute unit).  Returns
+    (tiles (T_max, 4) int32, rel_tptr (R+1,) int32, part_tptr (n_parts+1,) int32); rel_tptr[-1]
+    is the number of tiles in use."""
     lib = _lib.load()
     rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr")
     gptr = _need(gptr, torch.int32, "gptr", rel_ptr.shape)
     gid = _need(gid, torch.int32, "gid")
     n_rel = rel_ptr.numel() - 1
     e = gid.numel()
-    t_max = int(lib.kgat_fold_tiles_max(e, int(n_groups), n_rel, int(cap)))
-    tiles = torch.zeros((max(t_max, 1), 4), dtype=torch.int32, device=gid.device)
-    rel_tptr = torch.zeros(n_rel + 1, dtype=torch.int32, device=gid.device)
-    ws = _workspace(lib.kgat_fold_tiles_workspace_bytes(int(n_groups), n_rel), gid.device)
+    dev = gid.device
+    t_max = max(int(lib.kgat_fold_tiles_max(e, int(n_groups), n_rel, int(cap))), 1)
+    tiles = torch.zeros((t_max, 4), dtype=torch.int32, device=dev)
+    rel_tptr = torch.zeros(n_rel + 1, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.kgat_fold_tiles_workspace_bytes(int(n_groups), n_rel), dev)
     check(lib.kgat_fold_tiles(e, n_rel, int(n_groups), _ptr(rel_ptr), _ptr(gid), _ptr(gptr), int(cap), _ptr(tiles),
                               _ptr(rel_tptr), _ptr(ws), ws.numel(), _stream(gid)), "kgat_fold_tiles")
-    return tiles, rel_tptr
+    if n_parts is None:
+        n_parts = torch.cuda.get_device_properties(dev).multi_processor_count
+    part_tptr = torch.zeros(int(n_parts) + 1, dtype=torch.int32, device=dev)
+    ws2 = _workspace(lib.kgat_fold_tile_parts_workspace_bytes(t_max), dev)
+    check(lib.kgat_fold_tile_parts(t_max, n_rel, _ptr(tiles), _ptr(rel_tptr), int(n_parts), int(cost[0]), int(cost[1]),
+                                   int(cost[2]), _ptr(part_tptr), _ptr(ws2), ws2.numel(), _stream(gid)),
+          "kgat_fold_tile_parts")
+    return tiles, rel_tptr, part_tptr
 
 
 def att_score_fused_supported(n_nodes, d, k, n_rel):
@@ -261,9 +277,10 @@ def att_score_fused_supported(n_nodes, d, k, n_rel):
 
 
 def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
-                    want_csr=True, want_eid=True):
-    """Attention logits, fused folded form (kgat_att_score_fused_f32).  Returns
-    (logits edge-id order or None, logits CSR order or None)."""
+                    want_csr=True, want_eid=True, part_tptr=None):
+    """Attention logits, fused folded form (kgat_att_score_fused_f32).  `part_tptr`: the tile range
+    of every workgroup (fold_tiles); None: equal tile counts, one workgroup per compute unit.
+    Returns (logits edge-id order or None, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
@@ -278,13 +295,18 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
     _need(rel_tptr, torch.int32, "rel_tptr", (n_rel + 1,))
     _need(g_node, torch.int32, "g_node")
     _need(tiles, torch.int32, "tiles")
+    n_parts = 0
+    if part_tptr is not None:
+        part_tptr = _need(part_tptr, torch.int32, "part_tptr")
+        n_parts = part_tptr.numel() - 1
     logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
     with _timed("att_score", (e, d, k)):
         check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
                                                    _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), _ptr(tiles),
-                                                   _ptr(rel_tptr), _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits),
-                                                   _ptr(logits_csr), _stream(ent)), "kgat_att_score_fused_f32")
+                                                   _ptr(rel_tptr), _ptr(part_tptr), n_parts, _ptr(ent), _ptr(W_R),
+                                                   _ptr(rel), _ptr(logits), _ptr(logits_csr), _stream(ent)),
+              "kgat_att_score_fused_f32")
     return logits, logits_csr
 
 
@@ -320,28 +342,32 @@ def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=Tr
     return loss, g_ent, g_w, g_rel
 
 
-def edge_softmax(n_nodes, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
+def edge_softmax(indptr, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
                  want_csr=False, three_pass=False):
-    """Softmax over each destination's in-edges.  `logits` (E,) is in edge-id order, or in
-    CSR order with in_csr_order=True.  Returns (out in edge-id order, out_csr in CSR order);
-    unrequested ones are None.  three_pass=True runs the independent three-pass implementation
-    (kgat_edge_softmax_3pass_f32)."""
+    """Softmax over each destination's in-edges (`indptr`, `row_of`, `eid` of the destination-major
+    CSR).  `logits` (E,) is in edge-id order, or in CSR order with in_csr_order=True.  Returns
+    (out in edge-id order, out_csr in CSR order); unrequested ones are None.  three_pass=True runs
+    the independent three-pass implementation (kgat_edge_softmax_3pass_f32)."""
     logits = _need(logits, torch.float32, "logits")
+    indptr = _need(indptr, torch.int32, "indptr")
     row_of = _need(row_of, torch.int32, "row_of", logits.shape)
     eid = _need(eid, torch.int32, "eid", logits.shape)
+    n_nodes = indptr.numel() - 1
     lib = _lib.load()
     e0, e1 = (0, logits.numel()) if e_range is None else e_range
     out = torch.empty_like(logits) if want_out else None
     out_csr = torch.empty_like(logits) if want_csr else None
-    if three_pass:
-        ws = _workspace(lib.kgat_edge_softmax_3pass_workspace_bytes(n_nodes), logits.device)
-        fn, name = lib.kgat_edge_softmax_3pass_f32, "kgat_edge_softmax_3pass_f32"
-    else:
-        ws = _workspace(lib.kgat_edge_softmax_workspace_bytes(n_nodes, e1 - e0), logits.device)
-        fn, name = lib.kgat_edge_softmax_f32, "kgat_edge_softmax_f32"
     with _timed("edge_softmax", (e1 - e0,)):
-        check(fn(n_nodes, e0, e1, _ptr(row_of), _ptr(eid), _ptr(logits), 1 if in_csr_order else 0, _ptr(out),
-                 _ptr(out_csr), _ptr(ws), ws.numel(), _stream(logits)), name)
+        if three_pass:
+            ws = _workspace(lib.kgat_edge_softmax_3pass_workspace_bytes(n_nodes), logits.device)
+            check(lib.kgat_edge_softmax_3pass_f32(n_nodes, e0, e1, _ptr(row_of), _ptr(eid), _ptr(logits),
+                                                  1 if in_csr_order else 0, _ptr(out), _ptr(out_csr), _ptr(ws),
+                                                  ws.numel(), _stream(logits)), "kgat_edge_softmax_3pass_f32")
+        else:
+            ws = _workspace(lib.kgat_edge_softmax_workspace_bytes(n_nodes, e1 - e0), logits.device)
+            check(lib.kgat_edge_softmax_f32(n_nodes, e0, e1, _ptr(indptr), _ptr(row_of), _ptr(eid), _ptr(logits),
+                                            1 if in_csr_order else 0, _ptr(out), _ptr(out_csr), _ptr(ws),
+                                            ws.numel(), _stream(logits)), "kgat_edge_softmax_f32")
     return out, out_csr
 
 

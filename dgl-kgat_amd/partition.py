@@ -114,8 +114,7 @@ class Partition:
         CSR positions are [0, E_local) - then the dense part on those rows only."""
         st = g._st
         csr = st.csr(h.device)
-        w = g.edata["w"]
-        w_csr = st.weight_in_csr_order(w.detach().reshape(-1).contiguous())
+        w_csr = st.csr_weights(g.edata["w"])
         prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
                         rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
         return torch.nn.functional.leaky_relu(torch.nn.functional.linear(prod, weight))
@@ -130,7 +129,7 @@ class Partition:
         exchange buffer, then exchanged."""
         st = g._st
         csr = st.csr(h.device)
-        w_csr = st.weight_in_csr_order(g.edata["w"].detach().reshape(-1).contiguous())
+        w_csr = st.csr_weights(g.edata["w"])
         prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
                         rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
         full = self.new_buffer(weight.shape[0], h.device)

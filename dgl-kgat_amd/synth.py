@@ -75,27 +75,48 @@ def power_law_ckg(n_nodes, n_edges, n_rel, seed=1234, alpha=1.1, max_in_degree=1
     return n_nodes, np.stack([h, r, t], 1).astype(np.int32), n_rel
 
 
-def power_law_coo_device(n_nodes, n_edges, n_rel, device, seed=1234, alpha=1.1, max_in_degree=1_000_000):
+def power_law_coo_device(n_nodes, n_edges, n_rel, device, seed=1234, alpha=1.1, max_in_degree=1_000_000,
+                         cap="redraw"):
     """The C5 graph drawn on the device (torch RNG) so that a 10 M / 200 M instance costs a
-    second instead of minutes of host sampling: destinations follow a shifted Zipf
-    (``p_i ~ (i + i0)^-alpha``, Zipf-Mandelbrot; ``i0`` is the smallest shift that keeps the
-    expected heaviest in-degree under `max_in_degree`), popularity rank decoupled from node id
-    by a random permutation; sources and relation types uniform.  Returns int32 device tensors
-    ``(src, dst, etype)`` in edge-id order (src = tail, dst = head, as dataset.py:116)."""
+    fraction of a second instead of minutes of host sampling.  Destinations follow Zipf(alpha)
+    over a random relabelling of the nodes; sources and relation types are uniform.  The heaviest
+    destinations are capped near `max_in_degree` in one of two ways:
+
+    * ``cap="redraw"`` (default; the shape of `power_law_ckg`): an edge that lands on a node whose
+      expected in-degree exceeds the cap keeps it with probability cap / expected, otherwise its
+      destination is re-drawn uniformly - the hubs end at ~cap edges (binomial spread) and their
+      excess becomes a uniform background;
+    * ``cap="shift"``: a shifted Zipf ``p_i ~ (i + i0)^-alpha`` (Zipf-Mandelbrot) with the smallest
+      shift that keeps the heaviest expectation under the cap - no background, a flatter head.
+
+    Returns int32 device tensors ``(src, dst, etype)`` in edge-id order (src = tail, dst = head,
+    as dataset.py:116)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(int(seed))
     rank = torch.arange(1, n_nodes + 1, dtype=torch.float64, device=device)
-    lo, hi = 0.0, float(n_nodes)
-    for _ in range(40):  # bisection on the shift: p_max(i0) is decreasing in i0
-        i0 = 0.5 * (lo + hi)
-        w = (rank + i0).pow(-alpha)
-        if float(w[0] / w.sum()) * n_edges > max_in_degree:
-            lo = i0
-        else:
-            hi = i0
-    w = (rank + hi).pow(-alpha)
+    shift = 0.0
+    if cap == "shift":
+        lo, hi = 0.0, float(n_nodes)
+        for _ in range(40):  # bisection on the shift: p_max(i0) is decreasing in i0
+            i0 = 0.5 * (lo + hi)
+            w = (rank + i0).pow(-alpha)
+            if float(w[0] / w.sum()) * n_edges > max_in_degree:
+                lo = i0
+            else:
+                hi = i0
+        shift = hi
+    elif cap != "redraw":
+        raise ValueError("cap must be 'redraw' or 'shift'")
+    w = (rank + shift).pow(-alpha)
+    w /= w.sum()
+    keep = None
+    if cap == "redraw":
+        keep = (max_in_degree / (w * n_edges)).clamp_(max=1.0)  # per popularity rank
+        if bool((keep >= 1.0).all()):
+            keep = None
     cdf = torch.cumsum(w, 0)
     cdf /= cdf[-1].clone()
+    del w, rank
     dst = torch.empty(n_edges, dtype=torch.int32, device=device)
     relabel = torch.randperm(n_nodes, generator=gen, device=device).to(torch.int32)
     chunk = 1 << 26
@@ -103,6 +124,11 @@ def power_law_coo_device(n_nodes, n_edges, n_rel, device, seed=1234, alpha=1.1, 
         m = min(chunk, n_edges - lo_e)
         u = torch.rand(m, generator=gen, device=device, dtype=torch.float64)
         idx = torch.searchsorted(cdf, u).clamp_(max=n_nodes - 1)
+        if keep is not None:
+            redraw = torch.rand(m, generator=gen, device=device, dtype=torch.float64) >= keep[idx]
+            uniform = torch.randint(0, n_nodes, (m,), generator=gen, device=device)
+            idx = torch.where(redraw, uniform, idx)
+            del redraw, uniform
         dst[lo_e:lo_e + m] = relabel[idx]
         del u, idx
     src = torch.randint(0, n_nodes, (n_edges,), generator=gen, device=device, dtype=torch.int32)

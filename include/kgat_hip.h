@@ -172,11 +172,25 @@ size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel);
 int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,
                     const int32_t* gptr, int cap, int32_t* tiles, int32_t* rel_tptr, void* workspace,
                     size_t workspace_bytes, kgat_stream_t stream);
+/* Split of the tiles over the n_parts workgroups of the fused kernel (graph-static, like the
+ * tiles): part b owns the contiguous tile range [part_tptr[b], part_tptr[b+1]), chosen on the
+ * prefix sum of a per-tile cost
+ *   cost_tile + (cost_first * min(P, 64) + cost_later * max(P - 64, 0)) / 64,  P = positions of the tile
+ * so that every workgroup gets the same cost, not the same tile count (a tile's MFMA phase is
+ * constant, its edge phase grows with P, and positions past the first 64 run without row
+ * look-ahead).  t_max = number of rows of `tiles`; part_tptr[n_parts + 1]. */
+size_t kgat_fold_tile_parts_workspace_bytes(int64_t t_max);
+int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const int32_t* rel_tptr, int n_parts,
+                         int cost_tile, int cost_first, int cost_later, int32_t* part_tptr, void* workspace,
+                         size_t workspace_bytes, kgat_stream_t stream);
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
+/* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
+ * compute unit, equal tile counts. */
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                             const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
                              float* logits_csr, kgat_stream_t stream);
 
@@ -190,11 +204,15 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
  * position order (1).  Outputs (either may be NULL, not both): out in edge-id order (written
  * through eid) and out_csr in CSR order.  eid = original edge id per CSR position.
  * One sweep over the positions (rows finished inside a wavefront's 1,024-position range are
- * normalised on the spot; the rows cut by range boundaries are combined from carry entries in
- * range order and normalised by a short fix-up launch).  No atomics, fixed combination order:
- * bitwise reproducible, no bound on a row's length.  Workspace: n_edges = e_end - e_begin. */
+ * normalised on the spot) plus one short launch in which every wavefront combines, for the rows
+ * its range cuts, the carry entries of the row's whole chain in a fixed order and normalises its
+ * own positions of them.  No atomics, fixed combination order: bitwise reproducible, no bound on
+ * a row's length.  indptr[N+1] is the CSR row pointer (the extent of a cut row - which
+ * wavefronts hold its carries - is read from it); every row that has a position in
+ * [e_begin, e_end) must lie inside it completely (true for the whole graph and for a
+ * destination-range shard).  Workspace: n_edges = e_end - e_begin. */
 size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes, int64_t n_edges);
-int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end,
+int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end, const int32_t* indptr,
                           const int32_t* row_of, const int32_t* eid, const float* logits,
                           int logits_in_csr_order, float* out, float* out_csr, void* workspace,
                           size_t workspace_bytes, kgat_stream_t stream);

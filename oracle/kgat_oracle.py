@@ -286,6 +286,22 @@ def fold_tiles(rel_ptr, gid, gptr, cap):
     return np.asarray(tiles, dtype=np.int32).reshape(-1, 4), np.asarray(rel_tptr, dtype=np.int32)
 
 
+def fold_tile_parts(tiles, n_parts, cost):
+    """Cost-balanced split of the fused attention kernel's tiles over its workgroups, restated
+    (include/kgat_hip.h kgat_fold_tile_parts): tile cost ``c_tile + (c_first * min(P, 64) + c_later *
+    max(P - 64, 0)) // 64`` with P the tile's positions; part b starts at the first tile whose
+    exclusive cost prefix reaches ``total * b // n_parts``.  Returns part_tptr (n_parts+1,)."""
+    tiles = np.asarray(tiles, dtype=np.int64).reshape(-1, 4)
+    c_tile, c_first, c_later = cost
+    P = tiles[:, 3] - tiles[:, 2]
+    first = np.minimum(P, 64)
+    c = c_tile + (c_first * first + c_later * (P - first)) // 64
+    prefix = np.concatenate([[0], np.cumsum(c)])
+    total = int(prefix[-1])
+    out = [int(np.searchsorted(prefix[:len(tiles) + 1], total * b // n_parts, side="left")) for b in range(n_parts)]
+    return np.asarray(out + [len(tiles)], dtype=np.int32)
+
+
 # ---------------------------------------------------------------------------- evaluation
 def recall_ndcg_per_user(embedding, train_user_dict, test_user_dict, all_item_id_range, K):
     """``calc_recall_ndcg`` restated user by user (reference ``metric.py:36-68`` with

@@ -82,9 +82,14 @@ def main():
             algos = algos + ["folded"]
         if ops.att_score_fused_supported(n, D, D, R):
             for cap in (64, 128, 192, 256):
-                tl, tp = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap)
+                tl, tp, pp = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap)
                 print("fold tiles cap %d: %d (base %d)" % (cap, int(tp[-1]), (n_groups + 15) // 16))
-                fns["fused%d_csr" % cap] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False)
+                fns["fused%d_csr" % cap] = lambda tl=tl, tp=tp, pp=pp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False, part_tptr=pp)
+                fns["fused%d_csr_even" % cap] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False)
+                if cap == 128:
+                    for cost in ((64, 8, 16), (64, 8, 64), (64, 16, 32), (64, 0, 0)):
+                        pc = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap, cost=cost)[2]
+                        fns["fused128_cost%d_%d_%d" % cost] = lambda tl=tl, tp=tp, pc=pc: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False, part_tptr=pc)
             fns["fused"] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel)
             algos = algos + ["fused"]
         if ops.att_score_split_supported(n, D, D, R):
@@ -114,7 +119,7 @@ def main():
     elif args.kernel == "spmm":
         X = torch.randn(n, D, generator=g).to(dev)
         logits = torch.randn(E, generator=g).to(dev)
-        _, w_csr = ops.edge_softmax(n, row_of, eid, logits, want_out=False, want_csr=True)
+        _, w_csr = ops.edge_softmax(indptr, row_of, eid, logits, want_out=False, want_csr=True)
         order = ops.row_order_by_degree(indptr)
         out = torch.empty(n, D, device=dev)
         ws = ops.spmm_workspace(E, D, dev)
@@ -214,10 +219,10 @@ def main():
             print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, {True: "fused kernels", False: "torch ops"}.get(fused, "fused kernels + torch's fused Adam"), dt * 1e3))
     else:
         logits = torch.randn(E, generator=g).to(dev)
-        fns = {"softmax_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True),
-               "softmax_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True),
-               "3pass_eid": lambda: ops.edge_softmax(n, row_of, eid, logits, want_out=True, want_csr=True, three_pass=True),
-               "3pass_csr": lambda: ops.edge_softmax(n, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True, three_pass=True)}
+        fns = {"softmax_eid": lambda: ops.edge_softmax(indptr, row_of, eid, logits, want_out=True, want_csr=True),
+               "softmax_csr": lambda: ops.edge_softmax(indptr, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True),
+               "3pass_eid": lambda: ops.edge_softmax(indptr, row_of, eid, logits, want_out=True, want_csr=True, three_pass=True),
+               "3pass_csr": lambda: ops.edge_softmax(indptr, row_of, eid, logits, in_csr_order=True, want_out=False, want_csr=True, three_pass=True)}
         res = timeit(fns, args.rounds)
         b = 12 * E + 4 * n
         for a, t in res.items():

@@ -18,7 +18,7 @@ from dgl_kgat_amd import _lib, ops, synth  # noqa: E402
 so = "/tmp/libkgat_hip_stamps.so"
 srcs = [os.path.join(_lib.CSRC, s) for s in _lib.SOURCES]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
-subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + ["-DKGAT_SPMM_STAMPS"] + extra + ["-shared", "-o", so] + srcs)
+subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + ["-DKGAT_SPMM_STAMPS", '-DKGAT_BUILD_HASH="kgat-src-hash:%s"' % _lib.source_hash()] + extra + ["-shared", "-o", so] + srcs)
 print("build flags:", extra)
 _lib.SO_PATH = so
 _lib._lib = None

@@ -171,24 +171,24 @@ def test_edge_softmax_vs_oracle(K, dev, name, n, e, hub, iso):
     s[: min(e, 4)] = [80.0, -80.0, 0.0, -0.0][: min(e, 4)]
     ref = orc.edge_softmax(n, dst, s)
     indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
-    out, out_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
+    out, out_csr = ops.edge_softmax(indptr, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
     out, out_csr = out.cpu().numpy(), out_csr.cpu().numpy()
     assert np.all(np.isfinite(out))
     assert rel_err(out, ref) < TOL
     assert np.array_equal(out_csr, out[eid.cpu().numpy()])
     # CSR-ordered input gives the same bits
     s_csr = ops.gather(eid, tf(s, dev))
-    out2, _ = ops.edge_softmax(n, row_of, eid, s_csr, in_csr_order=True, want_out=True)
+    out2, _ = ops.edge_softmax(indptr, row_of, eid, s_csr, in_csr_order=True, want_out=True)
     assert np.array_equal(out2.cpu().numpy(), out)
     # every non-empty destination's weights sum to one; shift invariance per destination
     sums = np.zeros(n)
     np.add.at(sums, dst, out.astype(np.float64))
     assert np.allclose(sums[np.bincount(dst, minlength=n) > 0], 1.0, atol=1e-5)
     shift = rng.standard_normal(n).astype(np.float32)[dst] * 3
-    out3, _ = ops.edge_softmax(n, row_of, eid, tf(s + shift, dev))
+    out3, _ = ops.edge_softmax(indptr, row_of, eid, tf(s + shift, dev))
     assert rel_err(out3.cpu().numpy(), ref) < 5e-4  # the shifted fp32 logits round differently
     # reproducible bit for bit
-    out4, _ = ops.edge_softmax(n, row_of, eid, tf(s, dev))
+    out4, _ = ops.edge_softmax(indptr, row_of, eid, tf(s, dev))
     assert np.array_equal(out4.cpu().numpy(), out)
 
 
@@ -212,10 +212,10 @@ def test_edge_softmax_range_boundaries_and_hubs(K, dev, e):
         s = (rng.standard_normal(e) * 5).astype(np.float32)
         ref = orc.edge_softmax(n, dst, s)
         indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
-        out, out_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
+        out, out_csr = ops.edge_softmax(indptr, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
         assert rel_err(out.cpu().numpy(), ref) < TOL, layout
         assert torch.equal(out_csr, out[eid.long()])
-        old, old_csr = ops.edge_softmax(n, row_of, eid, tf(s, dev), want_out=True, want_csr=True, three_pass=True)
+        old, old_csr = ops.edge_softmax(indptr, row_of, eid, tf(s, dev), want_out=True, want_csr=True, three_pass=True)
         assert rel_err(out.cpu().numpy(), old.cpu().numpy()) < 1e-5, layout
         # a destination-range shard: positions [indptr[lo], indptr[hi]) only
         ip = indptr.cpu().numpy()
@@ -223,7 +223,7 @@ def test_edge_softmax_range_boundaries_and_hubs(K, dev, e):
             e0, e1 = int(ip[lo]), int(ip[hi])
             if e1 == e0:
                 continue
-            _, part_csr = ops.edge_softmax(n, row_of, eid, ops.gather(eid, tf(s, dev)), in_csr_order=True,
+            _, part_csr = ops.edge_softmax(indptr, row_of, eid, ops.gather(eid, tf(s, dev)), in_csr_order=True,
                                            e_range=(e0, e1), want_out=False, want_csr=True)
             # (other range boundaries: the cut rows are combined in another association)
             assert rel_err(part_csr[e0:e1].cpu().numpy(), out_csr[e0:e1].cpu().numpy()) < 1e-6, (layout, lo, hi)
@@ -234,7 +234,7 @@ def test_edge_softmax_known_answers(K, dev):
     src = np.array([1, 2, 3, 0], np.int32)
     dst = np.array([0, 0, 2, 3], np.int32)
     indptr, col, eid, row_of = ops.csr_from_coo(5, t32(src, dev), t32(dst, dev))
-    a, _ = ops.edge_softmax(5, row_of, eid, tf([0.3, 0.3, -7.0, 80.0], dev))
+    a, _ = ops.edge_softmax(indptr, row_of, eid, tf([0.3, 0.3, -7.0, 80.0], dev))
     assert np.array_equal(a.cpu().numpy(), np.array([0.5, 0.5, 1.0, 1.0], np.float32))
 
 
@@ -357,12 +357,16 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
     et[et == 1] = 2  # an empty relation in the middle
     rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
     gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
-    tiles, rel_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap)
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=37, cost=(64, 8, 32))
     o_tiles, o_tptr = orc.fold_tiles(rel_ptr.cpu().numpy(), gid.cpu().numpy(), gptr.cpu().numpy(), cap)
     assert np.array_equal(rel_tptr.cpu().numpy(), o_tptr)
     n_tiles = int(o_tptr[-1])
     assert n_tiles <= tiles.shape[0] and np.array_equal(tiles.cpu().numpy()[:n_tiles], o_tiles)
     assert np.all(o_tiles[:, 3] - o_tiles[:, 2] <= cap)
+    # the cost-balanced split over workgroups: bit-exact against its restatement, monotone, complete
+    o_parts = orc.fold_tile_parts(o_tiles, 37, (64, 8, 32))
+    assert np.array_equal(part_tptr.cpu().numpy(), o_parts) and o_parts[0] == 0 and o_parts[-1] == n_tiles
+    assert np.all(np.diff(o_parts) >= 0)
     ent = rng.standard_normal((n, d)).astype(np.float32)
     W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
     rel = rng.standard_normal((R, d)).astype(np.float32)
@@ -371,11 +375,16 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
                                          tf(ent, dev), tf(W, dev), tf(rel, dev), folded=True)
     for want_eid in (True, False):
         fused, fused_csr = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
-                                               tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=want_eid)
+                                               tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=want_eid,
+                                               part_tptr=part_tptr)
         # (another lane split of the d-length dot product than the two-launch form: fp32 rounding apart)
         assert rel_err_inf(fused_csr.cpu().numpy(), fold_csr.cpu().numpy()) < 2e-6
         if want_eid:
             assert torch.equal(fused_csr, fused[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].long()])
+        # which workgroup computes a tile does not enter its arithmetic: any split gives the same bits
+        even = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                   tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=False)[1]
+        assert torch.equal(even, fused_csr)
     assert rel_err_inf(fused_csr.cpu().numpy(), ref[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].cpu().numpy()]) < 1e-5
 
 
@@ -387,14 +396,14 @@ def test_att_fused_small_and_single_relation(K, dev):
         et = rng.integers(lo, R, e).astype(np.int32)
         rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
         gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
-        tiles, rel_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=64)
+        tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=64)
         d = 32
         ent = rng.standard_normal((n, d)).astype(np.float32)
         W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
         rel = rng.standard_normal((R, d)).astype(np.float32)
         ref = orc.att_score(ent, W, rel, src, dst, et)
         fused, fused_csr = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
-                                               tf(ent, dev), tf(W, dev), tf(rel, dev))
+                                               tf(ent, dev), tf(W, dev), tf(rel, dev), part_tptr=part_tptr)
         _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
         assert rel_err_inf(fused.cpu().numpy(), ref) < 1e-5, (n, e, R)
         assert np.all(fused.cpu().numpy()[et < 0] == 0)
@@ -636,7 +645,7 @@ def test_full_size_properties(K, dev):
     assert np.array_equal(np.sort(eid_h), np.arange(e)) and np.array_equal(dst[eid_h], row_of.cpu().numpy())
     gen = torch.Generator(device="cpu").manual_seed(1)
     s = torch.randn(e, generator=gen).to(dev) * 3
-    a, a_csr = ops.edge_softmax(n, row_of, eid, s, want_out=True, want_csr=True)
+    a, a_csr = ops.edge_softmax(indptr, row_of, eid, s, want_out=True, want_csr=True)
     ones = torch.ones((n, 64), device=dev)
     unity = ops.spmm(indptr, col, row_of, ones, a_csr, algo="merge")
     nonempty = torch.as_tensor(np.diff(ip) > 0, device=dev)
@@ -674,9 +683,11 @@ def test_full_size_attention_forms(K, dev):
     st = g._st
     groups = st.rel_groups(g.edata["type"], R)
     args = (n, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g, groups.gid, groups.gptr, groups.g_node)
-    tiles, tptr = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups)
+    tiles, tptr, parts = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups)
     assert int(tptr[-1]) <= tiles.shape[0] and int(tptr[-1]) >= (groups.n_groups + 15) // 16
-    fused, _ = ops.att_score_fused(*args, tiles, tptr, ent, W, rel, want_csr=False)
+    assert int(parts[0]) == 0 and int(parts[-1]) == int(tptr[-1]) and bool((parts[1:] >= parts[:-1]).all())
+    fused, _ = ops.att_score_fused(*args, tiles, tptr, ent, W, rel, want_csr=False, part_tptr=parts)
+    assert torch.equal(fused, ops.att_score_fused(*args, tiles, tptr, ent, W, rel, want_csr=False)[0])
     folded, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False, folded=True)
     split, _ = ops.att_score_split(*args, groups.n_groups, ent, W, rel, want_csr=False)
     one, _ = ops.att_score(n, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g, ent, W, rel)

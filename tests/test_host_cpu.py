@@ -194,6 +194,50 @@ def test_balanced_bounds_and_shards_cover_graph():
         assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(len(trip)))
 
 
+def test_lazy_edge_weights_mechanics():
+    """lazy.LazyEdgeWeights: metadata never triggers the deferred fill, any value-level operation
+    triggers it exactly once (before the operation runs), frames accept it, autograd functions
+    pass the very object through forward and saved_tensors."""
+    from dgl_kgat_amd.lazy import LazyEdgeWeights, pending_csr_weights
+    calls, st = [], object()
+    base, src = torch.empty(5, 1), torch.arange(5.0).reshape(5, 1)
+
+    def fill():
+        calls.append(1)
+        base.copy_(src)
+    w = LazyEdgeWeights(base, fill, st, "csr-copy")
+    assert isinstance(w, torch.Tensor) and w.shape == (5, 1) and w.dim() == 2 and len(w) == 5 and w.dtype == torch.float32
+    assert w.device.type == "cpu" and w.is_contiguous() and w.numel() == 5 and not w.requires_grad and not calls
+    g = _toy_graph()
+    g.edata["w"] = w                      # Frame checks type, dim and length only
+    assert g.edata["w"] is w and w.pending and pending_csr_weights(w, st) == "csr-copy"
+    assert pending_csr_weights(w, object()) is None and pending_csr_weights(torch.zeros(1), st) is None
+
+    class Pass(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, ww):
+            assert ww is w and ww.pending
+            ctx.save_for_backward(x, ww)
+            return x * 1
+
+        @staticmethod
+        def backward(ctx, grad):
+            assert ctx.saved_tensors[1] is w and w.pending
+            return grad, None
+    x = torch.ones(5, 1, requires_grad=True)
+    Pass.apply(x, w).sum().backward()
+    assert not calls
+    flat = w.reshape(-1)                  # value-level: fill first, result is an ordinary tensor
+    assert calls == [1] and type(flat) is torch.Tensor and flat.tolist() == [0, 1, 2, 3, 4] and not w.pending
+    assert pending_csr_weights(w, st) is None and float(w.sum()) == 10 and calls == [1]
+    assert w.data_ptr() == base.data_ptr()
+    for op in (lambda t: t.cpu(), lambda t: t.data_ptr(), lambda t: repr(t), lambda t: torch.cat([t, t]),
+               lambda t: t[0], lambda t: t.detach(), lambda t: t.numpy(), lambda t: t.add_(1)):
+        hits = []
+        op(LazyEdgeWeights(torch.zeros(3, 1), lambda: hits.append(1), st, None))
+        assert hits == [1], op
+
+
 def test_shard_layer_refuses_autograd():
     """A destination-range shard is forward-only: under autograd the layer raises instead of
     returning a result whose gradients would silently miss the aggregation and the exchange."""
