@@ -184,6 +184,50 @@ __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(int64_t n_rows, 
   }
 }
 
+// The concatenated readout of Model.gnn (reference models.py:159-168: [h0 | normalize(h1) | ...])
+// from separately held blocks in one pass: a 16-lane group per row walks the blocks, 16 bytes per
+// lane, normalising where asked.  Used where the layers' rows come back from the multi-GPU exchange
+// (one launch instead of one normalisation per layer plus the copy of the ego block).
+constexpr int kMaxReadoutBlocks = 8;
+struct ReadoutBlocks {
+  const float* ptr[kMaxReadoutBlocks];
+  int width[kMaxReadoutBlocks];
+  int normalize[kMaxReadoutBlocks];
+  int n;
+};
+__global__ __launch_bounds__(256) void readout_concat_kernel(int64_t n_rows, ReadoutBlocks b, float* __restrict__ out,
+                                                             int64_t out_stride) {
+  const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + sub; row < n_rows; row += (int64_t)gridDim.x * 16) {
+    float* o = out + (size_t)row * out_stride;
+    for (int k = 0; k < b.n; ++k) {
+      const int w = b.width[k];
+      const float4* xr = reinterpret_cast<const float4*>(b.ptr[k] + (size_t)row * w);
+      float4 v[2];
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {  // widths up to 128: two float4 per lane
+        const int c = sl + 16 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * c < w) v[j] = xr[c];
+        ss = fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, fmaf(v[j].w, v[j].w, ss))));
+      }
+      float inv = 1.f;
+      if (b.normalize[k]) inv = 1.0f / fmaxf(sqrtf(row16_sum_d(ss)), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = sl + 16 * j;
+        if (4 * c < w) {
+          float4 r = v[j];
+          if (b.normalize[k]) r = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+          *reinterpret_cast<float4*>(o + 4 * c) = r;
+        }
+      }
+      o += w;
+    }
+  }
+}
+
 struct DropArgs {
   uint32_t threshold = 0;
   float keep_scale = 1.f;
@@ -289,6 +333,31 @@ int kgat_l2_normalize_rows_f32(int64_t n_rows, int d, const float* x, float* out
   hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n_rows, d,
                      x, out, out_stride);
   KGAT_CHECK_LAUNCH("l2_normalize_rows");
+  return KGAT_OK;
+}
+
+int kgat_readout_concat_f32(int64_t n_rows, int n_blocks, const float* const* blocks, const int* widths,
+                            const int* normalize, float* out, int64_t out_stride, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_blocks > 0 && n_blocks <= kMaxReadoutBlocks, "readout_concat: bad size");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(blocks && widths && normalize && out, "readout_concat: null pointer");
+  ReadoutBlocks b;
+  int64_t total = 0;
+  for (int k = 0; k < n_blocks; ++k) {
+    KGAT_CHECK_ARG(blocks[k] && widths[k] > 0 && widths[k] <= 128 && widths[k] % 4 == 0,
+                   "readout_concat: block widths must be multiples of 4 up to 128");
+    KGAT_CHECK_ARG((reinterpret_cast<uintptr_t>(blocks[k]) & 15u) == 0, "readout_concat: blocks must be 16-byte aligned");
+    b.ptr[k] = blocks[k]; b.width[k] = widths[k]; b.normalize[k] = normalize[k];
+    total += widths[k];
+  }
+  b.n = n_blocks;
+  KGAT_CHECK_ARG(out_stride >= total && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0,
+                 "readout_concat: out must be 16-byte aligned with a row stride that is a multiple of 4 floats");
+  int64_t nb = (n_rows + 15) / 16;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(readout_concat_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), n_rows, b, out,
+                     out_stride);
+  KGAT_CHECK_LAUNCH("readout_concat");
   return KGAT_OK;
 }
 

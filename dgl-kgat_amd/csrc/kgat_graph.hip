@@ -224,9 +224,9 @@ int radix_sort_index(const int32_t* keys_in, int64_t n, int key_bits, int32_t* v
 }
 
 // ---- cost-balanced split of the fused attention kernel's tiles over its workgroups
-// cost[t] = c_tile + (c_first * min(P, 64) + c_later * max(P - 64, 0)) / 64, P = positions of tile t
+// cost[t] = c_tile + c_chunk * ceil(max(P - 64, 0) / 64) + (t opens its relation ? c_rel : 0), P = positions of tile t
 __global__ void fold_tile_cost_kernel(int64_t t_max, int n_rel, const int32_t* __restrict__ rel_tptr,
-                                      const int4* __restrict__ tiles, int c_tile, int c_first, int c_later,
+                                      const int4* __restrict__ tiles, int c_tile, int c_chunk, int c_rel,
                                       int32_t* __restrict__ cost) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > t_max) return;
@@ -234,8 +234,8 @@ __global__ void fold_tile_cost_kernel(int64_t t_max, int n_rel, const int32_t* _
   if (t < rel_tptr[n_rel]) {
     const int4 d = tiles[t];
     const int32_t P = d.w - d.z;
-    const int32_t first = P < 64 ? P : 64;
-    c = c_tile + (c_first * first + c_later * (P - first)) / 64;
+    const int32_t later = P > 64 ? (P - 64 + 63) >> 6 : 0;
+    c = c_tile + c_chunk * later + (rel_tptr[d.x] == (int32_t)t ? c_rel : 0);
   }
   cost[t] = c;
 }
@@ -631,11 +631,11 @@ size_t kgat_fold_tile_parts_workspace_bytes(int64_t t_max) {
 }
 
 int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const int32_t* rel_tptr, int n_parts,
-                         int cost_tile, int cost_first, int cost_later, int32_t* part_tptr, void* workspace,
+                         int cost_tile, int cost_chunk, int cost_relation, int32_t* part_tptr, void* workspace,
                          size_t workspace_bytes, kgat_stream_t stream) {
   KGAT_CHECK_ARG(t_max >= 0 && t_max < INT32_MAX - 1 && n_rel > 0 && n_parts > 0, "fold_tile_parts: bad size");
-  KGAT_CHECK_ARG(cost_tile > 0 && cost_first >= 0 && cost_later >= 0 && cost_tile <= 4096 && cost_first <= 4096 &&
-                 cost_later <= 4096, "fold_tile_parts: cost coefficients must lie in [0, 4096], cost_tile > 0");
+  KGAT_CHECK_ARG(cost_tile > 0 && cost_chunk >= 0 && cost_relation >= 0 && cost_tile <= 256 && cost_chunk <= 256 &&
+                 cost_relation <= 65536, "fold_tile_parts: cost coefficients out of range");
   KGAT_CHECK_ARG(tiles && rel_tptr && part_tptr && workspace, "fold_tile_parts: null pointer");
   if (workspace_bytes < kgat_fold_tile_parts_workspace_bytes(t_max)) {
     set_error("fold_tile_parts: workspace too small");
@@ -646,7 +646,7 @@ int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const i
   int32_t* cost = cv.take<int32_t>((size_t)t_max + 1);
   int32_t* scan_ws = cv.take<int32_t>(scan_workspace_elems(t_max + 1));
   hipLaunchKernelGGL(fold_tile_cost_kernel, dim3(blocks_for(t_max + 1, 256)), dim3(256), 0, st, t_max, n_rel, rel_tptr,
-                     reinterpret_cast<const int4*>(tiles), cost_tile, cost_first, cost_later, cost);
+                     reinterpret_cast<const int4*>(tiles), cost_tile, cost_chunk, cost_relation, cost);
   KGAT_CHECK_LAUNCH("fold_tile_cost");
   const int rc = exclusive_scan_i32(cost, t_max + 1, scan_ws, st);
   if (rc != KGAT_OK) return rc;

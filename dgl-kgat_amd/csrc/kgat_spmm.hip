@@ -434,7 +434,19 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
       const int32_t bo = __shfl(b, src, kWave);
       const int so = __shfl(s, src, kWave);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int32_t bb = bo + q; bb <= bl; bb += SPW) {
+      int32_t bb = bo + q;
+      constexpr int U = 8;  // partials requested together (the chain of a 10^5-edge row has hundreds)
+      for (; bb + (U - 1) * SPW <= bl; bb += U * SPW) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t t = bb + u * SPW;
+          v[u] = bpart[((size_t)t * 2 + ((t == bo) ? so : 0)) * LPR + sl];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = add4(acc, v[u]);
+      }
+      for (; bb <= bl; bb += SPW) {
         const int slot = (bb == bo) ? so : 0;
         acc = add4(acc, bpart[((size_t)bb * 2 + slot) * LPR + sl]);
       }
@@ -547,19 +559,30 @@ struct SpmmArgs {
 };
 
 // C: edges per lane-group run in the merge kernels; tiles are NSUB * C <= 2048 edges (the
-// LDS record stage of the second form holds one tile)
+// LDS record stage of the second form holds one tile).  A launch over few edges - a destination
+// shard of a multi-GPU run holds E/P of them - takes the short run length: a tile is walked
+// serially by its lane groups, so a launch cannot be shorter than one tile's time (~25 us at
+// C = 64, which is what a 458 k-edge shard's launch took: a third of the whole graph's time for an
+// eighth of its edges); a quarter of the run length gives four times the tiles, each a quarter as long.
 constexpr int run_len(int lpr) { return lpr >= 8 ? 64 : (lpr == 4 ? 32 : (lpr == 2 ? 16 : 8)); }
+constexpr int short_run_len(int lpr) { return run_len(lpr) / 4 >= 4 ? run_len(lpr) / 4 : 4; }
+constexpr int64_t kShortRunTileLimit = 4096;  // use the short runs while they give at most this many tiles
 
-template <int LPR>
-static int64_t merge_tiles(int64_t n_edges) {
-  constexpr int TE = SpmmGeom<LPR>::NSUB * run_len(LPR);
+template <int LPR, int C>
+static int64_t merge_tiles_c(int64_t n_edges) {
+  constexpr int TE = SpmmGeom<LPR>::NSUB * C;
   return (n_edges + TE - 1) / TE;
 }
 
-template <int LPR, bool MUL_SELF, bool HAS_EID>
-static int launch_merge(const SpmmArgs& a) {
+template <int LPR>
+static bool use_short_runs(int64_t n_edges) {
+  return merge_tiles_c<LPR, short_run_len(LPR)>(n_edges) <= kShortRunTileLimit;
+}
+
+template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
+static int launch_merge_c(const SpmmArgs& a) {
   const int64_t e0 = a.e0_host, e1 = a.e1_host;
-  const int64_t tiles = merge_tiles<LPR>(e1 - e0);
+  const int64_t tiles = merge_tiles_c<LPR, C>(e1 - e0);
   const size_t need = (size_t)tiles * 2 * LPR * sizeof(float4);
   if (tiles > 0 && (a.ws == nullptr || a.ws_bytes < need)) {
     set_error("spmm: workspace too small (%zu < %zu)", a.ws_bytes, need);
@@ -568,11 +591,11 @@ static int launch_merge(const SpmmArgs& a) {
   float4* bpart = static_cast<float4*>(a.ws);
   if (tiles > 0) {
     if (!HAS_EID && a.algo != KGAT_SPMM_ALGO_MERGE1) {
-      hipLaunchKernelGGL((spmm_merge2_kernel<LPR, run_len(LPR), MUL_SELF>), dim3((unsigned)tiles),
+      hipLaunchKernelGGL((spmm_merge2_kernel<LPR, C, MUL_SELF>), dim3((unsigned)tiles),
                          dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
                          (const float4*)a.X, a.w, (float4*)a.out, bpart);
     } else {
-      hipLaunchKernelGGL((spmm_merge_kernel<LPR, run_len(LPR), MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
+      hipLaunchKernelGGL((spmm_merge_kernel<LPR, C, MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
                          dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
                          a.eid, (const float4*)a.X, a.w, (float4*)a.out, bpart);
     }
@@ -583,12 +606,19 @@ static int launch_merge(const SpmmArgs& a) {
   int64_t nz_blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
-  hipLaunchKernelGGL((spmm_finish_kernel<LPR, run_len(LPR), MUL_SELF>),
+  hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF>),
                      dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kSpmmThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
                      (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks);
   KGAT_CHECK_LAUNCH("spmm_finish");
   return KGAT_OK;
+}
+
+template <int LPR, bool MUL_SELF, bool HAS_EID>
+static int launch_merge(const SpmmArgs& a) {
+  if (use_short_runs<LPR>((int64_t)a.e1_host - a.e0_host))
+    return launch_merge_c<LPR, short_run_len(LPR), MUL_SELF, HAS_EID>(a);
+  return launch_merge_c<LPR, run_len(LPR), MUL_SELF, HAS_EID>(a);
 }
 
 template <int LPR, bool MUL_SELF, bool HAS_EID>
@@ -675,8 +705,10 @@ size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   const int lpr = lpr_for(D);
   if (lpr == 0 || n_edges <= 0) return 256;
   const int nsub = kSpmmThreads / lpr;
-  const int64_t te = (int64_t)nsub * run_len(lpr);
-  const int64_t tiles = (n_edges + te - 1) / te;
+  const int64_t te = (int64_t)nsub * run_len(lpr), te_s = (int64_t)nsub * short_run_len(lpr);
+  int64_t tiles = (n_edges + te - 1) / te;
+  const int64_t tiles_s = (n_edges + te_s - 1) / te_s;
+  if (tiles_s <= kShortRunTileLimit && tiles_s > tiles) tiles = tiles_s;  // the launch takes the short runs
   return align_up((size_t)tiles * 2 * lpr * sizeof(float4), 256) + 256;
 }
 

@@ -480,9 +480,10 @@ class DGLGraph:
         ~0.156 ms per 1e6 groups + 0.038 ms per 1e6 edges, one-kernel 0.153 ms per 1e6 edges -> the
         group forms win below ~0.74 groups per edge).  Between the two folded forms: the fused
         kernel recomputes a 16-group block's vectors once per `cap` positions, so it wins while its
-        tile count stays near the minimum ceil(n_groups / 16) (amazon-book-shaped CKG: 1.16x,
-        fused 0.25 vs 0.29 ms) and loses when large groups inflate it (last-fm-shaped: ~4x, folded
-        0.155 vs 0.195 ms); the threshold is 2x.  ``KGAT_ATT_FORM=race`` times the two instead
+        tile count stays near the minimum ceil(n_groups / 16) and loses when large groups inflate
+        it.  With 256 positions per tile and the cost-balanced split it wins on both benchmark
+        shapes (amazon-book: 1.04x the minimum, 0.192 vs 0.278 ms; last-fm: 1.87x, 0.126 vs
+        0.137 ms); the threshold stays at 2x.  ``KGAT_ATT_FORM=race`` times the two instead
         (opt-in: a wall-clock race is not reproducible across processes)."""
         st = self._st
         shares = 4 * groups.n_groups <= 3 * st.n_edges

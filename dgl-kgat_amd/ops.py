@@ -237,11 +237,16 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
     return logits, logits_csr
 
 
-FOLD_TILE_CAP = 128  # measured best on MI355X (64: 0.268, 128: 0.251, 192: 0.261, 256: 0.283 ms)
-# per-tile cost model of the fused kernel, in units of ~90 shader cycles: the MFMA phase of a tile
-# (~5,800 cycles), its first 64 positions (rows requested before the MFMA phase: ~10 cycles each),
-# positions past the first 64 (no row look-ahead: ~50 cycles each)
-FOLD_TILE_COST = (64, 8, 32)
+# positions per tile of the fused kernel: a 16-group block with more positions is cut and every
+# piece recomputes the block's V rows (1,459 ticks) where walking on would cost 267 ticks per 64
+# positions, so pieces should be long - but one wave walks a piece alone, and a piece must stay a
+# small part of its workgroup's time for the eight waves to balance.  Measured on MI355X with the
+# cost-balanced split (amazon-book-shaped CKG): 128: 0.2135 ms, 256: 0.2019.
+FOLD_TILE_CAP = 256
+# per-tile cost model of the fused kernel (kgat_fold_tile_parts; units of ~23 ticks of workgroup
+# time, from per-workgroup clock stamps: scripts/micro/att_stamps.py): a tile, a chunk of 64
+# positions past the first 64, a relation change inside a workgroup's range
+FOLD_TILE_COST = (64, 12, 466)
 
 
 def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, cost=FOLD_TILE_COST):
@@ -532,6 +537,30 @@ def l2_normalize_rows(x, out):
     return out
 
 
+def readout_concat(blocks, normalize, out=None):
+    """[b0 | b1 | ...] with the blocks flagged in `normalize` L2-normalised per row
+    (kgat_readout_concat_f32): the readout of Model.gnn from separately held layer outputs."""
+    import ctypes as C
+    n = blocks[0].shape[0]
+    widths = []
+    for i, b in enumerate(blocks):
+        _need(b, torch.float32, "blocks[%d]" % i)
+        if b.dim() != 2 or b.shape[0] != n:
+            raise ValueError("blocks must be (n, w_i) matrices with the same n")
+        widths.append(int(b.shape[1]))
+    if out is None:
+        out = torch.empty((n, sum(widths)), dtype=torch.float32, device=blocks[0].device)
+    else:
+        out = _need(out, torch.float32, "out", (n, sum(widths)))
+    k = len(blocks)
+    ptrs = (C.c_void_p * k)(*[b.data_ptr() for b in blocks])
+    w_arr = (C.c_int * k)(*widths)
+    f_arr = (C.c_int * k)(*[1 if f else 0 for f in normalize])
+    check(_lib.load().kgat_readout_concat_f32(n, k, ptrs, w_arr, f_arr, _ptr(out), out.stride(0), _stream(out)),
+          "kgat_readout_concat_f32")
+    return out
+
+
 def sddmm_dot(src, dst, X, G):
     X = _need(X, torch.float32, "X")
     G = _need(G, torch.float32, "grad_out")
@@ -547,5 +576,5 @@ def sddmm_dot(src, dst, X, G):
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
            "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
-           "bi_interaction", "bi_interaction_supported", "l2_normalize_rows",
+           "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]

@@ -61,19 +61,33 @@ class Partition:
         self.mode = mode or os.environ.get("KGAT_EXCHANGE", "allreduce")
         if self.mode not in EXCHANGE_MODES:
             raise ValueError("exchange mode %r is not one of %s" % (self.mode, EXCHANGE_MODES))
+        self.exchange_enabled = True  # False: the collective is skipped (local-time probes on one GPU)
+        self._bufs = {}
 
     def _global_rank(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
-    def new_buffer(self, width, device, dtype=torch.float32):
-        """The N x width exchange buffer; zeroed only where the exchange mode sums."""
-        alloc = torch.zeros if self.mode == "allreduce" else torch.empty
-        return alloc((self.n_nodes, width), dtype=dtype, device=device)
+    def new_buffer(self, width, device, dtype=torch.float32, slot=None):
+        """The N x width exchange buffer, zeroed where the exchange mode sums: only the rows this
+        rank does not own (the owned rows are about to be overwritten).  `slot` (an int) makes the
+        buffer a persistent one of this partition, reused by every later call with the same width
+        and slot - for callers that consume the assembled rows before they ask again."""
+        if slot is None:
+            full = torch.empty((self.n_nodes, width), dtype=dtype, device=device)
+        else:
+            key = (width, str(device), dtype, slot)
+            full = self._bufs.get(key)
+            if full is None:
+                full = self._bufs[key] = torch.empty((self.n_nodes, width), dtype=dtype, device=device)
+        if self.mode == "allreduce" and self.world > 1:
+            full[:self.lo].zero_()
+            full[self.hi:].zero_()
+        return full
 
     def assemble(self, full):
         """Complete `full` (N x width, this rank's rows already in place) with the other ranks'
         rows, in place."""
-        if self.world == 1:
+        if self.world == 1 or not self.exchange_enabled:
             return full
         b = self.bounds
         if self.mode == "allreduce":
@@ -123,16 +137,16 @@ class Partition:
         """One KGATConv on a shard + the all-reduce of its D_out-wide result."""
         return self.exchange(self.propagate_local(g, h, weight), weight.shape[0])
 
-    def propagate_fused(self, g, h, weight):
+    def propagate_fused(self, g, h, weight, slot=None):
         """Forward-only form of `propagate` with fewer launches: the owned rows of
         LeakyReLU((h*h_N) W2^T) are written by the bi-interaction kernel straight into the
-        exchange buffer, then exchanged."""
+        exchange buffer, then exchanged.  `slot`: see new_buffer."""
         st = g._st
         csr = st.csr(h.device)
         w_csr = st.csr_weights(g.edata["w"])
         prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
                         rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
-        full = self.new_buffer(weight.shape[0], h.device)
+        full = self.new_buffer(weight.shape[0], h.device, slot=slot)
         if self.hi > self.lo:
             ops.bi_interaction(prod, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
         return self.assemble(full)

@@ -175,13 +175,18 @@ int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t*
 /* Split of the tiles over the n_parts workgroups of the fused kernel (graph-static, like the
  * tiles): part b owns the contiguous tile range [part_tptr[b], part_tptr[b+1]), chosen on the
  * prefix sum of a per-tile cost
- *   cost_tile + (cost_first * min(P, 64) + cost_later * max(P - 64, 0)) / 64,  P = positions of the tile
- * so that every workgroup gets the same cost, not the same tile count (a tile's MFMA phase is
- * constant, its edge phase grows with P, and positions past the first 64 run without row
- * look-ahead).  t_max = number of rows of `tiles`; part_tptr[n_parts + 1]. */
+ *   cost_tile + cost_chunk * ceil(max(P - 64, 0) / 64) + (the tile opens its relation ? cost_relation : 0)
+ * (P = positions of the tile) so that every workgroup gets the same cost, not the same tile
+ * count.  The form follows what per-workgroup clock stamps showed on MI355X (least squares over
+ * 3,072 workgroup samples, 1 % rms residual): a tile's MFMA phase is a constant (1,459 ticks of
+ * workgroup time), its first 64 positions are free (their rows arrive during the MFMA phase),
+ * every further chunk of 64 positions costs 267 ticks, and a relation change inside a
+ * workgroup's range - W_r reload, two barriers, the prefetch pipeline of eight waves restarting -
+ * costs 10,630 ticks, as much as seven tiles.  t_max = number of rows of `tiles`;
+ * part_tptr[n_parts + 1]. */
 size_t kgat_fold_tile_parts_workspace_bytes(int64_t t_max);
 int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const int32_t* rel_tptr, int n_parts,
-                         int cost_tile, int cost_first, int cost_later, int32_t* part_tptr, void* workspace,
+                         int cost_tile, int cost_chunk, int cost_relation, int32_t* part_tptr, void* workspace,
                          size_t workspace_bytes, kgat_stream_t stream);
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
 /* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
@@ -276,6 +281,14 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
  * multi-GPU exchange and the fused kernel above could not normalise them. */
 int kgat_l2_normalize_rows_f32(int64_t n_rows, int d, const float* x, float* out, int64_t out_stride,
                                kgat_stream_t stream);
+
+/* The concatenated readout of Model.gnn (reference models.py:159-168: [h0 | normalize(h1) | ...]) from
+ * n_blocks (<= 8) separately held row-major blocks in one pass: block k is n_rows x widths[k]
+ * (widths multiples of 4, <= 128; `blocks` and `widths` are HOST arrays, the pointers in `blocks`
+ * device pointers), copied as is or L2-normalised per row (normalize[k] != 0, eps 1e-12) into
+ * columns [sum of the earlier widths, +widths[k]) of `out` (row stride out_stride floats). */
+int kgat_readout_concat_f32(int64_t n_rows, int n_blocks, const float* const* blocks, const int* widths,
+                            const int* normalize, float* out, int64_t out_stride, kgat_stream_t stream);
 
 /* Permute a per-edge array: out[i] = in[index[i]]. */
 int kgat_gather_f32(int64_t n, const int32_t* index, const float* in, float* out,

@@ -286,16 +286,19 @@ def fold_tiles(rel_ptr, gid, gptr, cap):
     return np.asarray(tiles, dtype=np.int32).reshape(-1, 4), np.asarray(rel_tptr, dtype=np.int32)
 
 
-def fold_tile_parts(tiles, n_parts, cost):
+def fold_tile_parts(tiles, rel_tptr, n_parts, cost):
     """Cost-balanced split of the fused attention kernel's tiles over its workgroups, restated
-    (include/kgat_hip.h kgat_fold_tile_parts): tile cost ``c_tile + (c_first * min(P, 64) + c_later *
-    max(P - 64, 0)) // 64`` with P the tile's positions; part b starts at the first tile whose
-    exclusive cost prefix reaches ``total * b // n_parts``.  Returns part_tptr (n_parts+1,)."""
+    (include/kgat_hip.h kgat_fold_tile_parts): tile cost ``c_tile + c_chunk * ceil(max(P - 64, 0) / 64)
+    + (c_rel if the tile opens its relation)`` with P the tile's positions; part b starts at the
+    first tile whose exclusive cost prefix reaches ``total * b // n_parts``.  Returns part_tptr
+    (n_parts+1,)."""
     tiles = np.asarray(tiles, dtype=np.int64).reshape(-1, 4)
-    c_tile, c_first, c_later = cost
+    rel_tptr = np.asarray(rel_tptr, dtype=np.int64)
+    c_tile, c_chunk, c_rel = cost
     P = tiles[:, 3] - tiles[:, 2]
-    first = np.minimum(P, 64)
-    c = c_tile + (c_first * first + c_later * (P - first)) // 64
+    later = np.where(P > 64, (P - 64 + 63) // 64, 0)
+    opens = rel_tptr[tiles[:, 0]] == np.arange(len(tiles))
+    c = c_tile + c_chunk * later + np.where(opens, c_rel, 0)
     prefix = np.concatenate([[0], np.cumsum(c)])
     total = int(prefix[-1])
     out = [int(np.searchsorted(prefix[:len(tiles) + 1], total * b // n_parts, side="left")) for b in range(n_parts)]

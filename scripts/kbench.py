@@ -81,15 +81,15 @@ def main():
             fns["folded_csr"] = lambda: ops.att_score_split(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, n_groups, ent, W, rel, g_tab=g_tab, folded=True, want_eid=False)
             algos = algos + ["folded"]
         if ops.att_score_fused_supported(n, D, D, R):
-            for cap in (64, 128, 192, 256):
+            for cap in (128, 256, 512):
                 tl, tp, pp = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap)
                 print("fold tiles cap %d: %d (base %d)" % (cap, int(tp[-1]), (n_groups + 15) // 16))
                 fns["fused%d_csr" % cap] = lambda tl=tl, tp=tp, pp=pp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False, part_tptr=pp)
                 fns["fused%d_csr_even" % cap] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False)
-                if cap == 128:
-                    for cost in ((64, 8, 16), (64, 8, 64), (64, 16, 32), (64, 0, 0)):
+                if cap == 256:
+                    for cost in ((64, 12, 0), (64, 12, 233), (64, 12, 700), (64, 8, 466), (64, 16, 466)):
                         pc = ops.fold_tiles(rp2, gid, gptr, n_groups, cap=cap, cost=cost)[2]
-                        fns["fused128_cost%d_%d_%d" % cost] = lambda tl=tl, tp=tp, pc=pc: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False, part_tptr=pc)
+                        fns["fused256_cost%d_%d_%d" % cost] = lambda tl=tl, tp=tp, pc=pc: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel, want_eid=False, part_tptr=pc)
             fns["fused"] = lambda tl=tl, tp=tp: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel)
             algos = algos + ["fused"]
         if ops.att_score_split_supported(n, D, D, R):

@@ -48,10 +48,11 @@ ent = torch.randn(n, D, generator=g).to(dev)
 W = ((torch.rand(R, D, D, generator=g) - 0.5) * (2 * 1.414 * (6 / (D * D + R * D)) ** 0.5)).to(dev)
 rel = torch.randn(R, D, generator=g).to(dev)
 n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
-variants = [("equal tile counts", None)] + [("cost %s" % (c,), c) for c in ((64, 8, 32), (64, 8, 16), (64, 8, 64), (64, 16, 48), (64, 4, 24))]
-for cap in (128,):
+variants = [("equal tile counts", None)] + [("cost %s" % (c,), c) for c in ((64, 12, 466), (64, 12, 0), (64, 12, 233), (64, 8, 466), (64, 16, 700))]
+fit_rows, fit_y = [], []
+for cap in (256, 512):
     for name, cost in variants:
-        tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups, cap=cap, cost=cost or (64, 8, 32))
+        tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups, cap=cap, cost=cost or (64, 12, 466))
         pt = parts if cost else None
         fn = lambda: ops.att_score_fused(n, rp, perm, sg, idx, gid, gptr, g_node, tiles, tptr, ent, W, rel,  # noqa: E731
                                          want_eid=False, part_tptr=pt)
@@ -75,3 +76,19 @@ for cap in (128,):
               "max %.0f  max/mean %.3f | last end - first start %.0f"
               % (cap, name, ms, dur.min(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(),
                  dur.max() / dur.mean(), st[:, 1].max() - t0))
+        # regressors of the workgroup's busy time: tiles, first-chunk positions, later positions, later chunks, relations
+        tl = tiles.cpu().numpy()[:int(tptr[-1])].astype(np.int64)
+        pp = (pt if pt is not None else torch.as_tensor([len(tl) * b // n_wg for b in range(n_wg + 1)])).cpu().numpy()
+        P = tl[:, 3] - tl[:, 2]
+        feats = np.stack([np.ones_like(P), np.minimum(P, 64), np.maximum(P - 64, 0), (np.maximum(P - 64, 0) + 63) // 64], 1).astype(np.float64)
+        cs = np.concatenate([np.zeros((1, 4)), np.cumsum(feats, 0)])
+        rows = cs[pp[1:]] - cs[pp[:-1]]
+        nrel = np.array([len(np.unique(tl[pp[b]:pp[b + 1], 0])) if pp[b + 1] > pp[b] else 0 for b in range(n_wg)], dtype=np.float64)
+        fit_rows.append(np.concatenate([rows, nrel[:, None], np.ones((n_wg, 1))], 1))
+        fit_y.append(dur)
+A, y = np.concatenate(fit_rows), np.concatenate(fit_y)
+coef, res, _, _ = np.linalg.lstsq(A, y, rcond=None)
+pred = A @ coef
+print("least squares over %d workgroup samples: ticks = %.0f*tiles + %.1f*first_pos + %.1f*later_pos + %.0f*later_chunks "
+      "+ %.0f*relations + %.0f ; rms residual %.0f (%.1f%% of mean)"
+      % (len(y), *coef, np.sqrt(np.mean((pred - y) ** 2)), 100 * np.sqrt(np.mean((pred - y) ** 2)) / y.mean()))

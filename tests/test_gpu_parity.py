@@ -139,6 +139,30 @@ def test_spmm_vs_oracle(K, dev, D, name, n, e, hub, iso):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 128, 256])
+def test_spmm_long_runs_every_width(K, dev, D):
+    """Launches over few edges take a quarter of the run length (kgat_spmm.hip: short_run_len), so
+    the graphs above exercise the short runs; this one is large enough (4.3 M edges) for the full
+    run length at every width, hubs and empty rows included."""
+    from dgl_kgat_amd import ops
+    n, e = 20000, 4_300_000
+    src, dst = random_graph(31, n, e, hub=600_000, isolated_tail=500)
+    rng = np.random.default_rng(32)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(e).astype(np.float32)
+    ref = orc.spmm_u_mul_e_sum_sparse(n, src, dst, X, w)
+    ref_abs = orc.spmm_u_mul_e_sum_sparse(n, src, dst, np.abs(X), w)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w_csr = ops.gather(eid, tf(w, dev))
+    for algo in ("merge", "merge1"):
+        out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, algo=algo)
+        assert sum_err(out.cpu().numpy(), ref, ref_abs) < TOL, algo
+        assert torch.equal(out, ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, algo=algo))
+    out = ops.spmm(indptr, col, row_of, tf(X, dev), w_csr, mul_self=True).cpu().numpy()
+    assert sum_err(out, ref * X, ref_abs * np.abs(X)) < TOL
+    assert np.all(out[np.diff(indptr.cpu().numpy()) == 0] == 0)
+
+
 def test_spmm_row_range_shard(K, dev):
     """Destination-range shard: rows [lo, hi) with their CSR position range (multi-GPU layout)."""
     from dgl_kgat_amd import ops
@@ -357,14 +381,14 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
     et[et == 1] = 2  # an empty relation in the middle
     rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
     gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
-    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=37, cost=(64, 8, 32))
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=37, cost=(64, 12, 466))
     o_tiles, o_tptr = orc.fold_tiles(rel_ptr.cpu().numpy(), gid.cpu().numpy(), gptr.cpu().numpy(), cap)
     assert np.array_equal(rel_tptr.cpu().numpy(), o_tptr)
     n_tiles = int(o_tptr[-1])
     assert n_tiles <= tiles.shape[0] and np.array_equal(tiles.cpu().numpy()[:n_tiles], o_tiles)
     assert np.all(o_tiles[:, 3] - o_tiles[:, 2] <= cap)
     # the cost-balanced split over workgroups: bit-exact against its restatement, monotone, complete
-    o_parts = orc.fold_tile_parts(o_tiles, 37, (64, 8, 32))
+    o_parts = orc.fold_tile_parts(o_tiles, o_tptr, 37, (64, 12, 466))
     assert np.array_equal(part_tptr.cpu().numpy(), o_parts) and o_parts[0] == 0 and o_parts[-1] == n_tiles
     assert np.all(np.diff(o_parts) >= 0)
     ent = rng.standard_normal((n, d)).astype(np.float32)
@@ -628,6 +652,22 @@ def test_destination_shards_reassemble_to_unsharded(K, dev):
         ops.l2_normalize_rows(x, wide[:, 4:52])
         assert torch.allclose(wide[:, 4:52], torch.nn.functional.normalize(x, dim=1), atol=1e-6)
         assert torch.all(wide[:, :4] == 3.0) and torch.all(wide[:, 52:] == 3.0) and torch.all(wide[7, 4:52] == 0)
+
+
+def test_readout_concat(K, dev):
+    """kgat_readout_concat_f32: [h0 | normalize(h1) | ...] (models.py:159-168) from separate blocks."""
+    from dgl_kgat_amd import ops
+    torch.manual_seed(9)
+    for n in (1, 15, 16, 17, 4099):
+        blocks = [torch.randn(n, w, device=dev) for w in (64, 128, 32, 16, 4)]
+        blocks[2][n // 2] = 0  # an all-zero row normalises to zeros (eps clamp)
+        flags = [False, True, True, True, False]
+        out = ops.readout_concat(blocks, flags)
+        ref = torch.cat([torch.nn.functional.normalize(b, p=2, dim=1) if f else b for b, f in zip(blocks, flags)], 1)
+        assert out.shape == ref.shape and torch.allclose(out, ref, atol=1e-6) and torch.isfinite(out).all()
+        assert torch.equal(out[:, :64], blocks[0]) and torch.equal(out[:, -4:], blocks[4])
+    with pytest.raises(Exception):
+        ops.readout_concat([torch.randn(4, 6, device=dev)], [True])  # width not a multiple of 4
 
 
 def test_full_size_properties(K, dev):
