@@ -9,9 +9,9 @@ from . import function  # noqa: F401
 from .graph import ALL, DGLError, DGLGraph  # noqa: F401
 from .softmax import edge_softmax  # noqa: F401
 from .kgat_layer import KGATConv, KGATPropagation  # noqa: F401
-from .compat import install_as_dgl  # noqa: F401
+from .compat import accelerate, install_as_dgl  # noqa: F401
 from .ckg_io import CKGDataset  # noqa: F401
 from ._lib import KGATLibraryError  # noqa: F401
 
 __all__ = ["DGLGraph", "DGLError", "ALL", "function", "edge_softmax", "KGATConv", "KGATPropagation",
-           "install_as_dgl", "KGATLibraryError", "CKGDataset"]
+           "install_as_dgl", "accelerate", "KGATLibraryError", "CKGDataset"]

@@ -31,3 +31,51 @@ def install_as_dgl(force=False):
             "dgl.nn.pytorch.softmax": softmax, "dgl.nn.pytorch.conv": conv}
     sys.modules.update(mods)
     return pkg
+
+
+def accelerate(model):
+    """Route a reference-shaped model's two hot-path methods to the fused kernels, in place.
+
+    `model` is an instance of the reference's ``models.Model`` (unmodified; constructed with
+    ``gnn_model="kgat"``, ``use_KG=True``) or anything with the same attribute layout:
+    ``entity_embed``, ``relation_embed``, ``W_R``, ``layers[i].res_fc_2`` / ``.mess_drop``.  After
+    the call
+
+    * ``model.compute_attention(g)`` (models.py:146-154) is one fused attention-logit launch + the
+      destination softmax (``DGLGraph.kgat_attention``) instead of R rounds of ``filter_edges`` /
+      ``apply_edges`` through Python (72 ms -> 0.26 ms on the amazon-book-shaped CKG), and
+    * ``model.gnn(g, x)`` (models.py:156-168) is the aggregation with the ``h * h_N`` epilogue +
+      the bi-interaction kernel per layer (the whole stack as one autograd unit when gradients
+      are enabled)
+
+    with the same parameters (shared, not copied), the same call signatures and the same results.
+    This is the one line a maintainer adds after ``model = Model(...)`` in kgat.py:95-98; the
+    reference's files stay as they are.  Returns the model."""
+    import types
+
+    from .kgat_layer import KGATPropagation
+
+    for attr in ("entity_embed", "relation_embed", "W_R", "layers"):
+        if not hasattr(model, attr):
+            raise TypeError("accelerate(): the model has no attribute %r (not a KGAT Model)" % attr)
+    for layer in model.layers:
+        if not (hasattr(layer, "res_fc_2") and hasattr(layer, "mess_drop")):
+            raise TypeError("accelerate(): layer %s is not a bi-interaction KGATConv (gnn_model='kgat', res_type='Bi')"
+                            % type(layer).__name__)
+    if getattr(model, "_use_KG", True) is False:
+        raise TypeError("accelerate(): use_KG=False models build their input from item/user projections; outside the path")
+    if not hasattr(model, "_n_entities") or model._n_entities is None:
+        model._n_entities = model.entity_embed.weight.shape[0]
+
+    def gnn(self, g, x=None, fused=None):
+        return KGATPropagation.gnn(self, g, x, fused)
+
+    def compute_attention(self, g, algo="auto"):
+        return KGATPropagation.compute_attention(self, g, algo)
+
+    for name in ("_can_fuse_readout", "_can_fuse_training", "_gnn_fused", "_gnn_fused_sharded", "_node_embeddings"):
+        setattr(model, name, types.MethodType(getattr(KGATPropagation, name), model))
+    model.gnn = types.MethodType(gnn, model)
+    model.compute_attention = types.MethodType(compute_attention, model)
+    model._kgat_accelerated = True
+    return model

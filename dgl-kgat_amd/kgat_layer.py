@@ -152,7 +152,8 @@ class KGATPropagation(nn.Module):
         h = self._node_embeddings(g)
         node_embed_cache = [h]
         for layer in self.layers:
-            h = layer(g, h, fused=fused)
+            # (a reference-shaped model routed here by compat.accelerate has the reference's own layers)
+            h = layer(g, h, fused=fused) if isinstance(layer, KGATConv) else layer(g, h)
             node_embed_cache.append(F.normalize(h, p=2, dim=1))
         return torch.cat(node_embed_cache, 1)
 

@@ -318,3 +318,78 @@ def test_lazy_edge_weights_on_device(dev):
         half = m.layers[0](g, m.entity_embed.weight, fused=True)
         g.edata["w"] = a
         assert torch.allclose(m.layers[0](g, m.entity_embed.weight, fused=True), half, atol=1e-7)
+
+
+def test_accelerate_reference_shaped_model(dev):
+    """compat.accelerate on a model with the reference Model's attribute layout and call signatures
+    (models.py:72-111,135-168; the reference's own file cannot travel to this box): the routed
+    compute_attention / gnn give what the surface call sequence gives, parameters are shared, the
+    training path produces gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import function as fn, synth
+
+    class RefConv(nn.Module):  # the layout of the reference's KGATConv (models.py:49-70), surface calls only
+        def __init__(self, i, o, p):
+            super().__init__()
+            self.mess_drop = nn.Dropout(p)
+            self._res_type = "Bi"
+            self.res_fc_2 = nn.Linear(i, o, bias=False)
+
+        def forward(self, g, nfeat):
+            g = g.local_var()
+            g.ndata["h"] = nfeat
+            g.update_all(fn.u_mul_e("h", "w", "m"), fn.sum("m", "h_neighbor"))
+            return self.mess_drop(F.leaky_relu(self.res_fc_2(torch.mul(g.ndata["h"], g.ndata["h_neighbor"]))))
+
+    class RefModel(nn.Module):
+        def __init__(self, n, R, d):
+            super().__init__()
+            self._use_KG, self._n_entities, self._n_relations = True, n, R
+            self.entity_embed, self.relation_embed = nn.Embedding(n, d), nn.Embedding(R, d)
+            self.W_R = nn.Parameter(torch.empty(R, d, d))
+            nn.init.xavier_uniform_(self.W_R, gain=nn.init.calculate_gain("relu"))
+            self.layers = nn.ModuleList([RefConv(d, d, 0.0), RefConv(d, d // 2, 0.0)])
+
+        def _att_score(self, edges):
+            t_r = torch.matmul(self.entity_embed(edges.src["id"]), self.W_r)
+            h_r = torch.matmul(self.entity_embed(edges.dst["id"]), self.W_r)
+            return {"att_w": torch.bmm(t_r.unsqueeze(1), torch.tanh(h_r + self.relation_embed(edges.data["type"])).unsqueeze(2)).squeeze(-1)}
+
+        def compute_attention(self, g):
+            g = g.local_var()
+            for i in range(self._n_relations):
+                e_idxs = g.filter_edges(lambda edges: edges.data["type"] == i)
+                self.W_r = self.W_R[i]
+                g.apply_edges(self._att_score, e_idxs)
+            return K.edge_softmax(g, g.edata.pop("att_w"))
+
+        def gnn(self, g, x):
+            g = g.local_var()
+            h = self.entity_embed(g.ndata["id"])
+            cache = [h]
+            for layer in self.layers:
+                h = layer(g, h)
+                cache.append(F.normalize(h, p=2, dim=1))
+            return torch.cat(cache, 1)
+
+    n, trip, R = synth.amazon_book_ckg(scale=0.02)
+    torch.manual_seed(4)
+    m = RefModel(n, R, 32).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    with torch.no_grad():
+        a_ref = m.compute_attention(g)
+        g.edata["w"] = a_ref
+        out_ref = m.gnn(g, g.ndata["id"])
+    w_before = m.W_R
+    assert K.accelerate(m) is m and m.W_R is w_before
+    with torch.no_grad():
+        a = m.compute_attention(g)
+        assert rel_err(a.cpu().numpy(), a_ref.cpu().numpy()) < 1e-4
+        g.edata["w"] = a
+        out = m.gnn(g, g.ndata["id"])
+        assert out.shape == out_ref.shape and float((out - out_ref).abs().max()) < 1e-5 * float(out_ref.abs().max())
+    loss = m.gnn(g, g.ndata["id"]).pow(2).sum()   # gradients enabled: the fused training stack
+    loss.backward()
+    assert m.entity_embed.weight.grad is not None and float(m.layers[0].res_fc_2.weight.grad.abs().sum()) > 0

@@ -352,6 +352,18 @@ def test_unmodified_reference_model_over_the_surface():
             model = model.float()
             with pytest.raises(K.KGATLibraryError):
                 model.compute_attention(graph)  # edge_softmax needs the HIP device
+            # one added line routes the unmodified Model's compute_attention / gnn to the fused kernels
+            # (here, without a device, they must fail in the kernel wrappers - not fall back to torch)
+            calls = []
+            orig = K.DGLGraph.kgat_attention
+            K.DGLGraph.kgat_attention = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+            try:
+                assert K.accelerate(model) is model and model._kgat_accelerated
+                with pytest.raises(K.KGATLibraryError):
+                    model.compute_attention(graph)
+                assert calls == [1]
+            finally:
+                K.DGLGraph.kgat_attention = orig
             graph.edata["w"] = torch.as_tensor(g["attention"], dtype=torch.float32)
             with pytest.raises(K.KGATLibraryError):
                 model.gnn(graph, graph.ndata["id"])  # update_all needs the HIP device
