@@ -185,9 +185,16 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
 // LDS: one 5 KB patch per wavefront, used for the logits, then the row ids, then the results
 // (40 KB per workgroup with two patches limited a CU to 3 workgroups = 768 of the benchmark
 // graph's 895: a second, almost empty round doubled the kernel's time).
-constexpr int kSmEPL = 16;                // positions per lane
-constexpr int kSmEPW = kWave * kSmEPL;    // positions per wavefront
-constexpr int kSmPad = 20;                // floats per lane in the LDS patch (16 + 4: conflict-free b128)
+// positions per lane: 16 (1,024 per wavefront), or 8 for launches over fewer than kSmSmallEdges
+// positions, where the sweep is a latency chain (load, transpose, scans, store) rather than a
+// stream and twice the wavefronts with half the chain each finish sooner (amazon-book graph: sweep
+// 22 -> 17 us, cut rows 13 -> 12 us; 4 per lane was slower again: 36 us for both)
+constexpr int kSmMaxEPL = 16;
+constexpr int64_t kSmSmallEdges = 8 << 20;
+template <int EPL> struct SmGeom {
+  static constexpr int EPW = kWave * EPL;   // positions per wavefront
+  static constexpr int Pad = EPL + 4;       // floats per lane in the LDS patch (conflict-free b128 for 8 and 16)
+};
 constexpr float kSmNegBig = -3.0e38f;     // stands in for -inf (keeps the combine NaN-free)
 
 struct __attribute__((aligned(16))) SmCarry {
@@ -227,11 +234,12 @@ __device__ __forceinline__ void sm_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool IN_CSR>
+template <bool IN_CSR, int kSmEPL>
 __global__ __launch_bounds__(256) void softmax_local_kernel(
     int64_t e0, int64_t e1, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
     const int32_t* __restrict__ eid, const float* __restrict__ logits, float* __restrict__ out,
     float* __restrict__ out_csr, SmCarry* __restrict__ carry) {
+  constexpr int kSmEPW = SmGeom<kSmEPL>::EPW, kSmPad = SmGeom<kSmEPL>::Pad;
   __shared__ __attribute__((aligned(16))) float s_patch[256 / kWave][kWave * kSmPad];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
   const int64_t w = sm_wave_index();
@@ -262,8 +270,8 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   // transpose through the wave's patch: the logits, then (same patch) the row ids
 #pragma unroll
   for (int j = 0; j < kSmEPL; ++j) {
-    const int idx = j * kWave + lane;  // owner lane idx / 16, slot idx % 16
-    px[(idx >> 4) * kSmPad + (idx & 15)] = xs[j];
+    const int idx = j * kWave + lane;  // owner lane idx / EPL, slot idx % EPL
+    px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)] = xs[j];
   }
   sm_wave_sync();
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
 #pragma unroll
   for (int j = 0; j < kSmEPL; ++j) {
     const int idx = j * kWave + lane;
-    pr[(idx >> 4) * kSmPad + (idx & 15)] = rs[j];
+    pr[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)] = rs[j];
   }
   sm_wave_sync();
 #pragma unroll
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   for (int j = 0; j < kSmEPL; ++j) {
     const int64_t p = base + j * kWave + lane;
     const int idx = j * kWave + lane;
-    const float a = px[(idx >> 4) * kSmPad + (idx & 15)];
+    const float a = px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)];
     if (p >= skip_lo && p < skip_hi) {
       if (out_csr) out_csr[p] = a;
       if (out) out[eid ? eid[p] : p] = a;
@@ -452,10 +460,11 @@ __device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float
   }
 }
 
-template <bool IN_CSR>
+template <bool IN_CSR, int kSmEPL>
 __global__ __launch_bounds__(256) void softmax_cut_rows_kernel(
     int64_t e0, int64_t e1, const int32_t* __restrict__ eid, const float* __restrict__ logits,
     float* __restrict__ out, float* __restrict__ out_csr, const SmCarry* __restrict__ carry) {
+  constexpr int kSmEPW = SmGeom<kSmEPL>::EPW;
   const int lane = threadIdx.x % kWave;
   const int64_t w = sm_wave_index();
   const int64_t base = e0 + w * kSmEPW;
@@ -522,11 +531,24 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int32_t n_rows, int32_
 
 using namespace kgat;
 
+template <bool IN_CSR, int EPL>
+static void launch_softmax_sweep(int64_t e_begin, int64_t e_end, const int32_t* indptr, const int32_t* row_of,
+                                 const int32_t* eid, const float* logits, float* out, float* out_csr, SmCarry* carry,
+                                 hipStream_t st) {
+  const int64_t n_waves = (e_end - e_begin + SmGeom<EPL>::EPW - 1) / SmGeom<EPL>::EPW;
+  const unsigned blocks = (unsigned)((n_waves + 3) / 4);
+  hipLaunchKernelGGL((softmax_local_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
+                     eid, logits, out, out_csr, carry);
+  hipLaunchKernelGGL((softmax_cut_rows_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
+                     out, out_csr, (const SmCarry*)carry);
+}
+
 extern "C" {
 
 size_t kgat_edge_softmax_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
   (void)n_nodes;
-  const size_t n_waves = (size_t)((n_edges > 0 ? n_edges : 0) + kSmEPW - 1) / kSmEPW;
+  constexpr int kMinEPW = SmGeom<8>::EPW;  // the shortest range any launch uses: the most carry entries
+  const size_t n_waves = (size_t)((n_edges > 0 ? n_edges : 0) + kMinEPW - 1) / kMinEPW;
   return align_up((2 * n_waves + 2) * sizeof(SmCarry), 256);
 }
 
@@ -548,18 +570,13 @@ int kgat_edge_softmax_f32(int64_t n_nodes, int64_t e_begin, int64_t e_end, const
   }
   hipStream_t st = as_stream(stream);
   SmCarry* carry = static_cast<SmCarry*>(workspace);
-  const int64_t n_waves = (ne + kSmEPW - 1) / kSmEPW;
-  const unsigned blocks = (unsigned)((n_waves + 3) / 4);
+  const bool small = ne < kSmSmallEdges;
   if (logits_in_csr_order) {
-    hipLaunchKernelGGL(softmax_local_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
-                       eid, logits, out, out_csr, carry);
-    hipLaunchKernelGGL(softmax_cut_rows_kernel<true>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
-                       out, out_csr, (const SmCarry*)carry);
+    if (small) launch_softmax_sweep<true, 8>(e_begin, e_end, indptr, row_of, eid, logits, out, out_csr, carry, st);
+    else launch_softmax_sweep<true, 16>(e_begin, e_end, indptr, row_of, eid, logits, out, out_csr, carry, st);
   } else {
-    hipLaunchKernelGGL(softmax_local_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
-                       eid, logits, out, out_csr, carry);
-    hipLaunchKernelGGL(softmax_cut_rows_kernel<false>, dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
-                       out, out_csr, (const SmCarry*)carry);
+    if (small) launch_softmax_sweep<false, 8>(e_begin, e_end, indptr, row_of, eid, logits, out, out_csr, carry, st);
+    else launch_softmax_sweep<false, 16>(e_begin, e_end, indptr, row_of, eid, logits, out, out_csr, carry, st);
   }
   KGAT_CHECK_LAUNCH("edge_softmax");
   return KGAT_OK;
