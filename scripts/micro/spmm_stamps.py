@@ -28,8 +28,10 @@ lib.kgat_debug_set_spmm_stamps.argtypes = [C.c_void_p]
 
 dev = torch.device("cuda:0")
 same_rows = "--same-rows" in sys.argv
-n, trip, R = synth.amazon_book_ckg()
-E, D = len(trip), 64
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
+D = int(args[0]) if args else 64
+n, trip, R = synth.last_fm_ckg() if (len(args) > 1 and args[1] == "last-fm") else synth.amazon_book_ckg()
+E = len(trip)
 src = torch.as_tensor(trip[:, 2].copy(), device=dev)
 dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
 indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
@@ -37,7 +39,8 @@ if same_rows:
     col = col % 16
 X = torch.randn(n, D, device=dev)
 w = torch.rand(E, device=dev)
-tiles = (E + 1023) // 1024
+te = (256 // (D // 4)) * (64 if D >= 32 else (32 if D == 16 else (16 if D == 8 else 8)))
+tiles = (E + te - 1) // te
 stamps = torch.zeros(tiles * 8, dtype=torch.int64, device=dev)
 out = torch.empty(n, D, device=dev)
 for _ in range(3):
