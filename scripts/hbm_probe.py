@@ -22,7 +22,13 @@ def main():
     launches = int(sys.argv[4]) if len(sys.argv) > 4 else 20
     mul_self = os.environ.get("PROBE_MUL_SELF", "1") == "1"
     dev = torch.device("cuda:0")
-    src, dst, _ = synth.power_law_coo_device(n, e, 64, dev, cap=cap)
+    if cap == "numpy":
+        _, trip, _ = synth.power_law_ckg(n, e, 64)
+        src = torch.as_tensor(trip[:, 2].copy(), device=dev)
+        dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
+        del trip
+    else:
+        src, dst, _ = synth.power_law_coo_device(n, e, 64, dev, cap=cap)
     indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
     deg = (indptr[1:] - indptr[:-1])
     print("cap=%s N=%d E=%d max deg %d zero rows %d rows>1024 %d edges in rows>1024 %.3f" % (
@@ -33,6 +39,18 @@ def main():
     gen.manual_seed(99)
     X = torch.randn((n, 64), generator=gen, device=dev)
     w = torch.rand(e, generator=gen, device=dev)
+    if os.environ.get("PROBE_SOFTMAX_W"):
+        w = ops.edge_softmax(indptr, row_of, torch.arange(e, dtype=torch.int32, device=dev), w * 6, in_csr_order=True,
+                             want_out=False, want_csr=True)[1]
+    xv = os.environ.get("PROBE_X", "randn")
+    if xv == "zeros":
+        X.zero_()
+    elif xv == "small":
+        X.mul_(1e-3)
+    elif xv == "relu":
+        X.clamp_(min=0)
+    elif xv == "const":
+        X.fill_(0.37)
     out = torch.empty((n, 64), device=dev)
     ws = ops.spmm_workspace(e, 64, dev)
     for _ in range(5):
