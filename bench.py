@@ -240,8 +240,10 @@ def cpu_baseline_torch(n, trip, n_rel, params, n_layers, steps):
     """Second stand-in: the reference's own formulation in torch CPU ops - per
     relation a filter + two gathers + two GEMMs + tanh (models.py:135-152), the destination softmax
     from scatter/index_add segment ops, `torch.sparse_csr @ X` for update_all(u_mul_e, sum), Linear
-    + LeakyReLU + normalize - on every host core."""
-    torch.set_num_threads(os.cpu_count() or 1)
+    + LeakyReLU + normalize.  The thread count is the best of a short calibration (the first
+    relations of the attention loop at 8 ... all host threads): with every hardware thread of a
+    128-core box the many small per-relation ops spend their time synchronising (86-95 s per step at
+    256 threads), which would make the stand-in a strawman."""
     src = torch.as_tensor(trip[:, 2].astype(np.int64))
     dst = torch.as_tensor(trip[:, 0].astype(np.int64))
     et = torch.as_tensor(trip[:, 1].astype(np.int64))
@@ -271,11 +273,32 @@ def cpu_baseline_torch(n, trip, n_rel, params, n_layers, steps):
                 cache.append(torch.nn.functional.normalize(h, p=2, dim=1))
             return torch.cat(cache, 1), a
 
-    out, a = step()
+    def probe():  # the attention of the three largest relations: the dominant part of a step
+        with torch.no_grad():
+            for r in torch.bincount(et.clamp(0, n_rel - 1), minlength=n_rel).argsort(descending=True)[:3].tolist():
+                idx = torch.nonzero(et == r).reshape(-1)
+                (ent[src[idx]] @ W_R[r] * torch.tanh(ent[dst[idx]] @ W_R[r] + rel[r])).sum(1)
+
+    cands = sorted({c for c in (8, 16, 32, 64, 128, os.cpu_count() or 1) if c <= (os.cpu_count() or 1)})
+    best = None
+    for c in cands:
+        torch.set_num_threads(c)
+        probe()
+        t0 = time.perf_counter()
+        probe()
+        tc = time.perf_counter() - t0
+        if best is None or tc < best[0]:
+            best = (tc, c)
+    torch.set_num_threads(best[1])
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = (time.perf_counter() - t0) / max(steps, 1)
+    out, a = step()
+    first = time.perf_counter() - t0
+    dt = first
+    if first * steps < 30.0:  # bounded: repeat only while the stand-in stays within ~30 s
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = (time.perf_counter() - t0) / max(steps, 1)
     return dt, torch.get_num_threads(), out.numpy(), a.numpy()
 
 
@@ -529,8 +552,9 @@ def main():
         result["cpu_baseline"]["torch_restatement"] = {
             "value": round(args.layers * E / tdt, 1), "unit": "edges/s", "cores": tcores, "kind": "port",
             "ms_per_step": round(tdt * 1e3, 2),
-            "sample": "1 full step (after one warm-up step) in torch CPU ops: per-relation filter + gathers + GEMMs + "
-                      "tanh, scatter/index_add destination softmax, sparse_csr @ X, Linear/LeakyReLU/normalize",
+            "sample": "1 full step in torch CPU ops (per-relation filter + gathers + GEMMs + tanh, scatter/index_add "
+                      "destination softmax, sparse_csr @ X, Linear/LeakyReLU/normalize) at the thread count a short "
+                      "calibration found fastest (of 8 ... %d)" % (os.cpu_count() or 1),
             "vs_c_port_max_abs_diff": {"gnn_out_rel_to_max": float(np.max(np.abs(t_out - c_out))) / scale,
                                        "attention_abs": float(np.max(np.abs(t_a.reshape(-1) - c_a)))}}
         assert result["cpu_baseline"]["torch_restatement"]["vs_c_port_max_abs_diff"]["gnn_out_rel_to_max"] < 1e-4
