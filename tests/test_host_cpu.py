@@ -397,3 +397,68 @@ def test_all_edges_orders():
     assert list(zip(u.tolist(), v.tolist())) == [(0, 3), (1, 1), (2, 0), (2, 1)] and e.tolist() == [1, 3, 2, 0]
     with pytest.raises(Exception):
         g.all_edges(order="random")
+
+
+def test_device_graph_generator_on_cpu():
+    """synth.power_law_coo_device (torch RNG; runs on any device): both capping modes keep the
+    heaviest in-degree near the cap, ids in range, int32 outputs, seeded."""
+    n, e, cap = 200_000, 4_000_000, 20_000
+    for mode in ("redraw", "shift"):
+        s1, d1, t1 = synth.power_law_coo_device(n, e, 7, "cpu", seed=3, max_in_degree=cap, cap=mode)
+        s2, d2, t2 = synth.power_law_coo_device(n, e, 7, "cpu", seed=3, max_in_degree=cap, cap=mode)
+        assert torch.equal(d1, d2) and torch.equal(s1, s2) and torch.equal(t1, t2)
+        assert d1.dtype == s1.dtype == t1.dtype == torch.int32 and len(d1) == e
+        assert int(d1.min()) >= 0 and int(d1.max()) < n and int(s1.max()) < n and int(t1.max()) == 6
+        deg = np.bincount(d1.numpy(), minlength=n)
+        assert 0.8 * cap < deg.max() < 1.15 * cap, (mode, deg.max())
+        assert np.sort(deg)[-50:].mean() > 20 * np.median(deg[deg > 0])   # heavy tail
+    with pytest.raises(ValueError):
+        synth.power_law_coo_device(10, 10, 2, "cpu", cap="nope")
+
+
+def test_tile_parts_restatement_balances_cost():
+    from oracle import kgat_oracle as orc
+    rng = np.random.default_rng(5)
+    # three relations; tiles with 1..256 positions, a few heavy ones
+    tiles, rel_tptr, p = [], [0], 0
+    for r, cnt in enumerate((300, 5, 900)):
+        for _ in range(cnt):
+            w = int(rng.integers(1, 257)) if rng.random() < 0.2 else int(rng.integers(1, 65))
+            tiles.append((r, 0, p, p + w))
+            p += w
+        rel_tptr.append(len(tiles))
+    tiles = np.asarray(tiles)
+    cost = (64, 12, 466)
+    parts = orc.fold_tile_parts(tiles, rel_tptr, 16, cost)
+    assert parts[0] == 0 and parts[-1] == len(tiles) and np.all(np.diff(parts) >= 0) and len(parts) == 17
+    P = tiles[:, 3] - tiles[:, 2]
+    c = cost[0] + cost[1] * np.where(P > 64, (P - 64 + 63) // 64, 0) + np.where(np.isin(np.arange(len(tiles)), rel_tptr[:-1]), cost[2], 0)
+    per = np.array([c[parts[b]:parts[b + 1]].sum() for b in range(16)])
+    assert per.max() <= per.mean() + c.max() + 1   # within one tile of the mean
+    assert np.array_equal(orc.fold_tile_parts(tiles, rel_tptr, 1, cost), [0, len(tiles)])
+
+
+def test_bench_traffic_records_are_keyed_on_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py pairs a committed PMC figure with a timing only while the record's hash equals the
+    hash of the kernel sources beside the library."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    srcs = ("kgat_spmm.hip", "kgat_common.h")
+    h = bench.source_hash(*srcs)
+    assert len(h) == 16 and h == bench.source_hash(*srcs) and h != bench.source_hash("kgat_softmax.hip", "kgat_common.h")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r00_pmc_spmm_traffic.json").write_text(json.dumps({"kernel_source_sha16": "0" * 16, "traffic_bytes_per_launch": 1}))
+    (prof / "r01_pmc_spmm_traffic.json").write_text(json.dumps({"kernel_source_sha16": h, "traffic_bytes_per_launch": 42}))
+    (prof / "r02_pmc_spmm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 7}))   # no hash: never used
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "dgl-kgat_amd" / "csrc")
+    for f in srcs:
+        (tmp_path / "dgl-kgat_amd" / "csrc" / f).write_bytes(open(os.path.join(ROOT, "dgl-kgat_amd", "csrc", f), "rb").read())
+    assert bench.committed_traffic("pmc_spmm_traffic.json", srcs) == (42, "r01_pmc_spmm_traffic.json")
+    with open(tmp_path / "dgl-kgat_amd" / "csrc" / "kgat_spmm.hip", "ab") as fh:
+        fh.write(b"// edited\n")
+    assert bench.committed_traffic("pmc_spmm_traffic.json", srcs) == (None, None)
