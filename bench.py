@@ -123,11 +123,13 @@ def hbm_resident_spmm_leg(args, dev):
     # the same bytes: fresh allocations of the same size at the same virtual address fall into a fast
     # (9.2-9.4 ms) or a slow (10.3-10.5 ms) mode, allocation by allocation (scripts/placement_probe2.py;
     # DESIGN.md 3.1).  A long-lived table is allocated once, so the leg does what a deployment can do
-    # once: it draws a few candidate allocations, times two launches on each, keeps the fastest and
+    # once: it draws up to eight candidate allocations, times two launches on each, keeps the fastest and
     # frees the others - and reports every candidate's time, so the slow mode is on the line too.
     torch.cuda.empty_cache()
     X, trials, keep_alive = None, [], []
-    for _ in range(4):
+    for _ in range(8):
+        if len(trials) >= 2 and min(trials) < 0.94 * max(trials):
+            break  # both modes seen: the fastest candidate so far sits in a fast region
         cand = torch.empty((n, D), dtype=torch.float32, device=dev)
         cand.normal_(generator=gen)
         t_c = event_times(lambda: ops.spmm(indptr, col, row_of, cand, w, out=out, workspace=ws), 2)
