@@ -594,6 +594,8 @@ def main():
                 continue  # gloo stages device tensors through the host for send/recv: seconds per call, no information
             if mode == "allreduce" and bounds is even:
                 continue  # the all-reduce moves the whole buffer whatever the ownership
+            if mode == "allgather" and dist.get_backend() != "nccl" and len({bounds[r + 1] - bounds[r] for r in range(world)}) > 1:
+                continue  # gloo's all_gather wants equal slices
             q = partition.Partition(rank, world, bounds, n, g.partition.group, mode=mode)
 
             def one():

@@ -37,7 +37,7 @@ def balanced_row_bounds(in_degrees, world):
     return bounds
 
 
-EXCHANGE_MODES = ("allreduce", "p2p", "broadcast")
+EXCHANGE_MODES = ("allreduce", "p2p", "broadcast", "allgather")
 
 
 class Partition:
@@ -52,8 +52,12 @@ class Partition:
       straight into their place in the buffer (``batch_isend_irecv``: one grouped RCCL
       send/recv set, a direct xGMI link per pair).  Half the bytes of the all-reduce.
     * ``broadcast`` - one broadcast per owner of its slice (what an all-gather of unequal
-      slices amounts to).
-    All three leave the same bits in the buffer."""
+      slices amounts to), issued one after the other.
+    * ``allgather`` - ``dist.all_gather`` straight into the row slices of the buffer; with unequal
+      slices the RCCL backend runs the per-owner broadcasts as ONE group (concurrent, a direct
+      link per pair).  Backends that insist on equal slice sizes (gloo) only take it for an even
+      split of the rows.
+    All of them leave the same bits in the buffer."""
 
     def __init__(self, rank, world, bounds, n_nodes, group=None, mode=None):
         self.rank, self.world, self.bounds, self.n_nodes, self.group = rank, world, list(bounds), n_nodes, group
@@ -106,6 +110,9 @@ class Partition:
             if ops_:
                 for work in dist.batch_isend_irecv(ops_):
                     work.wait()
+        elif self.mode == "allgather":
+            dist.all_gather([full[b[r]:b[r + 1]] for r in range(self.world)], full[self.lo:self.hi].clone(),
+                            group=self.group)
         else:
             for owner in range(self.world):
                 if b[owner + 1] > b[owner]:

