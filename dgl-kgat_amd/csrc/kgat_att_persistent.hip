@@ -1032,7 +1032,12 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         const int4 d3 = desc_of(n3);                                                   \
         const int32_t h2 = head_idx(d2);                                               \
         const CIdx c1 = chunk_idx(d1, d1.z);                                           \
-        CIdx cx = chunk_idx(d0, d0.z + kWave);  /* second chunk's indices, if any */    \
+        /* indices of the second to fourth chunk (a tile of the default cap has at most */ \
+        /* four): requested before the MFMA phase, which hides their trip from HBM - in */ \
+        /* the step the index arrays were last read a whole pass ago                    */ \
+        CIdx cx = chunk_idx(d0, d0.z + kWave);                                         \
+        const CIdx cy = chunk_idx(d0, d0.z + 2 * kWave);                               \
+        const CIdx cz = chunk_idx(d0, d0.z + 3 * kWave);                               \
         EBuf eb0;                                                                      \
         load_edges(eb0, c0);                                                           \
         load_head(HNEXT, h1);                                                          \
@@ -1040,11 +1045,24 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         mfma_phase(HCUR);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
         edge_phase(eb0, c0, d0.z, d0.w);                                               \
-        for (int32_t p0 = d0.z + kWave; p0 < d0.w; p0 += kWave) {                      \
+        if (d0.z + kWave < d0.w) {                                                     \
           load_edges(eb0, cx);                                                         \
-          const CIdx cn = chunk_idx(d0, p0 + kWave);                                   \
-          edge_phase(eb0, cx, p0, d0.w);                                               \
-          cx = cn;                                                                     \
+          edge_phase(eb0, cx, d0.z + kWave, d0.w);                                     \
+          if (d0.z + 2 * kWave < d0.w) {                                               \
+            load_edges(eb0, cy);                                                       \
+            cx = chunk_idx(d0, d0.z + 4 * kWave);  /* fifth chunk (caps above 256) */   \
+            edge_phase(eb0, cy, d0.z + 2 * kWave, d0.w);                               \
+            if (d0.z + 3 * kWave < d0.w) {                                             \
+              load_edges(eb0, cz);                                                     \
+              edge_phase(eb0, cz, d0.z + 3 * kWave, d0.w);                             \
+              for (int32_t p0 = d0.z + 4 * kWave; p0 < d0.w; p0 += kWave) {            \
+                load_edges(eb0, cx);                                                   \
+                const CIdx cn = chunk_idx(d0, p0 + kWave);                             \
+                edge_phase(eb0, cx, p0, d0.w);                                         \
+                cx = cn;                                                               \
+              }                                                                        \
+            }                                                                          \
+          }                                                                            \
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
         d0 = d1; d1 = d2; d2 = d3;                                                     \

@@ -65,3 +65,27 @@ def step_sync():
 
 
 print("full step, host sync around attention:", timed(step_sync, 30))
+
+# which of the attention's inputs does the step evict?  Touch them (a read pass) before the launch.
+groups = g._st.rel_groups(g.edata["type"], R)
+tiles = groups.g_tab["tiles"]
+idx_arrays = [groups.src_g, groups.gid, groups.pos_g, groups.g_node, tiles[0]]
+ent = model.entity_embed.weight
+
+
+def step_touch(which):
+    with torch.no_grad():
+        out = model.gnn(g)
+        if which in ("indices", "both"):
+            for t in idx_arrays:
+                t.sum()
+        if which in ("table", "both"):
+            ent.sum()
+        a = model.compute_attention(g)
+        g.edata["w"] = a
+        return out
+
+
+for which in ("none", "indices", "table", "both"):
+    step_touch(which)
+    print("gnn, touch %-8s, attention:" % which, {k: round(v, 4) for k, v in timed(lambda: step_touch(which), 30).items() if k == "att_score"})
