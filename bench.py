@@ -130,6 +130,8 @@ def hbm_resident_spmm_leg(args, dev):
     for _ in range(8):
         if len(trials) >= 2 and min(trials) < 0.94 * max(trials):
             break  # both modes seen: the fastest candidate so far sits in a fast region
+        if len(trials) >= 4 and max(trials) < 1.02 * min(trials):
+            break  # four alike: this box offers one mode only
         cand = torch.empty((n, D), dtype=torch.float32, device=dev)
         cand.normal_(generator=gen)
         t_c = event_times(lambda: ops.spmm(indptr, col, row_of, cand, w, out=out, workspace=ws), 2)
