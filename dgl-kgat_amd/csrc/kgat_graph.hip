@@ -347,13 +347,19 @@ __global__ void group_relstart_kernel(int n_rel, const int32_t* __restrict__ rel
   if (r < n_rel && rel_ptr[r] < rel_ptr[r + 1]) flag[rel_ptr[r]] = 1;
 }
 // ex = exclusive scan of the flags (E+1 entries): ex[i+1] - ex[i] recovers flag i
-__global__ void group_fill_kernel(int64_t n, const int32_t* __restrict__ ex,
-                                  const int32_t* __restrict__ dst_g, int32_t* __restrict__ gid,
-                                  int32_t* __restrict__ g_node) {
+// Positions past rel_ptr[n_rel] (edges whose type is never scored) get group id 0: the tail kernels
+// of the split forms read the ids of a whole 16-position tile, i.e. up to 15 positions past the last
+// relation's end, and index the per-group table with them before discarding the result - an id
+// beyond the table (these positions used to open groups of their own) is an out-of-bounds read that
+// faults when the table ends a mapped segment (found by scripts/fuzz_gpu.py, seed 5393).
+__global__ void group_fill_kernel(int64_t n, int n_rel, const int32_t* __restrict__ rel_ptr,
+                                  const int32_t* __restrict__ ex, const int32_t* __restrict__ dst_g,
+                                  int32_t* __restrict__ gid, int32_t* __restrict__ g_node) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t inc = ex[i + 1];
-  gid[i] = inc - 1;
+  const bool scored = i < rel_ptr[n_rel];
+  gid[i] = scored ? inc - 1 : 0;
   if (inc != ex[i]) g_node[inc - 1] = dst_g[i];
 }
 __global__ void group_ptr_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
@@ -554,7 +560,7 @@ int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const i
   int32_t* ex = cv.take<int32_t>((size_t)n_edges + 1);
   int32_t* scan_ws = cv.take<int32_t>(scan_workspace_elems(n_edges + 1));
   // (positions past rel_ptr[n_rel] - edges whose type is never scored - open groups of their
-  // own beyond gptr[n_rel]; nothing reads them, g_node is sized for them)
+  // own beyond gptr[n_rel] in the scan; g_node is sized for them, their gid entries are written as 0)
   hipLaunchKernelGGL(group_flag_kernel, dim3(blocks_for(n_edges + 1, 256)), dim3(256), 0, st,
                      n_edges, n_edges, dst_g, ex);
   KGAT_CHECK_LAUNCH("group_flag");
@@ -566,7 +572,7 @@ int kgat_head_groups(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const i
   int rc = exclusive_scan_i32(ex, n_edges + 1, scan_ws, st);
   if (rc != KGAT_OK) return rc;
   if (n_edges > 0) {
-    hipLaunchKernelGGL(group_fill_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st, n_edges,
+    hipLaunchKernelGGL(group_fill_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, st, n_edges, n_rel, rel_ptr,
                        (const int32_t*)ex, dst_g, gid, g_node);
     KGAT_CHECK_LAUNCH("group_fill");
   }

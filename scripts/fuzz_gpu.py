@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Developer tool: randomised parity fuzzing of the sparse kernels against the fp64 oracle -
+random graph shapes (hubs, empty rows, multi-edges, tiny and ragged sizes), widths, relation counts,
+destination-range sub-ranges.  Prints the first failure with its seed and exits non-zero.
+
+  python scripts/fuzz_gpu.py [seconds] [first_seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import rel_err, rel_err_inf, sum_err  # noqa: E402
+from dgl_kgat_amd import ops  # noqa: E402
+from oracle import kgat_oracle as orc  # noqa: E402
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def t32(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int32), device=dev)
+
+
+def tf(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def graph(rng):
+    n = int(rng.choice([1, 2, 3, 17, 64, 300, 1500, 9000]))
+    e = int(rng.choice([0, 1, 2, 63, 64, 65, 255, 257, 1023, 1025, 5000, 40000, 150000]))
+    src = rng.integers(0, n, e)
+    dst = rng.integers(0, max(n - int(rng.integers(0, max(n // 3, 1))), 1), e)
+    for _ in range(int(rng.integers(0, 4))):          # hubs
+        if e:
+            dst[rng.random(e) < rng.choice([0.05, 0.3, 0.8])] = rng.integers(0, n)
+    if e and rng.random() < 0.2:                       # sorted edge order (contiguous eids per row)
+        o = np.argsort(dst, kind="stable")
+        src, dst = src[o], dst[o]
+    return n, e, src.astype(np.int32), dst.astype(np.int32)
+
+
+def stage(name):
+    if os.environ.get("FUZZ_VERBOSE"):
+        torch.cuda.synchronize()
+        print("  ok up to:", name, flush=True)
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    n, e, src, dst = graph(rng)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("seed %d n %d e %d" % (seed, n, e), flush=True)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src), t32(dst))
+    oi, oc, oe = orc.csr_from_coo(n, src, dst)
+    assert np.array_equal(indptr.cpu().numpy(), oi) and np.array_equal(col.cpu().numpy(), oc), "csr"
+    assert np.array_equal(eid.cpu().numpy(), oe), "csr eid"
+    stage("csr")
+    if e == 0:
+        return
+    # softmax (whole graph and a row-aligned sub-range)
+    s = (rng.standard_normal(e) * rng.choice([0.1, 3.0, 30.0])).astype(np.float32)
+    ref = orc.edge_softmax(n, dst, s)
+    out, out_csr = ops.edge_softmax(indptr, row_of, eid, tf(s), want_out=True, want_csr=True)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-4, "softmax"
+    assert np.array_equal(out_csr.cpu().numpy(), out.cpu().numpy()[oe]), "softmax csr order"
+    lo = int(rng.integers(0, n))
+    hi = int(rng.integers(lo, n)) + 1
+    e0, e1 = int(oi[lo]), int(oi[hi])
+    if e1 > e0:
+        _, part = ops.edge_softmax(indptr, row_of, eid, ops.gather(eid, tf(s)), in_csr_order=True, e_range=(e0, e1),
+                                   want_out=False, want_csr=True)
+        assert rel_err(part[e0:e1].cpu().numpy(), out_csr[e0:e1].cpu().numpy()) < 1e-5, "softmax sub-range"
+    stage("softmax")
+    # spmm, every width, both weight orders, epilogue, a row range
+    D = int(rng.choice([4, 8, 16, 32, 64, 128, 256, 20]))
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(e).astype(np.float32)
+    r_ = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
+    r_abs = orc.spmm_u_mul_e_sum(n, src, dst, np.abs(X), w)
+    w_csr = ops.gather(eid, tf(w))
+    deg_max = int(np.diff(oi).max())
+    for algo in (["merge", "merge1", "rows"] if D != 20 else ["generic"]):
+        # the row-per-lane-group kernels add a row's terms one after the other: their fp32 error
+        # grows with the row length (same-sign terms: up to ~n*eps/2 of the sum), the merge kernels'
+        # blocked sums do not (seed 417: 124 k same-sign terms, 1.1e-4 serial vs 1.6e-6 blocked)
+        tol = 1e-4 if algo.startswith("merge") else max(1e-4, deg_max * 6e-8)
+        o = ops.spmm(indptr, col, row_of, tf(X), w_csr, algo=algo).cpu().numpy()
+        assert sum_err(o, r_, r_abs) < tol, "spmm " + algo
+        o = ops.spmm(indptr, col, row_of, tf(X), w_csr, algo=algo, mul_self=True).cpu().numpy()
+        assert sum_err(o, r_ * X, r_abs * np.abs(X)) < tol, "spmm mul_self " + algo
+        o = ops.spmm(indptr, col, row_of, tf(X), w_csr, rows=(lo, hi - lo), e_range=(e0, e1), algo=algo).cpu().numpy()
+        assert sum_err(o, r_[lo:hi], r_abs[lo:hi]) < tol, "spmm row range " + algo
+    stage("spmm D=%d" % D)
+    # attention: every form that supports the shape
+    R = int(rng.choice([1, 2, 5, 41]))
+    d = int(rng.choice([16, 32, 64]))
+    et = rng.integers(-1 if rng.random() < 0.3 else 0, R + (1 if rng.random() < 0.3 else 0), e).astype(np.int32)
+    ent = rng.standard_normal((n, d)).astype(np.float32)
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ref = orc.att_score(ent, W, rel, src, dst, et)
+    rel_ptr, idx = ops.group_by_relation(ops.gather(eid, t32(et)), R)
+    perm, src_g, dst_g = ops.gather(idx, eid), ops.gather(idx, col), ops.gather(idx, row_of)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    args = (n, rel_ptr, perm, src_g, idx, gid, gptr, g_node)
+    cap = int(rng.choice([64, 128, 256, 512]))
+    tiles, tptr, parts = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=int(rng.choice([1, 7, 256])))
+    stage("attention structures R=%d d=%d cap=%d parts=%d groups=%d" % (R, d, cap, parts.numel() - 1, n_groups))
+    got = {}
+    got["fused"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts)[0]
+    stage("fused")
+    got["folded"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True)[0]
+    stage("folded")
+    got["split"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel))[0]
+    stage("split")
+    got["one"] = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent), tf(W), tf(rel))[0]
+    stage("attention launches R=%d d=%d cap=%d parts=%d" % (R, d, cap, parts.numel() - 1))
+    for k, v in got.items():
+        err = np.abs(v.cpu().numpy() - ref)
+        assert float(err.max()) < 1e-5 * scale + 5e-6, ("attention %s: max err %.3e at edge %d (ref %.6f, type %d), scale %.3e, "
+                                                        "R=%d d=%d n=%d e=%d groups=%d; %d edges off by > tol"
+                                                        % (k, err.max(), int(err.argmax()), ref[err.argmax()], et[err.argmax()],
+                                                           scale, R, d, n, e, n_groups, int((err > 1e-5 * scale + 5e-6).sum())))
+
+
+t0, seed, done = time.time(), seed0, 0
+while time.time() - t0 < budget:
+    try:
+        one(seed)
+    except AssertionError as exc:
+        print("FAIL seed %d: %s" % (seed, exc))
+        sys.exit(1)
+    seed += 1
+    done += 1
+torch.cuda.synchronize()
+print("fuzz ok: %d cases (seeds %d..%d) in %.0f s" % (done, seed0, seed - 1, time.time() - t0))
