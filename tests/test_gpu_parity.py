@@ -335,6 +335,9 @@ def test_att_split_head_groups(K, dev, d):
     scored = int(rel_ptr[-1])
     assert n_groups == len(ognode) == int(ogptr[-1])
     assert np.array_equal(gid.cpu().numpy()[:scored], ogid[:scored])
+    # positions of never-scored edges carry group id 0: the tail kernels read the ids of a whole
+    # 16-position tile past the last relation's end and index the per-group table with them
+    assert scored < e and np.all(gid.cpu().numpy()[scored:] == 0)
     assert np.array_equal(gptr.cpu().numpy(), ogptr) and np.array_equal(g_node.cpu().numpy()[:n_groups], ognode)
     # every scored position's group has its (relation, destination)
     perm_h, et_g = perm.cpu().numpy(), et[perm.cpu().numpy()]
