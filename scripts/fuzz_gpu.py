@@ -131,10 +131,61 @@ def one(seed):
                                                            scale, R, d, n, e, n_groups, int((err > 1e-5 * scale + 5e-6).sum())))
 
 
+def one_model(seed):
+    """The layer level: attention + propagation stack of a random model on a random CKG against the
+    fp64 oracle, the lazy edge weights against the eager ones, and a random destination partition
+    reassembled shard by shard."""
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import partition, synth
+    from conftest import blocks_rel_err_inf
+    rng = np.random.default_rng(seed)
+    nu, ni, na = (int(rng.integers(2, 200)) for _ in range(3))
+    R_kg = int(rng.integers(1, 8))
+    n, trip, R = synth.collaborative_kg(nu, ni, na, R_kg, int(rng.integers(1, 6000)), int(rng.integers(1, 3000)), seed=seed)
+    d = int(rng.choice([16, 32, 64]))
+    layers = int(rng.integers(1, 4))
+    hidden = int(rng.choice([16, 32, 64, 128]))
+    if hidden // 2 ** (layers - 1) < 16:
+        hidden = 16 * 2 ** (layers - 1)
+    torch.manual_seed(seed)
+    m = K.KGATPropagation(n, R, d, d, layers, hidden, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("model seed %d n %d e %d R %d d %d layers %d hidden %d" % (seed, n, len(trip), R, d, layers, hidden), flush=True)
+    with torch.no_grad():
+        a = m.compute_attention(g)
+        g.edata["w"] = a
+        out = m.gnn(g)
+        a_eager = g.kgat_attention(m.entity_embed.weight, m.W_R, m.relation_embed.weight, lazy=False)
+        assert torch.equal(a.cpu(), a_eager.cpu()), "lazy vs eager attention"
+    p = {k: v.detach().cpu().double().numpy() for k, v in m.state_dict().items()}
+    src, dst, et = trip[:, 2], trip[:, 0], trip[:, 1]
+    a_ref = orc.compute_attention(n, src, dst, et, p["entity_embed.weight"], p["W_R"], p["relation_embed.weight"])
+    W2 = [p["layers.%d.res_fc_2.weight" % i] for i in range(layers)]
+    out_ref = orc.gnn_forward(n, src, dst, a_ref, p["entity_embed.weight"], W2)
+    assert rel_err(a_eager.cpu().numpy(), a_ref) < 1e-4, "model attention"
+    widths = [d] + [W.shape[0] for W in W2]
+    assert blocks_rel_err_inf(out.cpu().numpy(), out_ref, widths) < 1e-4, "model readout"
+    world = int(rng.integers(2, 6))
+    with torch.no_grad():
+        h = m.entity_embed.weight.detach()
+        ref = m.layers[0](g, h, fused=True)
+        acc = torch.zeros_like(ref)
+        for r in range(world):
+            sg, keep = partition.shard_graph(g, r, world)
+            sg.edata["w"] = m.compute_attention(sg)
+            loc = sg.partition.propagate_local(sg, h, m.layers[0].res_fc_2.weight)
+            acc += sg.partition.pad(loc, loc.shape[1])
+        assert float((acc - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-6) + 1e-7, "shard reassembly"
+
+
 t0, seed, done = time.time(), seed0, 0
 while time.time() - t0 < budget:
     try:
-        one(seed)
+        if os.environ.get("FUZZ_MODEL"):
+            one_model(seed)
+        else:
+            one(seed)
     except AssertionError as exc:
         print("FAIL seed %d: %s" % (seed, exc))
         sys.exit(1)
