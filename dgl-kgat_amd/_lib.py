@@ -55,7 +55,7 @@ SIGNATURES = {
     "kgat_fold_tile_parts_workspace_bytes": (_sz, [_i64]),
     "kgat_fold_tile_parts": (_i32, [_i64, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "kgat_att_score_fused_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
-                                        _p, _p, _p, _p, _p, _p]),
+                                        _p, _p, _p, _p, _p, _i32, _p]),
     "kgat_edge_softmax_workspace_bytes": (_sz, [_i64, _i64]),
     "kgat_edge_softmax_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "kgat_edge_softmax_3pass_workspace_bytes": (_sz, [_i64]),
@@ -98,7 +98,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def source_hash():

@@ -532,8 +532,9 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
                              const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
-                             float* logits_csr, kgat_stream_t stream) {
+                             float* logits_csr, int flags, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
+  KGAT_CHECK_ARG((flags & ~KGAT_ATT_FUSED_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_fused_supported(n_nodes, d, k, n_rel)) {
     set_error("att_score_fused: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
@@ -549,6 +550,7 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   AttArgs a;
   a.grid = (unsigned)n_parts;
   a.part_tptr = part_tptr;
+  a.f32_products = (flags & KGAT_ATT_FUSED_F32_PRODUCTS) != 0;
   a.st = as_stream(stream);
   a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;

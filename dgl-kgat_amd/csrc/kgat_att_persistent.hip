@@ -828,11 +828,50 @@ __device__ unsigned long long* g_att_stamps = nullptr;
     if (g_att_stamps && threadIdx.x == 0)                                               \
       g_att_stamps[(size_t)blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memtime();        \
   } while (0)
+// per-wave phase totals: [workgroup][wave][issue, mfma, first chunk, later chunks, tiles]
+__device__ unsigned long long* g_att_phases = nullptr;
+#define KGAT_ATT_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define KGAT_ATT_PHASE_ADD(k, a, b) ph[k] += (b) - (a)
 #else
 #define KGAT_ATT_STAMP(k) do { } while (0)
+#define KGAT_ATT_PHASE_T(var) do { } while (0)
+#define KGAT_ATT_PHASE_ADD(k, a, b) do { } while (0)
 #endif
 
-template <int D_, bool LOGITS_EID>
+// X3 = true (d = k a multiple of 32): the two products run on the bf16 matrix pipe at fp32
+// accuracy.  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by truncation (h =
+// the top 16 bits of x, m the top 16 bits of x - h, l the top 16 bits of x - h - m: 8 significand
+// bits each, so the three pieces hold all 24 bits of x and the two subtractions are exact), and a
+// product a*b is taken as the six piece products of weight >= 2^-16 (l*h, h*l, m*m, m*h, h*m,
+// h*h; the three dropped ones are <= 2^-24 of a*b, a quarter of an fp32 rounding), each exact in
+// the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  Six MFMAs of 16 cycles for a 16x16x32 block
+// against eight fp32 MFMAs of 32 cycles: 2.7 x fewer matrix-pipe cycles.  W_r's pieces are cut
+// once per relation segment into LDS, already in fragment order (one 16-byte read per lane per
+// fragment); the head rows and the tanh values are cut in registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], uintx4& h, uintx4& m, uintx4& l) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned u0 = __float_as_uint(x[2 * t]), u1 = __float_as_uint(x[2 * t + 1]);
+    h[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
+    const float r0 = x[2 * t] - __uint_as_float(u0 & 0xffff0000u);
+    const float r1 = x[2 * t + 1] - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m[t] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l[t] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, const floatx4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+template <int D_, bool LOGITS_EID, bool X3>
 __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
     const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
@@ -847,7 +886,12 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   constexpr int VPL = D_ / (4 * LPE);             // float4 pieces of a row per lane
   constexpr int LDV = D_ + 4;
   static_assert(D_ <= 64, "one float4 per lane per row");
-  __shared__ __attribute__((aligned(16))) float s_w[D_ * LD];
+  static_assert(!X3 || D_ % 32 == 0, "bf16 pieces: k-steps of 32");
+  constexpr int S3 = X3 ? D_ / 32 : 1;             // k-steps of the bf16 MFMA
+  constexpr int NFRAG = KT * S3 * kWave;           // fragments of one piece of one product
+  __shared__ __attribute__((aligned(16))) float s_w[X3 ? 4 : D_ * LD];
+  // X3: W_r's pieces as A fragments, [product][piece h,m,l][column tile][k-step][lane]
+  __shared__ uintx4 s_a[X3 ? 2 * 3 * NFRAG : 1];
   __shared__ __attribute__((aligned(16))) float s_v[NW][16 * LDV];
   __shared__ int32_t s_next;  // next unclaimed tile of the current relation segment
   const int tid = threadIdx.x;
@@ -870,6 +914,9 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   const int32_t t_end = part_tptr ? part_tptr[blockIdx.x + 1]
                                   : (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
   float* vrow = s_v[w];
+#ifdef KGAT_ATT_STAMPS
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#endif
 
   int32_t t = t_begin;
   while (t < t_end) {  // workgroup-uniform loop over relation segments
@@ -884,7 +931,32 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     seg_end = seg_end < t_end ? seg_end : t_end;
     __syncthreads();  // every wave is done with the previous relation's W_r
     if (tid == 0) s_next = t;
-    {
+    if (X3) {
+      // The contraction index of a k-step is permuted the same way in A and B so that a lane's
+      // eight B elements are registers it already holds: element jj of k-step s on lane group q
+      // is index 16 (2s + jj/4) + 4q + jj%4 (two float4 pieces of a head row / two accumulator
+      // tiles of the first product).
+      const float* W = W_R + (size_t)r * D_ * K_;
+      for (int f = tid; f < NFRAG; f += kFusedThreads) {
+        const int fl = f % kWave, fs = (f / kWave) % S3, fc = f / (kWave * S3);
+        const int fi = fl & 15, fq = fl >> 4;
+        float x[8];
+        uintx4 h, m, l;
+        // first product, P^T = W^T E^T: A[row 16c + i][kk] = W[kk][16c + i]
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          x[jj] = W[(16 * (2 * fs + (jj >> 2)) + 4 * fq + (jj & 3)) * K_ + 16 * fc + fi];
+        split_bf16x3(x, h, m, l);
+        s_a[0 * NFRAG + f] = h; s_a[1 * NFRAG + f] = m; s_a[2 * NFRAG + f] = l;
+        // second product, V^T = W T: A[row 16c2 + i][kk] = W[16c2 + i][kk]
+        const float4 w0 = *reinterpret_cast<const float4*>(W + (16 * fc + fi) * K_ + 32 * fs + 4 * fq);
+        const float4 w1 = *reinterpret_cast<const float4*>(W + (16 * fc + fi) * K_ + 32 * fs + 16 + 4 * fq);
+        x[0] = w0.x; x[1] = w0.y; x[2] = w0.z; x[3] = w0.w;
+        x[4] = w1.x; x[5] = w1.y; x[6] = w1.z; x[7] = w1.w;
+        split_bf16x3(x, h, m, l);
+        s_a[3 * NFRAG + f] = h; s_a[4 * NFRAG + f] = m; s_a[5 * NFRAG + f] = l;
+      }
+    } else {
       const float* W = W_R + (size_t)r * D_ * K_;
       for (int idx = tid * 4; idx < D_ * K_; idx += kFusedThreads * 4) {
         const float4 v = *reinterpret_cast<const float4*>(W + idx);
@@ -946,32 +1018,80 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       floatx4 acc[KT];
 #pragma unroll
       for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
-      const float* w1 = s_w + (4 * q) * LD + i;
+      floatx4 v[KT];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      if (X3) {
+        const uintx4* fa = s_a + lane;
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+        for (int s = 0; s < S3; ++s) {
+          float x[8];
+          uintx4 bh, bm, bl;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = f.a[8 * s + jj];
+          split_bf16x3(x, bh, bm, bl);
+#pragma unroll
+          for (int c = 0; c < KT; ++c) {  // smallest piece products first
+            const uintx4 ah = fa[0 * NFRAG + (c * S3 + s) * kWave];
+            const uintx4 am = fa[1 * NFRAG + (c * S3 + s) * kWave];
+            const uintx4 al = fa[2 * NFRAG + (c * S3 + s) * kWave];
+            acc[c] = mfma_bf16(al, bh, acc[c]);
+            acc[c] = mfma_bf16(ah, bl, acc[c]);
+            acc[c] = mfma_bf16(am, bm, acc[c]);
+            acc[c] = mfma_bf16(am, bh, acc[c]);
+            acc[c] = mfma_bf16(ah, bm, acc[c]);
+            acc[c] = mfma_bf16(ah, bh, acc[c]);
+          }
+        }
+      } else {
+        const float* w1 = s_w + (4 * q) * LD + i;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+#pragma unroll
+          for (int c = 0; c < KT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int c = 0; c < KT; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
-      floatx4 v[KT];
+      if (X3) {
+        const uintx4* fa = s_a + 3 * NFRAG + lane;
 #pragma unroll
-      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
-      const float* w2 = s_w + i * LD + 4 * q;
+        for (int s = 0; s < S3; ++s) {
+          float x[8];
+          uintx4 bh, bm, bl;
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+          for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
+          split_bf16x3(x, bh, bm, bl);
 #pragma unroll
-        for (int c2 = 0; c2 < KT; ++c2) {
-          const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+          for (int c2 = 0; c2 < KT; ++c2) {
+            const uintx4 ah = fa[0 * NFRAG + (c2 * S3 + s) * kWave];
+            const uintx4 am = fa[1 * NFRAG + (c2 * S3 + s) * kWave];
+            const uintx4 al = fa[2 * NFRAG + (c2 * S3 + s) * kWave];
+            v[c2] = mfma_bf16(al, bh, v[c2]);
+            v[c2] = mfma_bf16(ah, bl, v[c2]);
+            v[c2] = mfma_bf16(am, bm, v[c2]);
+            v[c2] = mfma_bf16(am, bh, v[c2]);
+            v[c2] = mfma_bf16(ah, bm, v[c2]);
+            v[c2] = mfma_bf16(ah, bh, v[c2]);
+          }
         }
+      } else {
+        const float* w2 = s_w + i * LD + 4 * q;
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int c2 = 0; c2 < KT; ++c2) {
+            const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+          }
+      }
       // v[c2][j] = V[group i][16c2 + 4q + j] -> the wave's LDS patch, row = group
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tile's reads are done
 #pragma unroll
@@ -1028,6 +1148,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       load_head(hb0, h0);
 #define KGAT_FUSED_STEP(HCUR, HNEXT)                                                   \
       {                                                                                \
+        KGAT_ATT_PHASE_T(pt0);                                                         \
         const int32_t n3 = claim();                                                    \
         const int4 d3 = desc_of(n3);                                                   \
         const int32_t h2 = head_idx(d2);                                               \
@@ -1042,9 +1163,13 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         load_edges(eb0, c0);                                                           \
         load_head(HNEXT, h1);                                                          \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        KGAT_ATT_PHASE_T(pt1);                                                         \
         mfma_phase(HCUR);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        KGAT_ATT_PHASE_T(pt2);                                                         \
         edge_phase(eb0, c0, d0.z, d0.w);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        KGAT_ATT_PHASE_T(pt3);                                                         \
         if (d0.z + kWave < d0.w) {                                                     \
           load_edges(eb0, cx);                                                         \
           edge_phase(eb0, cx, d0.z + kWave, d0.w);                                     \
@@ -1065,6 +1190,10 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
           }                                                                            \
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        KGAT_ATT_PHASE_T(pt4);                                                         \
+        KGAT_ATT_PHASE_ADD(0, pt0, pt1); KGAT_ATT_PHASE_ADD(1, pt1, pt2);              \
+        KGAT_ATT_PHASE_ADD(2, pt2, pt3); KGAT_ATT_PHASE_ADD(3, pt3, pt4);              \
+        KGAT_ATT_PHASE_ADD(4, 0, 1);                                                   \
         d0 = d1; d1 = d2; d2 = d3;                                                     \
         h1 = h2;                                                                       \
         c0 = c1;                                                                       \
@@ -1081,22 +1210,31 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     t = seg_end;
   }
 #ifdef KGAT_ATT_STAMPS
+  if (g_att_phases && lane == 0)
+    for (int k2 = 0; k2 < 5; ++k2) g_att_phases[((size_t)blockIdx.x * NW + w) * 5 + k2] = ph[k2];
   __syncthreads();
   KGAT_ATT_STAMP(1);
 #endif
 }
 
+template <int D_, bool EID, bool X3>
+static void launch_att_fold_fused_form(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
+  hipLaunchKernelGGL((att_fold_fused_kernel<D_, EID, X3>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
+                     a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
+                     a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
+}
+
 template <int D_>
 static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
-  const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
-  if (a.logits)
-    hipLaunchKernelGGL((att_fold_fused_kernel<D_, true>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
-                       a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
-                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
-  else
-    hipLaunchKernelGGL((att_fold_fused_kernel<D_, false>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
-                       a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
-                       a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
+  constexpr bool kCanSplit = D_ % 32 == 0;
+  if (kCanSplit && !a.f32_products) {
+    if (a.logits) launch_att_fold_fused_form<D_, true, kCanSplit>(a, rel_tptr, tiles);
+    else launch_att_fold_fused_form<D_, false, kCanSplit>(a, rel_tptr, tiles);
+  } else {
+    if (a.logits) launch_att_fold_fused_form<D_, true, false>(a, rel_tptr, tiles);
+    else launch_att_fold_fused_form<D_, false, false>(a, rel_tptr, tiles);
+  }
   KGAT_CHECK_LAUNCH("att_fold_fused");
   return KGAT_OK;
 }
@@ -1104,6 +1242,9 @@ static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, cons
 #ifdef KGAT_ATT_STAMPS
 extern "C" int kgat_debug_set_att_stamps(void* dev_ptr) {
   return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
+}
+extern "C" int kgat_debug_set_att_phases(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_phases), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
 }
 #endif
 

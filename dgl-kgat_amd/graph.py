@@ -253,6 +253,18 @@ class _Structure:
                                                w_csr, w_flat)
 
 
+def _fused_tiles(groups, d):
+    """Work tiles of the fused attention kernel and their split over the workgroups, kept with the
+    relation grouping (graph-static); the split cost goes with the product form taken at width d."""
+    cost = ops.fold_tile_cost(d)
+    tiles = groups.g_tab.get("tiles")
+    if tiles is None or groups.g_tab.get("tiles_cost") != cost:
+        tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups,
+                                                       cost=cost)
+        groups.g_tab["tiles_cost"] = cost
+    return tiles
+
+
 class EdgeBatch:
     """What a UDF passed to filter_edges / apply_edges sees: lazily gathered src / dst /
     edge features of the selected edges (reference models.py:140-143)."""
@@ -505,10 +517,7 @@ class DGLGraph:
                         best = (ms, f)
                 form = best[1]
             else:
-                tiles = groups.g_tab.get("tiles")
-                if tiles is None:
-                    tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr,
-                                                                   groups.n_groups)
+                tiles = _fused_tiles(groups, d)
                 n_tiles = int(tiles[1][-1])
                 form = "fused" if n_tiles <= 2 * ((groups.n_groups + 15) // 16) else "folded"
             groups.g_tab.pop("tiles" if form == "folded" else d, None)  # the other form's scratch
@@ -544,10 +553,7 @@ class DGLGraph:
         # reference's contraction order (bit-identical to "one")
         def run(form):
             if form == "fused":
-                tiles = groups.g_tab.get("tiles")  # graph-static work tiles of the fused kernel
-                if tiles is None:
-                    tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr,
-                                                                   groups.n_groups)
+                tiles = _fused_tiles(groups, d)  # graph-static work tiles of the fused kernel
                 return ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
                                            groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
                                            ent_c, W_c, rel_c, want_eid=False, part_tptr=tiles[2])[1]

@@ -243,10 +243,18 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
 # small part of its workgroup's time for the eight waves to balance.  Measured on MI355X with the
 # cost-balanced split (amazon-book-shaped CKG): 128: 0.2135 ms, 256: 0.2019.
 FOLD_TILE_CAP = 256
-# per-tile cost model of the fused kernel (kgat_fold_tile_parts; units of ~23 ticks of workgroup
-# time, from per-workgroup clock stamps: scripts/micro/att_stamps.py): a tile, a chunk of 64
-# positions past the first 64, a relation change inside a workgroup's range
-FOLD_TILE_COST = (64, 12, 466)
+# per-tile cost model of the fused kernel (kgat_fold_tile_parts; from per-workgroup clock stamps,
+# scripts/micro/att_stamps.py): a tile, a chunk of 64 positions past the first 64, a relation
+# change inside a workgroup's range.  With the bf16-piece products (d % 32 == 0) the fit is 649
+# ticks of workgroup time per tile, 389 per later chunk, 10,661 per relation change; with the fp32
+# products 1,459 / 267 / 10,630.  Both in units of a 64th of a tile.
+FOLD_TILE_COST = (64, 38, 1051)
+FOLD_TILE_COST_F32 = (64, 12, 466)
+
+
+def fold_tile_cost(d, f32_products=False):
+    """The split cost that goes with the product form att_score_fused takes at width d."""
+    return FOLD_TILE_COST if (d % 32 == 0 and not f32_products) else FOLD_TILE_COST_F32
 
 
 def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, cost=FOLD_TILE_COST):
@@ -277,14 +285,19 @@ def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, co
     return tiles, rel_tptr, part_tptr
 
 
+ATT_FUSED_F32_PRODUCTS = 1  # include/kgat_hip.h
+
+
 def att_score_fused_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_fused_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
 
 def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
-                    want_csr=True, want_eid=True, part_tptr=None):
+                    want_csr=True, want_eid=True, part_tptr=None, f32_products=False):
     """Attention logits, fused folded form (kgat_att_score_fused_f32).  `part_tptr`: the tile range
     of every workgroup (fold_tiles); None: equal tile counts, one workgroup per compute unit.
+    `f32_products`: the two products on the fp32 MFMA (KGAT_ATT_FUSED_F32_PRODUCTS) instead of the
+    three-bf16-piece products the kernel takes by default when d % 32 == 0.
     Returns (logits edge-id order or None, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
@@ -310,7 +323,8 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
         check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
                                                    _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), _ptr(tiles),
                                                    _ptr(rel_tptr), _ptr(part_tptr), n_parts, _ptr(ent), _ptr(W_R),
-                                                   _ptr(rel), _ptr(logits), _ptr(logits_csr), _stream(ent)),
+                                                   _ptr(rel), _ptr(logits), _ptr(logits_csr),
+                                                   ATT_FUSED_F32_PRODUCTS if f32_products else 0, _stream(ent)),
               "kgat_att_score_fused_f32")
     return logits, logits_csr
 
@@ -575,6 +589,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]

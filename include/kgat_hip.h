@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 2
+#define KGAT_ABI_VERSION 3
 
 enum {
   KGAT_OK = 0,
@@ -59,6 +59,15 @@ enum {
    * chunk kernel, 2: device-library tanhf instead of the exp2/rcp form, 4: workgroup-chunk
    * kernel instead of the persistent-wavefront kernel, 8: one persistent wave per SIMD) */
   KGAT_ATT_ALGO_VARIANT_BASE = 16
+};
+
+/* flags for kgat_att_score_fused_f32 */
+enum {
+  KGAT_ATT_FUSED_F32_PRODUCTS = 1 /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead
+                                   * of the default for d % 32 == 0: every fp32 operand cut into three
+                                   * bf16 pieces that together hold its 24 significand bits, the six
+                                   * piece products of weight >= 2^-16 accumulated in fp32 by
+                                   * v_mfma_f32_16x16x32_bf16 (dropped: <= 2^-24 of a product) */
 };
 
 typedef void* kgat_stream_t; /* hipStream_t */
@@ -190,14 +199,14 @@ int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const i
                          size_t workspace_bytes, kgat_stream_t stream);
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
 /* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
- * compute unit, equal tile counts. */
+ * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_FUSED_F32_PRODUCTS. */
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
                              const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
-                             float* logits_csr, kgat_stream_t stream);
+                             float* logits_csr, int flags, kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):

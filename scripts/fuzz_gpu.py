@@ -117,6 +117,9 @@ def one(seed):
     got = {}
     got["fused"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts)[0]
     stage("fused")
+    got["fused, fp32 products"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts,
+                                                      f32_products=True)[0]
+    stage("fused, fp32 products")
     got["folded"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True)[0]
     stage("folded")
     got["split"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel))[0]

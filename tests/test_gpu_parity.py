@@ -437,6 +437,46 @@ def test_att_fused_small_and_single_relation(K, dev):
         assert torch.equal(fused_csr, fused[eid.long()])
 
 
+@pytest.mark.parametrize("d", [32, 64])
+def test_att_fused_product_forms(K, dev, d):
+    """The fused kernel's default products (three bf16 pieces per fp32 operand, six piece products
+    in the fp32 accumulator of the bf16 MFMA) against its fp32-MFMA products and the fp64 oracle:
+    no further from fp64 than the fp32 form, under 8c and in absolute terms, also when the
+    operands span forty orders of magnitude (every piece keeps the fp32 exponent range)."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(2024 + d)
+    n, e, R = 3000, 60000, 7
+    src, dst = random_graph(31, n, e, hub=3000, isolated_tail=10)
+    et = rng.integers(0, R, e).astype(np.int32)
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, n_parts=19)
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    for case in ("normal", "wide range", "tiny", "signed zeros"):
+        ent = rng.standard_normal((n, d)).astype(np.float32)
+        if case == "wide range":   # rows scaled by 2^-60 .. 2^+10; elements by up to 2^-12 more
+            ent *= np.exp2(rng.integers(-60, 11, (n, 1))).astype(np.float32)
+            ent *= np.exp2(-rng.integers(0, 13, (n, d))).astype(np.float32)
+        elif case == "tiny":       # around the subnormal boundary: products vanish, logits = 0 + rounding
+            ent *= np.float32(1e-37)
+        elif case == "signed zeros":
+            ent[rng.random((n, d)) < 0.5] = -0.0
+        ref = orc.att_score(ent, W, rel, src, dst, et)
+        got = {}
+        for f32p in (False, True):
+            got[f32p] = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                            tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False,
+                                            part_tptr=part_tptr, f32_products=f32p)[0].cpu().numpy()
+            assert np.isfinite(got[f32p]).all()
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        e_new, e_f32 = np.abs(got[False] - ref).max(), np.abs(got[True] - ref).max()
+        print("[att products d=%d %-12s] max|err|/max|ref|: bf16 pieces %.3e  fp32 products %.3e ; 8c %.3e  %.3e"
+              % (d, case, e_new / scale, e_f32 / scale, rel_err(got[False], ref), rel_err(got[True], ref)))
+        assert e_new <= max(2.0 * e_f32, 2e-7 * scale), (case, e_new, e_f32)
+        assert rel_err(got[False], ref) <= max(1e-4, 2.0 * rel_err(got[True], ref)), case
+
+
 def test_att_folded_d128(K, dev):
     """d = k = 128: W_r (64 KB) lives in LDS, 32 floats per lane in the per-edge dot."""
     from dgl_kgat_amd import ops

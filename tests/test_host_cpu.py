@@ -25,7 +25,7 @@ def test_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libkgat_hip.so lacks %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kgat_version() == 2 == _lib.ABI_VERSION
+    assert lib.kgat_version() == 3 == _lib.ABI_VERSION
     assert lib.kgat_build_hash().decode() == "kgat-src-hash:" + _lib.source_hash() and not _lib.needs_build()
     # argument validation happens before any device work: callable without a GPU
     assert lib.kgat_spmm_umule_sum_f32(-1, 0, 0, 0, 64, None, None, None, None, None, None, None, None, None,
