@@ -47,7 +47,7 @@ SIGNATURES = {
                                         _p, _p, _p, _p, _p]),
     "kgat_att_score_folded_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "kgat_att_score_folded_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
-                                         _p, _p, _p, _p, _p]),
+                                         _p, _p, _p, _p, _i32, _p]),
     "kgat_fold_tiles_max": (_i64, [_i64, _i64, _i32, _i32]),
     "kgat_fold_tiles_workspace_bytes": (_sz, [_i64, _i32]),
     "kgat_fold_tiles": (_i32, [_i64, _i32, _i64, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),

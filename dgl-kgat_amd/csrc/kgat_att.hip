@@ -486,9 +486,10 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
                               const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
                               const int32_t* g_node, int64_t n_groups, const float* ent,
                               const float* W_R, const float* rel, float* V_tab, float* logits,
-                              float* logits_csr, kgat_stream_t stream) {
+                              float* logits_csr, int flags, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_groups >= 0 && n_edges < INT32_MAX,
                  "att_score_folded: bad size");
+  KGAT_CHECK_ARG((flags & ~KGAT_ATT_F32_PRODUCTS) == 0, "att_score_folded: unknown flag");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_folded_supported(n_nodes, d, k, n_rel)) {
     set_error("att_score_folded: needs d == k in {16,32,64,128} or d in {8,16,32} with k <= 32, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
@@ -509,6 +510,7 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
   a.pos_g = pos_g;
   a.n_edges = n_edges;
   a.gid = gid; a.gptr = gptr; a.g_node = g_node; a.G_tab = V_tab;
+  a.f32_products = (flags & KGAT_ATT_F32_PRODUCTS) != 0;
   if (n_groups > 0) {
     const int rc = fold_small(d, k) ? launch_att_fold_head_small(d, k, a, n_groups) : launch_att_fold_head_any(d, a);
     if (rc != KGAT_OK) return rc;
@@ -534,7 +536,7 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const float* ent, const float* W_R, const float* rel, float* logits,
                              float* logits_csr, int flags, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
-  KGAT_CHECK_ARG((flags & ~KGAT_ATT_FUSED_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
+  KGAT_CHECK_ARG((flags & ~KGAT_ATT_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_fused_supported(n_nodes, d, k, n_rel)) {
     set_error("att_score_fused: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
@@ -550,7 +552,7 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   AttArgs a;
   a.grid = (unsigned)n_parts;
   a.part_tptr = part_tptr;
-  a.f32_products = (flags & KGAT_ATT_FUSED_F32_PRODUCTS) != 0;
+  a.f32_products = (flags & KGAT_ATT_F32_PRODUCTS) != 0;
   a.st = as_stream(stream);
   a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;

@@ -98,7 +98,7 @@ struct AttArgs {
   int64_t n_edges = 0;
   bool needs_memset = true;
   const int32_t* part_tptr = nullptr;  // fused form: tile range per workgroup (grid = number of parts)
-  bool f32_products = false;           // fused form: fp32 MFMA products instead of the bf16-piece products
+  bool f32_products = false;           // fused / folded forms: fp32 MFMA products instead of the bf16-piece products
 };
 
 

@@ -650,6 +650,60 @@ static int launch_att_fold_head(const AttArgs& a) {
   return KGAT_OK;
 }
 
+#ifdef KGAT_ATT_STAMPS
+// Diagnostic build only (-DKGAT_ATT_STAMPS, scripts/micro/att_stamps.py): start / end s_memtime of
+// every workgroup of the fused kernel.  Never compiled into the shipped library.
+__device__ unsigned long long* g_att_stamps = nullptr;
+#define KGAT_ATT_STAMP(k)                                                               \
+  do {                                                                                  \
+    if (g_att_stamps && threadIdx.x == 0)                                               \
+      g_att_stamps[(size_t)blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+// per-wave phase totals: [workgroup][wave][issue, mfma, first chunk, later chunks, tiles]
+__device__ unsigned long long* g_att_phases = nullptr;
+#define KGAT_ATT_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define KGAT_ATT_PHASE_ADD(k, a, b) ph[k] += (b) - (a)
+#else
+#define KGAT_ATT_STAMP(k) do { } while (0)
+#define KGAT_ATT_PHASE_T(var) do { } while (0)
+#define KGAT_ATT_PHASE_ADD(k, a, b) do { } while (0)
+#endif
+
+// Products at fp32 accuracy on the bf16 matrix pipe (X3 = true in the kernels below; d = k a
+// multiple of 32).  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by truncation
+// (h = the top 16 bits of x, m the top 16 bits of x - h, l the top 16 bits of x - h - m: 8
+// significand bits each, so the three pieces hold all 24 bits of x and the two subtractions are
+// exact), and a product a*b is taken as the six piece products of weight >= 2^-16 (l*h, h*l, m*m,
+// m*h, h*m, h*h; the three dropped ones are <= 2^-24 of a*b, a quarter of an fp32 rounding), each
+// exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  Six MFMAs of 16 cycles for a
+// 16x16x32 block against eight fp32 MFMAs of 32 cycles: 2.7 x fewer matrix-pipe cycles.  W_r's
+// pieces are cut once per relation segment into LDS; the head rows and the tanh values are cut in
+// registers.  Non-finite operands give NaN (Inf - Inf in the cut), where the fp32 products follow
+// IEEE and can give +-Inf.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], uintx4& h, uintx4& m, uintx4& l) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned u0 = __float_as_uint(x[2 * t]), u1 = __float_as_uint(x[2 * t + 1]);
+    h[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
+    const float r0 = x[2 * t] - __uint_as_float(u0 & 0xffff0000u);
+    const float r1 = x[2 * t + 1] - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m[t] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l[t] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, const floatx4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
 // Folded head kernel for widths whose W_r does not fit the register file (d = k = 128: 64 KB).
 // One 512-thread workgroup per CU keeps the current relation's W_r in LDS, row-major with a
 // 4-float pad (bank-conflict-free for both fragment shapes: the first product reads
@@ -659,15 +713,26 @@ static int launch_att_fold_head(const AttArgs& a) {
 // row look-ahead hides the gather.
 constexpr int kFoldLdsThreads = 512;
 
-template <int D_>
+template <int D_, bool X3>
 __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
     int n_rel, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
     float* __restrict__ V_tab) {
+  KGAT_ATT_STAMP(0);
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFoldLdsThreads / kWave;
+  // X3: one image of W_r per bf16 piece, [row d][column k] with 256-byte rows whose 16-byte
+  // chunks are swizzled (chunk ^ (2 (row % 8) + (row / 8) % 2)): the first product contracts over
+  // W_r's row index and takes its A fragments with ds_read_b64_tr_b16 (a 16-lane group reads 4
+  // rows x 16 columns and every lane receives one column: the eight rows of a 32-lane half land
+  // in eight different 32-byte slots), the second contracts over the column index and reads
+  // 8-byte row pieces (sixteen rows, sixteen different chunks) - both free of bank conflicts on
+  // the one image.
+  constexpr int S3 = D_ / 32, ROWB = D_ * 2, IMG = D_ * ROWB;
+  static_assert(!X3 || D_ == 128, "image swizzle is written for 256-byte rows");
   __shared__ int32_t s_tptr[kAttMaxRelLds + 1];
-  __shared__ __attribute__((aligned(16))) float s_w[D_ * LD];
+  __shared__ __attribute__((aligned(16))) float s_w[X3 ? 4 : D_ * LD];
+  __shared__ __attribute__((aligned(16))) unsigned char s_img[X3 ? 3 * IMG : 16];
   const int tid = threadIdx.x;
   for (int r = tid; r < n_rel; r += kFoldLdsThreads) s_tptr[r + 1] = (gptr[r + 1] - gptr[r] + 15) >> 4;
   __syncthreads();
@@ -685,6 +750,9 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
   const int i = lane & 15, q = lane >> 4;
   const int32_t t_begin = (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+#ifdef KGAT_ATT_STAMPS
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#endif
 
   struct Buf { float a[KS]; };
   auto load_rows = [&](Buf& f, int32_t row) {
@@ -710,7 +778,21 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
     int32_t seg_end = s_tptr[r + 1];
     seg_end = seg_end < t_end ? seg_end : t_end;
     __syncthreads();  // every wave is done with the previous relation's W_r
-    {
+    if (X3) {
+      const float* W = W_R + (size_t)r * D_ * K_;
+      for (int u = tid; u < D_ * (K_ / 8); u += kFoldLdsThreads) {
+        const int row = u / (K_ / 8), ch = u % (K_ / 8);
+        const float4 w0 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch);
+        const float4 w1 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch + 4);
+        const float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        uintx4 h, m, l;
+        split_bf16x3(x, h, m, l);
+        const int off = ROWB * row + 16 * (ch ^ (((row & 7) << 1) | ((row >> 3) & 1)));
+        *reinterpret_cast<uintx4*>(s_img + off) = h;
+        *reinterpret_cast<uintx4*>(s_img + IMG + off) = m;
+        *reinterpret_cast<uintx4*>(s_img + 2 * IMG + off) = l;
+      }
+    } else {
       const float* W = W_R + (size_t)r * D_ * K_;
       for (int idx = tid * 4; idx < D_ * K_; idx += kFoldLdsThreads * 4) {
         const float4 v = *reinterpret_cast<const float4*>(W + idx);
@@ -732,35 +814,132 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
       return g_node[g];
     };
     auto tile = [&](int32_t n, const Buf& f) {
+      KGAT_ATT_PHASE_T(pt0);
       floatx4 acc[KT];
 #pragma unroll
       for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
-      const float* w1 = s_w + (4 * q) * LD + i;
+      floatx4 v[KT];
+      if (X3) {
+        // First product, P^T = W^T E^T.  Element jj of k-step s on lane group q is contraction
+        // index 32s + 16 (jj / 4) + 4q + jj % 4 (the lane's own pieces of the head row); lane
+        // 4qq + p of the group addresses row (32s + 16t + 4q) + qq, columns 16c + 4p .. + 3.
+        // The fragments of step (s, c) are requested one step ahead of their six MFMAs.
+        typedef short shortx4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) shortx4 lds_shortx4;
+        const int qq = i >> 2, p = i & 3;
+        const int base1 = ROWB * (4 * q + qq) + 8 * (p & 1);
+        const int sw1 = ((4 * (q & 1) + qq) << 1) | (q >> 1);
+        auto frag1 = [&](int n, uintx4 (&ap)[3]) {
+          const int s = n / KT, c = n % KT;
+          const int o = base1 + 16 * ((2 * c + (p >> 1)) ^ sw1) + ROWB * 32 * s;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+          for (int pc = 0; pc < 3; ++pc) {
+            const shortx4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o));
+            const shortx4 hi =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o + ROWB * 16));
+            ap[pc] = __builtin_bit_cast(uintx4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        };
+        auto pieces1 = [&](int s, uintx4 (&b)[3]) {
+          float x[8];
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+          for (int jj = 0; jj < 8; ++jj) x[jj] = f.a[8 * s + jj];
+          split_bf16x3(x, b[0], b[1], b[2]);
+        };
+        uintx4 fa[2][3], fb[2][3];
+        frag1(0, fa[0]);
+        pieces1(0, fb[0]);
+#pragma unroll
+        for (int n = 0; n < S3 * KT; ++n) {
+          const int s = n / KT, c = n % KT;
+          if (n + 1 < S3 * KT) frag1(n + 1, fa[(n + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c == KT - 1 && s + 1 < S3) pieces1(s + 1, fb[(s + 1) & 1]);
+          const uintx4(&ap)[3] = fa[n & 1];
+          const uintx4(&bp)[3] = fb[s & 1];
+          acc[c] = mfma_bf16(ap[2], bp[0], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[2], acc[c]);
+          acc[c] = mfma_bf16(ap[1], bp[1], acc[c]);
+          acc[c] = mfma_bf16(ap[1], bp[0], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[1], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[0], acc[c]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        const float* w1 = s_w + (4 * q) * LD + i;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const float* ws = w1 + (16 * (s >> 2) + (s & 3)) * LD;
+#pragma unroll
+          for (int c = 0; c < KT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
+        }
       }
+      KGAT_ATT_PHASE_T(pt1);
 #pragma unroll
       for (int c = 0; c < KT; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
-      floatx4 v[KT];
 #pragma unroll
       for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
-      const float* w2 = s_w + i * LD + 4 * q;
+      __builtin_amdgcn_sched_barrier(0);
+      KGAT_ATT_PHASE_T(pt2);
+      if (X3) {
+        // Second product, V^T = W T: row 16c2 + i of the image, contraction index
+        // 32s + 16 (jj / 4) + 4q + jj % 4 = accumulator tile 2s + jj / 4, register jj % 4.
+        const int base2 = ROWB * i + 8 * (q & 1);
+        const int sw2 = ((i & 7) << 1) | (i >> 3);
+        auto frag2 = [&](int n, uintx4 (&ap)[3]) {
+          const int s = n / KT, c2 = n % KT;
+          const int o0 = base2 + 16 * (((4 * s) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
+          const int o1 = base2 + 16 * (((4 * s + 2) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+          for (int pc = 0; pc < 3; ++pc) {
+            const uintx2 l2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o0);
+            const uintx2 h2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o1);
+            ap[pc] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3);
+          }
+        };
+        auto pieces2 = [&](int s, uintx4 (&b)[3]) {
+          float x[8];
 #pragma unroll
-        for (int c2 = 0; c2 < KT; ++c2) {
-          const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
-          v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+          for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
+          split_bf16x3(x, b[0], b[1], b[2]);
+        };
+        uintx4 fa[2][3], fb[2][3];
+        frag2(0, fa[0]);
+        pieces2(0, fb[0]);
+#pragma unroll
+        for (int n = 0; n < S3 * KT; ++n) {
+          const int s = n / KT, c2 = n % KT;
+          if (n + 1 < S3 * KT) frag2(n + 1, fa[(n + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c2 == KT - 1 && s + 1 < S3) pieces2(s + 1, fb[(s + 1) & 1]);
+          const uintx4(&ap)[3] = fa[n & 1];
+          const uintx4(&bp)[3] = fb[s & 1];
+          v[c2] = mfma_bf16(ap[2], bp[0], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[2], v[c2]);
+          v[c2] = mfma_bf16(ap[1], bp[1], v[c2]);
+          v[c2] = mfma_bf16(ap[1], bp[0], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[1], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[0], v[c2]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+        const float* w2 = s_w + i * LD + 4 * q;
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int c2 = 0; c2 < KT; ++c2) {
+            const float4 wv = *reinterpret_cast<const float4*>(w2 + (16 * c2) * LD + 16 * c);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, acc[c][0], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, acc[c][1], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, acc[c][2], v[c2], 0, 0, 0);
+            v[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, acc[c][3], v[c2], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      KGAT_ATT_PHASE_T(pt3);
       const int32_t g = rbeg + ((n - tfirst) << 4) + i;
       if (g < rend) {
 #pragma unroll
@@ -770,6 +949,10 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
           *reinterpret_cast<float4*>(V_tab + (size_t)g * D_ + 16 * c2 + 4 * q) = o;
         }
       }
+      KGAT_ATT_PHASE_T(pt4);
+      KGAT_ATT_PHASE_ADD(0, pt0, pt1); KGAT_ATT_PHASE_ADD(1, pt1, pt2);
+      KGAT_ATT_PHASE_ADD(2, pt2, pt3); KGAT_ATT_PHASE_ADD(3, pt3, pt4);
+      KGAT_ATT_PHASE_ADD(4, 0, 1);
     };
     int32_t n = t + w;
     if (n < seg_end) {
@@ -795,13 +978,23 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
     }
     t = seg_end;
   }
+#ifdef KGAT_ATT_STAMPS
+  if (g_att_phases && lane == 0)
+    for (int k2 = 0; k2 < 5; ++k2) g_att_phases[((size_t)blockIdx.x * NW + w) * 5 + k2] = ph[k2];
+  __syncthreads();
+  KGAT_ATT_STAMP(1);
+#endif
 }
 
 template <int D_>
 static int launch_att_fold_head_lds(const AttArgs& a) {
   const int cus = device_cu_count();
-  hipLaunchKernelGGL((att_fold_head_lds_kernel<D_>), dim3((unsigned)cus), dim3(kFoldLdsThreads), 0, a.st, a.n_rel,
-                     a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
+  if (a.f32_products)
+    hipLaunchKernelGGL((att_fold_head_lds_kernel<D_, false>), dim3((unsigned)cus), dim3(kFoldLdsThreads), 0, a.st,
+                       a.n_rel, a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
+  else
+    hipLaunchKernelGGL((att_fold_head_lds_kernel<D_, true>), dim3((unsigned)cus), dim3(kFoldLdsThreads), 0, a.st,
+                       a.n_rel, a.gptr, a.g_node, a.ent, a.W_R, a.rel, a.G_tab);
   KGAT_CHECK_LAUNCH("att_fold_head_lds");
   return KGAT_OK;
 }
@@ -819,58 +1012,9 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
 // registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
 constexpr int kFusedThreads = 512;
 
-#ifdef KGAT_ATT_STAMPS
-// Diagnostic build only (-DKGAT_ATT_STAMPS, scripts/micro/att_stamps.py): start / end s_memtime of
-// every workgroup of the fused kernel.  Never compiled into the shipped library.
-__device__ unsigned long long* g_att_stamps = nullptr;
-#define KGAT_ATT_STAMP(k)                                                               \
-  do {                                                                                  \
-    if (g_att_stamps && threadIdx.x == 0)                                               \
-      g_att_stamps[(size_t)blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memtime();        \
-  } while (0)
-// per-wave phase totals: [workgroup][wave][issue, mfma, first chunk, later chunks, tiles]
-__device__ unsigned long long* g_att_phases = nullptr;
-#define KGAT_ATT_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define KGAT_ATT_PHASE_ADD(k, a, b) ph[k] += (b) - (a)
-#else
-#define KGAT_ATT_STAMP(k) do { } while (0)
-#define KGAT_ATT_PHASE_T(var) do { } while (0)
-#define KGAT_ATT_PHASE_ADD(k, a, b) do { } while (0)
-#endif
 
-// X3 = true (d = k a multiple of 32): the two products run on the bf16 matrix pipe at fp32
-// accuracy.  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by truncation (h =
-// the top 16 bits of x, m the top 16 bits of x - h, l the top 16 bits of x - h - m: 8 significand
-// bits each, so the three pieces hold all 24 bits of x and the two subtractions are exact), and a
-// product a*b is taken as the six piece products of weight >= 2^-16 (l*h, h*l, m*m, m*h, h*m,
-// h*h; the three dropped ones are <= 2^-24 of a*b, a quarter of an fp32 rounding), each exact in
-// the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  Six MFMAs of 16 cycles for a 16x16x32 block
-// against eight fp32 MFMAs of 32 cycles: 2.7 x fewer matrix-pipe cycles.  W_r's pieces are cut
-// once per relation segment into LDS, already in fragment order (one 16-byte read per lane per
-// fragment); the head rows and the tanh values are cut in registers.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split_bf16x3(const float (&x)[8], uintx4& h, uintx4& m, uintx4& l) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const unsigned u0 = __float_as_uint(x[2 * t]), u1 = __float_as_uint(x[2 * t + 1]);
-    h[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
-    const float r0 = x[2 * t] - __uint_as_float(u0 & 0xffff0000u);
-    const float r1 = x[2 * t + 1] - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    m[t] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
-    const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    l[t] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-  }
-}
-
-__device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, const floatx4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
-                                                 0);
-}
-
+// X3: the two products as bf16-piece products (above); W_r's pieces sit in LDS already in fragment
+// order, one 16-byte read per lane per fragment.
 template <int D_, bool LOGITS_EID, bool X3>
 __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
@@ -1175,7 +1319,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
           edge_phase(eb0, cx, d0.z + kWave, d0.w);                                     \
           if (d0.z + 2 * kWave < d0.w) {                                               \
             load_edges(eb0, cy);                                                       \
-            cx = chunk_idx(d0, d0.z + 4 * kWave);  /* fifth chunk (caps above 256) */   \
+            cx = chunk_idx(d0, d0.z + 4 * kWave);  /* fifth chunk (caps above 256) */  \
             edge_phase(eb0, cy, d0.z + 2 * kWave, d0.w);                               \
             if (d0.z + 3 * kWave < d0.w) {                                             \
               load_edges(eb0, cz);                                                     \

@@ -195,6 +195,9 @@ def head_groups(rel_ptr, dst_g):
     return gid, gptr, g_node[:max(n_groups, 1)].clone(), n_groups
 
 
+ATT_F32_PRODUCTS = 1  # include/kgat_hip.h: KGAT_ATT_F32_PRODUCTS
+
+
 def att_score_split_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_split_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
@@ -204,10 +207,10 @@ def att_score_folded_supported(n_nodes, d, k, n_rel):
 
 
 def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups, ent, W_R, rel,
-                    want_csr=True, g_tab=None, want_eid=True, folded=False):
+                    want_csr=True, g_tab=None, want_eid=True, folded=False, f32_products=False):
     """Attention logits via head groups (see kgat_att_score_split_f32; folded=True:
-    kgat_att_score_folded_f32, whose scratch table is n_groups x d).  Returns
-    (logits edge-id order, logits CSR order or None)."""
+    kgat_att_score_folded_f32, whose scratch table is n_groups x d; f32_products: its
+    KGAT_ATT_F32_PRODUCTS flag).  Returns (logits edge-id order, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
@@ -229,11 +232,12 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
     logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
     name = "kgat_att_score_folded_f32" if folded else "kgat_att_score_split_f32"
+    extra = ((ATT_F32_PRODUCTS if f32_products else 0),) if folded else ()
     with _timed("att_score", (e, d, k)):
         check(getattr(_lib.load(), name)(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
                                          _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), n_groups,
                                          _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(g_tab), _ptr(logits),
-                                         _ptr(logits_csr), _stream(ent)), name)
+                                         _ptr(logits_csr), *extra, _stream(ent)), name)
     return logits, logits_csr
 
 
@@ -285,9 +289,6 @@ def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, co
     return tiles, rel_tptr, part_tptr
 
 
-ATT_FUSED_F32_PRODUCTS = 1  # include/kgat_hip.h
-
-
 def att_score_fused_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_fused_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
@@ -296,7 +297,7 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
                     want_csr=True, want_eid=True, part_tptr=None, f32_products=False):
     """Attention logits, fused folded form (kgat_att_score_fused_f32).  `part_tptr`: the tile range
     of every workgroup (fold_tiles); None: equal tile counts, one workgroup per compute unit.
-    `f32_products`: the two products on the fp32 MFMA (KGAT_ATT_FUSED_F32_PRODUCTS) instead of the
+    `f32_products`: the two products on the fp32 MFMA (KGAT_ATT_F32_PRODUCTS) instead of the
     three-bf16-piece products the kernel takes by default when d % 32 == 0.
     Returns (logits edge-id order or None, logits CSR order or None)."""
     ent = _need(ent, torch.float32, "ent")
@@ -324,7 +325,7 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
                                                    _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), _ptr(tiles),
                                                    _ptr(rel_tptr), _ptr(part_tptr), n_parts, _ptr(ent), _ptr(W_R),
                                                    _ptr(rel), _ptr(logits), _ptr(logits_csr),
-                                                   ATT_FUSED_F32_PRODUCTS if f32_products else 0, _stream(ent)),
+                                                   ATT_F32_PRODUCTS if f32_products else 0, _stream(ent)),
               "kgat_att_score_fused_f32")
     return logits, logits_csr
 

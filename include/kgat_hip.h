@@ -61,13 +61,14 @@ enum {
   KGAT_ATT_ALGO_VARIANT_BASE = 16
 };
 
-/* flags for kgat_att_score_fused_f32 */
+/* flags for kgat_att_score_fused_f32 and kgat_att_score_folded_f32 */
 enum {
-  KGAT_ATT_FUSED_F32_PRODUCTS = 1 /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead
-                                   * of the default for d % 32 == 0: every fp32 operand cut into three
-                                   * bf16 pieces that together hold its 24 significand bits, the six
-                                   * piece products of weight >= 2^-16 accumulated in fp32 by
-                                   * v_mfma_f32_16x16x32_bf16 (dropped: <= 2^-24 of a product) */
+  KGAT_ATT_F32_PRODUCTS = 1 /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead of
+                             * the default where a kernel has it (fused: d % 32 == 0; folded: d = 128):
+                             * every fp32 operand cut into three bf16 pieces that together hold its 24
+                             * significand bits, the six piece products of weight >= 2^-16 accumulated
+                             * in fp32 by v_mfma_f32_16x16x32_bf16 (dropped: <= 2^-24 of a product;
+                             * error against fp64 measured no larger than the fp32 form's) */
 };
 
 typedef void* kgat_stream_t; /* hipStream_t */
@@ -158,14 +159,15 @@ int kgat_att_score_split_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
  * inputs and outputs as kgat_att_score_split_f32; the contraction order differs from the
  * reference's, so the results agree with the other forms to fp32 rounding (~1e-6 relative to
  * sum_j |t_j T_j|), not bit for bit.  Widths: d == k in {16,32,64,128} (MFMA), or d in {8,16,32}
- * with any k <= 32 (one thread per group; BASELINE configs[0] has d = k = 8). */
+ * with any k <= 32 (one thread per group; BASELINE configs[0] has d = k = 8).
+ * flags: 0 or KGAT_ATT_F32_PRODUCTS. */
 int kgat_att_score_folded_supported(int64_t n_nodes, int d, int k, int n_rel);
 int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                               const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                               const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
                               const int32_t* g_node, int64_t n_groups, const float* ent,
                               const float* W_R, const float* rel, float* V_tab, float* logits,
-                              float* logits_csr, kgat_stream_t stream);
+                              float* logits_csr, int flags, kgat_stream_t stream);
 
 /* Fused folded form: one launch, no V table.  Work tiles (graph-static, kgat_fold_tiles): at most
  * 16 consecutive head groups of one relation and at most `cap` grouped positions; a 16-group
@@ -199,7 +201,7 @@ int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const i
                          size_t workspace_bytes, kgat_stream_t stream);
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
 /* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
- * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_FUSED_F32_PRODUCTS. */
+ * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_F32_PRODUCTS. */
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
                              const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
                              const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,

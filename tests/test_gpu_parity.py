@@ -437,12 +437,13 @@ def test_att_fused_small_and_single_relation(K, dev):
         assert torch.equal(fused_csr, fused[eid.long()])
 
 
-@pytest.mark.parametrize("d", [32, 64])
+@pytest.mark.parametrize("d", [32, 64, 128])
 def test_att_fused_product_forms(K, dev, d):
-    """The fused kernel's default products (three bf16 pieces per fp32 operand, six piece products
-    in the fp32 accumulator of the bf16 MFMA) against its fp32-MFMA products and the fp64 oracle:
-    no further from fp64 than the fp32 form, under 8c and in absolute terms, also when the
-    operands span forty orders of magnitude (every piece keeps the fp32 exponent range)."""
+    """The default products of the fused kernel (d = 32, 64) and of the two-launch folded form's
+    head kernel (d = 128) - three bf16 pieces per fp32 operand, six piece products in the fp32
+    accumulator of the bf16 MFMA - against the fp32-MFMA products and the fp64 oracle: no further
+    from fp64 than the fp32 form, under 8c and in absolute terms, also when the operands span
+    forty orders of magnitude (every piece keeps the fp32 exponent range)."""
     from dgl_kgat_amd import ops
     rng = np.random.default_rng(2024 + d)
     n, e, R = 3000, 60000, 7
@@ -465,9 +466,14 @@ def test_att_fused_product_forms(K, dev, d):
         ref = orc.att_score(ent, W, rel, src, dst, et)
         got = {}
         for f32p in (False, True):
-            got[f32p] = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
-                                            tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False,
-                                            part_tptr=part_tptr, f32_products=f32p)[0].cpu().numpy()
+            if d <= 64:
+                out = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                          tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False,
+                                          part_tptr=part_tptr, f32_products=f32p)[0]
+            else:
+                out = ops.att_score_split(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_groups, tf(ent, dev),
+                                          tf(W, dev), tf(rel, dev), want_csr=False, folded=True, f32_products=f32p)[0]
+            got[f32p] = out.cpu().numpy()
             assert np.isfinite(got[f32p]).all()
         scale = max(float(np.abs(ref).max()), 1e-30)
         e_new, e_f32 = np.abs(got[False] - ref).max(), np.abs(got[True] - ref).max()
