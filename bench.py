@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+BF16_MFMA_PEAK_TF = 2500.0  # dense, MI355X_MICROARCH.md (Matrix cores)
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 matrix peak
 
 
@@ -496,21 +497,32 @@ def main():
             flops = ref_flops
             kern = "kgat_att_score_f32 (att_score_persistent_kernel)"
         tf_ = flops / (att_ms * 1e-3) / 1e12
+        # which matrix pipe the two products run on: three bf16 pieces per fp32 operand, six piece
+        # products per product on v_mfma_f32_16x16x32_bf16 (fused: d % 32 == 0; folded: d = 128), or
+        # v_mfma_f32_16x16x4_f32.  The ceiling of the first is the dense bf16 peak / 6.
+        pieces = (form == "fused" and D % 32 == 0) or (form == "folded" and D == 128)
+        att_peak = BF16_MFMA_PEAK_TF / 6.0 if pieces else FP32_MFMA_PEAK_TF
         att_traffic, att_traffic_file = None, None
         if form == "fused" and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
             # committed PMC measurement of the identical launch (see the SpMM's `traffic` above)
             att_traffic, att_traffic_file = committed_traffic(
                 "pmc_att_traffic.json", ("kgat_att_persistent.hip", "kgat_att_common.h", "kgat_common.h"))
         roofline_att = {"bound": "mfma", "kernel": kern, "form": form, "head_groups": int(n_groups),
-                        "achieved": round(tf_, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf_ / FP32_MFMA_PEAK_TF, 4), "traffic": att_traffic,
+                        "products": ("fp32 operands as three bf16 pieces, six piece products each on "
+                                     "v_mfma_f32_16x16x32_bf16 (fp32 accumulate; error vs fp64 no larger than the "
+                                     "fp32 MFMA's, tests/test_gpu_parity.py::test_att_fused_product_forms); peak = "
+                                     "dense bf16 peak / 6") if pieces else "v_mfma_f32_16x16x4_f32",
+                        "achieved": round(tf_, 2), "peak": round(att_peak, 1), "unit": "TFLOP/s",
+                        "frac": round(tf_ / att_peak, 4), "traffic": att_traffic,
                         "traffic_source": att_traffic_file, "median_ms": round(med_ms("att_score"), 4),
                         "avg_ms": round(att_ms, 4), "min_ms": round(att_min, 4),
                         "reference_flops_rate": round(ref_flops / (att_ms * 1e-3) / 1e12, 2),
-                        "note": "achieved = FLOPs this form executes / time (both launches); reference_flops_rate = the "
-                                "reference's per-edge formulation E*(4dk+3k) / time, an effective rate: the grouped forms "
-                                "do less arithmetic for the same logits, and the folded form's per-edge launch is a "
-                                "gather bound by the cache fabric, not by MFMA"}
+                        "note": "achieved = fp32-accuracy FLOPs this form executes / time (both launches); "
+                                "reference_flops_rate = the reference's per-edge formulation E*(4dk+3k) / time, an "
+                                "effective rate: the grouped forms do less arithmetic for the same logits.  With the "
+                                "piece products the fused kernel is bound by vector-instruction issue, not by the "
+                                "matrix pipe (per-wave clock stamps, profiles/: the pipe is ~40 % busy), and the folded "
+                                "form's per-edge launch is a gather bound by the cache fabric"}
 
     result = {
         "metric": "propagation-layer edges/sec on amazon-book CKG; achieved HBM GB/s vs peak",
@@ -520,6 +532,11 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "dtype_note": "fp32 storage and fp32 accumulation on the whole path.  The attention kernel's two dense "
+                      "products (d % 32 == 0) take each fp32 product as six bf16 piece products on the bf16 matrix "
+                      "pipe - every operand cut into three bf16 pieces that together hold its 24 significand bits, "
+                      "dropped terms <= 2^-24 of a product, fp32 accumulate: measured error against fp64 no larger "
+                      "than the fp32-MFMA form's (KGAT_ATT_F32_PRODUCTS selects that form)",
         "config": {"workload": "%s N=%d E=%d R=%d, %d layers, embed_dim=%d, fp32; step = compute_attention + "
                                "edge_softmax + %dx(u_mul_e_sum + bi-interaction) + normalize/concat"
                                % (name, n, E, n_rel, args.layers, D, args.layers),

@@ -48,11 +48,11 @@ ent = torch.randn(n, D, generator=g).to(dev)
 W = ((torch.rand(R, D, D, generator=g) - 0.5) * (2 * 1.414 * (6 / (D * D + R * D)) ** 0.5)).to(dev)
 rel = torch.randn(R, D, generator=g).to(dev)
 n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
-variants = [("equal tile counts", None)] + [("cost %s" % (c,), c) for c in ((64, 12, 466), (64, 12, 0), (64, 12, 233), (64, 8, 466), (64, 16, 700))]
+variants = [("equal tile counts", None)] + [("cost %s" % (c,), c) for c in (ops.FOLD_TILE_COST, ops.FOLD_TILE_COST_F32, (64, 12, 0), (64, 38, 0), (64, 25, 1051), (64, 50, 1400))]
 fit_rows, fit_y = [], []
 for cap in (256, 512):
     for name, cost in variants:
-        tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups, cap=cap, cost=cost or (64, 12, 466))
+        tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups, cap=cap, cost=cost or ops.FOLD_TILE_COST)
         pt = parts if cost else None
         fn = lambda: ops.att_score_fused(n, rp, perm, sg, idx, gid, gptr, g_node, tiles, tptr, ent, W, rel,  # noqa: E731
                                          want_eid=False, part_tptr=pt)
