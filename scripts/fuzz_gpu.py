@@ -100,7 +100,7 @@ def one(seed):
     stage("spmm D=%d" % D)
     # attention: every form that supports the shape
     R = int(rng.choice([1, 2, 5, 41]))
-    d = int(rng.choice([16, 32, 64]))
+    d = int(rng.choice([16, 32, 64, 64, 128]))
     et = rng.integers(-1 if rng.random() < 0.3 else 0, R + (1 if rng.random() < 0.3 else 0), e).astype(np.int32)
     ent = rng.standard_normal((n, d)).astype(np.float32)
     W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
@@ -115,15 +115,20 @@ def one(seed):
     tiles, tptr, parts = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=int(rng.choice([1, 7, 256])))
     stage("attention structures R=%d d=%d cap=%d parts=%d groups=%d" % (R, d, cap, parts.numel() - 1, n_groups))
     got = {}
-    got["fused"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts)[0]
-    stage("fused")
-    got["fused, fp32 products"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts,
-                                                      f32_products=True)[0]
-    stage("fused, fp32 products")
+    if ops.att_score_fused_supported(n, d, d, R):
+        got["fused"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts)[0]
+        stage("fused")
+        got["fused, fp32 products"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts,
+                                                          f32_products=True)[0]
+        stage("fused, fp32 products")
     got["folded"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True)[0]
     stage("folded")
-    got["split"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel))[0]
-    stage("split")
+    got["folded, fp32 products"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True,
+                                                       f32_products=True)[0]
+    stage("folded, fp32 products")
+    if ops.att_score_split_supported(n, d, d, R):
+        got["split"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel))[0]
+        stage("split")
     got["one"] = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent), tf(W), tf(rel))[0]
     stage("attention launches R=%d d=%d cap=%d parts=%d" % (R, d, cap, parts.numel() - 1))
     for k, v in got.items():
