@@ -631,6 +631,23 @@ struct SpmmArgs {
 constexpr int run_len(int lpr) { return lpr >= 8 ? 64 : (lpr == 4 ? 32 : (lpr == 2 ? 16 : 8)); }
 constexpr int short_run_len(int lpr) { return run_len(lpr) / 4 >= 4 ? run_len(lpr) / 4 : 4; }
 constexpr int64_t kShortRunTileLimit = 4096;  // use the short runs while they give at most this many tiles
+// Between the two, for rows of 64 and 128 bytes (LPR = 4, 8: a tile is 2,048 edges there): half
+// the run length while that gives at most kMidRunTileLimit tiles.  A launch of a few thousand
+// full-length tiles ends with its last, longest tiles running on a nearly empty chip (tile times
+// spread 14 k - 52 k cycles; 1,789 tiles on 1,280 workgroup slots at D = 32 on the amazon-book
+// graph), and half-length tiles halve that tail: D = 32 0.079 -> 0.066 ms, D = 16 0.066 -> 0.060
+// (quarter length: 0.076; at D = 64 / 128, 16-KB tiles of 1,024 edges, half length changes nothing,
+// at D = 8 it costs 6-10 %: scripts/micro/spmm_runlen_ab.py).  The two macros exist for that A/B build only.
+#ifndef KGAT_SPMM_MID_DIV
+#define KGAT_SPMM_MID_DIV 2
+#endif
+constexpr int mid_run_len(int lpr) {
+  return (lpr == 8 || lpr == 4) ? run_len(lpr) / KGAT_SPMM_MID_DIV : run_len(lpr);
+}
+#ifndef KGAT_SPMM_MID_LIMIT
+#define KGAT_SPMM_MID_LIMIT 16384
+#endif
+constexpr int64_t kMidRunTileLimit = KGAT_SPMM_MID_LIMIT;
 
 template <int LPR, int C>
 static int64_t merge_tiles_c(int64_t n_edges) {
@@ -641,6 +658,10 @@ static int64_t merge_tiles_c(int64_t n_edges) {
 template <int LPR>
 static bool use_short_runs(int64_t n_edges) {
   return merge_tiles_c<LPR, short_run_len(LPR)>(n_edges) <= kShortRunTileLimit;
+}
+template <int LPR>
+static bool use_mid_runs(int64_t n_edges) {
+  return merge_tiles_c<LPR, mid_run_len(LPR)>(n_edges) <= kMidRunTileLimit;
 }
 
 template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
@@ -682,6 +703,8 @@ template <int LPR, bool MUL_SELF, bool HAS_EID>
 static int launch_merge(const SpmmArgs& a) {
   if (use_short_runs<LPR>((int64_t)a.e1_host - a.e0_host))
     return launch_merge_c<LPR, short_run_len(LPR), MUL_SELF, HAS_EID>(a);
+  if (use_mid_runs<LPR>((int64_t)a.e1_host - a.e0_host))
+    return launch_merge_c<LPR, mid_run_len(LPR), MUL_SELF, HAS_EID>(a);
   return launch_merge_c<LPR, run_len(LPR), MUL_SELF, HAS_EID>(a);
 }
 
@@ -770,8 +793,10 @@ size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   if (lpr == 0 || n_edges <= 0) return 256;
   const int nsub = kSpmmThreads / lpr;
   const int64_t te = (int64_t)nsub * run_len(lpr), te_s = (int64_t)nsub * short_run_len(lpr);
+  const int64_t te_m = (int64_t)nsub * mid_run_len(lpr);
   int64_t tiles = (n_edges + te - 1) / te;
-  const int64_t tiles_s = (n_edges + te_s - 1) / te_s;
+  const int64_t tiles_s = (n_edges + te_s - 1) / te_s, tiles_m = (n_edges + te_m - 1) / te_m;
+  if (tiles_m <= kMidRunTileLimit && tiles_m > tiles) tiles = tiles_m;    // the launch takes the half-length runs
   if (tiles_s <= kShortRunTileLimit && tiles_s > tiles) tiles = tiles_s;  // the launch takes the short runs
   return align_up((size_t)tiles * 2 * lpr * sizeof(float4), 256) + 256;
 }

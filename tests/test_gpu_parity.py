@@ -717,6 +717,37 @@ def test_destination_shards_reassemble_to_unsharded(K, dev):
         assert torch.all(wide[:, :4] == 3.0) and torch.all(wide[:, 52:] == 3.0) and torch.all(wide[7, 4:52] == 0)
 
 
+def test_att_product_flag_is_validated(K, dev):
+    """An unknown flag bit of kgat_att_score_fused_f32 / kgat_att_score_folded_f32 is a bad
+    argument (KGAT_E_BADARG, message through kgat_last_error), not silently ignored."""
+    from dgl_kgat_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    n, e, R, d = 200, 3000, 3, 64
+    src, dst = rng.integers(0, n, e).astype(np.int32), rng.integers(0, n, e).astype(np.int32)
+    et = rng.integers(0, R, e).astype(np.int32)
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups)
+    ent, W, rel = torch.randn(n, d, device=dev), torch.randn(R, d, d, device=dev) * 0.1, torch.randn(R, d, device=dev)
+    out = torch.empty(e, device=dev)
+    lib = _lib.load()
+    p = lambda t: t.data_ptr()  # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    for flags, want in ((0, 0), (1, 0), (2, -1), (-1, -1)):
+        rc = lib.kgat_att_score_fused_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(src_g), p(pos_g), p(gid), p(gptr),
+                                          p(g_node), p(tiles), p(rel_tptr), p(part_tptr), part_tptr.numel() - 1, p(ent),
+                                          p(W), p(rel), p(out), None, flags, st)
+        assert rc == want, (flags, rc, lib.kgat_last_error())
+        if want:
+            assert b"unknown flag" in lib.kgat_last_error()
+    v_tab = torch.empty(max(n_groups, 1), d, device=dev)
+    for flags, want in ((0, 0), (1, 0), (4, -1)):
+        rc = lib.kgat_att_score_folded_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(src_g), p(pos_g), p(gid), p(gptr),
+                                           p(g_node), n_groups, p(ent), p(W), p(rel), p(v_tab), p(out), None, flags, st)
+        assert rc == want, (flags, rc, lib.kgat_last_error())
+    torch.cuda.synchronize()
+
+
 def test_readout_concat(K, dev):
     """kgat_readout_concat_f32: [h0 | normalize(h1) | ...] (models.py:159-168) from separate blocks."""
     from dgl_kgat_amd import ops
