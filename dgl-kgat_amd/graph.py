@@ -253,10 +253,16 @@ class _Structure:
                                                w_csr, w_flat)
 
 
+def _f32_products():
+    """``KGAT_ATT_F32_PRODUCTS=1``: the attention kernels' two products on the fp32 MFMA (the C
+    ABI's KGAT_ATT_F32_PRODUCTS flag) instead of the default bf16-piece products."""
+    return os.environ.get("KGAT_ATT_F32_PRODUCTS", "") not in ("", "0")
+
+
 def _fused_tiles(groups, d):
     """Work tiles of the fused attention kernel and their split over the workgroups, kept with the
     relation grouping (graph-static); the split cost goes with the product form taken at width d."""
-    cost = ops.fold_tile_cost(d)
+    cost = ops.fold_tile_cost(d, _f32_products())
     tiles = groups.g_tab.get("tiles")
     if tiles is None or groups.g_tab.get("tiles_cost") != cost:
         tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups,
@@ -556,7 +562,8 @@ class DGLGraph:
                 tiles = _fused_tiles(groups, d)  # graph-static work tiles of the fused kernel
                 return ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
                                            groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
-                                           ent_c, W_c, rel_c, want_eid=False, part_tptr=tiles[2])[1]
+                                           ent_c, W_c, rel_c, want_eid=False, part_tptr=tiles[2],
+                                           f32_products=_f32_products())[1]
             if form in ("folded", "split"):
                 folded = form == "folded"
                 width = d if folded else k
@@ -566,7 +573,8 @@ class DGLGraph:
                                                               device=dev)
                 return ops.att_score_split(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
                                            groups.gid, groups.gptr, groups.g_node, groups.n_groups,
-                                           ent_c, W_c, rel_c, g_tab=g_tab, want_eid=False, folded=folded)[1]
+                                           ent_c, W_c, rel_c, g_tab=g_tab, want_eid=False, folded=folded,
+                                           f32_products=folded and _f32_products())[1]
             return ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                  ent_c, W_c, rel_c, pos_g=groups.pos_g, algo="auto" if form == "one" else form)[1]
 

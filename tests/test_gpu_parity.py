@@ -748,6 +748,24 @@ def test_att_product_flag_is_validated(K, dev):
     torch.cuda.synchronize()
 
 
+def test_f32_products_switch_on_the_surface(K, dev, monkeypatch):
+    """KGAT_ATT_F32_PRODUCTS=1 routes compute_attention's kernels to the fp32-MFMA products: same
+    weights to rounding, through the same entry points (the flag of the C ABI)."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.collaborative_kg(300, 400, 300, 5, 20000, 9000, seed=3)
+    torch.manual_seed(0)
+    m = K.KGATPropagation(n, R, 64, 64, 1, 64, dropout=0.0).to(dev)
+    outs = {}
+    for val in ("", "1"):
+        monkeypatch.setenv("KGAT_ATT_F32_PRODUCTS", val)
+        g = synth.build_graph(n, trip, dev)
+        with torch.no_grad():
+            outs[val] = torch.as_tensor(m.compute_attention(g)).clone()
+    torch.cuda.synchronize()
+    assert float((outs[""] - outs["1"]).abs().max()) < 2e-6
+    assert not torch.equal(outs[""], outs["1"])  # two different summations
+
+
 def test_readout_concat(K, dev):
     """kgat_readout_concat_f32: [h0 | normalize(h1) | ...] (models.py:159-168) from separate blocks."""
     from dgl_kgat_amd import ops
