@@ -468,3 +468,22 @@ def test_bench_traffic_records_are_keyed_on_the_kernel_sources(tmp_path, monkeyp
     with open(tmp_path / "dgl-kgat_amd" / "csrc" / "kgat_spmm.hip", "ab") as fh:
         fh.write(b"// edited\n")
     assert bench.committed_traffic("pmc_spmm_traffic.json", srcs) == (None, None)
+
+
+def test_attention_product_form_switches(monkeypatch):
+    """Host-side choice of the attention kernels' product form: the split cost follows the form the
+    kernel will take at a width, and KGAT_ATT_F32_PRODUCTS is read as a boolean switch."""
+    import dgl_kgat_amd  # noqa: F401
+    from dgl_kgat_amd import graph, ops
+    assert ops.fold_tile_cost(64) == ops.FOLD_TILE_COST and ops.fold_tile_cost(32) == ops.FOLD_TILE_COST
+    assert ops.fold_tile_cost(16) == ops.FOLD_TILE_COST_F32          # no bf16-piece form below 32
+    assert ops.fold_tile_cost(64, f32_products=True) == ops.FOLD_TILE_COST_F32
+    assert ops.ATT_F32_PRODUCTS == 1
+    for val, want in (("", False), ("0", False), ("1", True), ("yes", True)):
+        monkeypatch.setenv("KGAT_ATT_F32_PRODUCTS", val)
+        assert graph._f32_products() is want
+    monkeypatch.delenv("KGAT_ATT_F32_PRODUCTS")
+    assert graph._f32_products() is False
+    # the header and the loader agree on the flag and on the ABI version that introduced it
+    hdr = open(os.path.join(ROOT, "include", "kgat_hip.h")).read()
+    assert "KGAT_ATT_F32_PRODUCTS = 1" in hdr and "#define KGAT_ABI_VERSION 3" in hdr
