@@ -766,6 +766,36 @@ def test_f32_products_switch_on_the_surface(K, dev, monkeypatch):
     assert not torch.equal(outs[""], outs["1"])  # two different summations
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_att_nonfinite_inputs_stay_contained(K, dev, d):
+    """An Inf / NaN embedding entry (a diverged model) poisons exactly the softmax rows that hold an
+    edge of that node - the bf16-piece cut turns Inf into NaN, nothing else - and every other
+    weight keeps its bits; entries near FLT_MAX and subnormals stay finite."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.collaborative_kg(300, 400, 300, 5, 20000, 9000, seed=3)
+    torch.manual_seed(0)
+    m = K.KGATPropagation(n, R, d, d, 1, d, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    dst = torch.as_tensor(trip[:, 0].astype(np.int64)).to(dev)
+    touched = (torch.as_tensor(trip[:, 0] == 7) | torch.as_tensor(trip[:, 2] == 7)).to(dev)
+    rows = torch.zeros(n, dtype=torch.bool, device=dev)
+    rows[dst[touched]] = True
+    clean = ~rows[dst]
+    with torch.no_grad():
+        a0 = torch.as_tensor(m.compute_attention(g)).clone().reshape(-1)
+        assert torch.isfinite(a0).all()
+        for val, poisons in ((float("inf"), True), (float("nan"), True), (1e38, False), (1e-45, False)):
+            w = m.entity_embed.weight
+            old = w[7].clone()
+            w[7, 3] = val
+            a = torch.as_tensor(m.compute_attention(g)).clone().reshape(-1)
+            w[7] = old
+            bad = ~torch.isfinite(a)
+            assert bool(bad.any()) == poisons, val
+            assert not bool((bad & clean).any()), val
+            assert torch.equal(a[clean], a0[clean]), val
+
+
 def test_readout_concat(K, dev):
     """kgat_readout_concat_f32: [h0 | normalize(h1) | ...] (models.py:159-168) from separate blocks."""
     from dgl_kgat_amd import ops
