@@ -500,7 +500,8 @@ def main():
         # which matrix pipe the two products run on: three bf16 pieces per fp32 operand, six piece
         # products per product on v_mfma_f32_16x16x32_bf16 (fused: d % 32 == 0; folded: d = 128), or
         # v_mfma_f32_16x16x4_f32.  The ceiling of the first is the dense bf16 peak / 6.
-        pieces = (form == "fused" and D % 32 == 0) or (form == "folded" and D == 128)
+        from dgl_kgat_amd.graph import _f32_products
+        pieces = not _f32_products() and ((form == "fused" and D % 32 == 0) or (form == "folded" and D == 128))
         att_peak = BF16_MFMA_PEAK_TF / 6.0 if pieces else FP32_MFMA_PEAK_TF
         att_traffic, att_traffic_file = None, None
         if form == "fused" and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
