@@ -54,8 +54,9 @@ SIGNATURES = {
     "kgat_att_score_fused_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "kgat_fold_tile_parts_workspace_bytes": (_sz, [_i64]),
     "kgat_fold_tile_parts": (_i32, [_i64, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
-    "kgat_att_score_fused_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
-                                        _p, _p, _p, _p, _p, _i32, _p]),
+    "kgat_att_pack_records": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "kgat_att_score_fused_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
+                                        _p, _p, _p, _p, _p, _p, _i32, _p]),
     "kgat_edge_softmax_workspace_bytes": (_sz, [_i64, _i64]),
     "kgat_edge_softmax_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "kgat_edge_softmax_3pass_workspace_bytes": (_sz, [_i64]),
@@ -65,10 +66,10 @@ SIGNATURES = {
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _p, _sz, _u32, _i32, _p]),
     "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
-    "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _p, _p,
-                                             _i64, _p]),
-    "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _p,
-                                               _p]),
+    "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _i64, _p,
+                                             _p, _i64, _p]),
+    "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _i64,
+                                               _p, _p]),
     "kgat_mul2_f32": (_i32, [_i64, _p, _p, _p, _p, _p, _p]),
     "kgat_transr_supported": (_i32, [_i64, _i32, _i32, _i32, _i64]),
     "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
@@ -98,7 +99,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def source_hash():
@@ -147,10 +148,27 @@ def _unit_hash(src, flags):
 def build(force=False):
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU): one
     object per source (per-file flags; an object whose inputs did not change is kept), then one
-    shared library.  The source hash is compiled into kgat_graph.hip (kgat_build_hash)."""
+    shared library.  The source hash is compiled into kgat_graph.hip (kgat_build_hash).
+
+    Safe under a multi-rank launch after a source edit: the build holds an exclusive lock on a
+    file in the object directory (the other ranks wait, then find the library fresh), and objects
+    and the library are written under temporary names and moved into place atomically, so no
+    process can dlopen a half-written file."""
     if not (force or needs_build()):
         return SO_PATH
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not (force or needs_build()):  # another process built it while this one waited
+                return SO_PATH
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force):
     procs, objs = [], []
     tag = '-DKGAT_BUILD_HASH="kgat-src-hash:%s"' % source_hash()
     for src, extra in SOURCES.items():
@@ -165,13 +183,22 @@ def build(force=False):
             fresh = False
         if fresh and not force:
             continue
-        procs.append((subprocess.Popen([_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]), obj, key))
-    for p, obj, key in procs:
+        tmp = "%s.%d.tmp" % (obj, os.getpid())
+        procs.append((subprocess.Popen([_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", tmp]), obj, tmp, key))
+    failed = None
+    for p, obj, tmp, key in procs:
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, p.args)
-        with open(obj + ".key", "w") as fh:
+            failed = failed or subprocess.CalledProcessError(p.returncode, p.args)
+            continue
+        os.replace(tmp, obj)
+        with open(obj + ".key.tmp", "w") as fh:
             fh.write(key)
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs)
+        os.replace(obj + ".key.tmp", obj + ".key")
+    if failed is not None:
+        raise failed
+    so_tmp = "%s.%d.tmp" % (SO_PATH, os.getpid())
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so_tmp] + objs)
+    os.replace(so_tmp, SO_PATH)
     return SO_PATH
 
 

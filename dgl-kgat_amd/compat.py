@@ -73,7 +73,8 @@ def accelerate(model):
     def compute_attention(self, g, algo="auto"):
         return KGATPropagation.compute_attention(self, g, algo)
 
-    for name in ("_can_fuse_readout", "_can_fuse_training", "_gnn_fused", "_gnn_fused_sharded", "_node_embeddings"):
+    for name in ("_can_fuse_readout", "_can_fuse_training", "_gnn_fused", "_gnn_fused_sharded", "_gnn_train_sharded",
+                 "_node_embeddings"):
         setattr(model, name, types.MethodType(getattr(KGATPropagation, name), model))
     model.gnn = types.MethodType(gnn, model)
     model.compute_attention = types.MethodType(compute_attention, model)

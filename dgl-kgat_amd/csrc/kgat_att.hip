@@ -529,12 +529,12 @@ int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel) {
 }
 
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
-                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
-                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                             const int32_t* pos_g, const int32_t* gptr,
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
                              const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
-                             float* logits_csr, int flags, kgat_stream_t stream) {
+                             float* logits_csr, float* logits_g, int flags, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
   KGAT_CHECK_ARG((flags & ~KGAT_ATT_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
   if (n_edges == 0) return KGAT_OK;
@@ -543,9 +543,11 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
               kAttMaxRelLds, d, k, n_rel);
     return KGAT_E_UNSUPPORTED;
   }
-  KGAT_CHECK_ARG(rel_ptr && perm && src_g && gid && gptr && g_node && tiles && rel_tptr && ent && W_R && rel,
+  KGAT_CHECK_ARG(n_nodes <= (1ll << 28), "att_score_fused: packed records hold node ids below 2^28");
+  KGAT_CHECK_ARG(rel_ptr && rec_g && gptr && g_node && tiles && rel_tptr && ent && W_R && rel,
                  "att_score_fused: null pointer");
-  KGAT_CHECK_ARG(logits || logits_csr, "att_score_fused: no output requested");
+  KGAT_CHECK_ARG(logits || logits_csr || logits_g, "att_score_fused: no output requested");
+  KGAT_CHECK_ARG(logits == nullptr || perm != nullptr, "att_score_fused: edge-id ordered logits need perm");
   KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score_fused: logits_csr needs pos_g");
   KGAT_CHECK_ARG((part_tptr == nullptr) == (n_parts == 0) && n_parts >= 0 && n_parts <= 65536,
                  "att_score_fused: part_tptr and n_parts go together");
@@ -554,11 +556,12 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   a.part_tptr = part_tptr;
   a.f32_products = (flags & KGAT_ATT_F32_PRODUCTS) != 0;
   a.st = as_stream(stream);
-  a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = src_g; a.dst_g = nullptr;
+  a.n_rel = n_rel; a.rel_ptr = rel_ptr; a.perm = perm; a.src_g = nullptr; a.dst_g = nullptr;
   a.ent = ent; a.W_R = W_R; a.rel = rel; a.logits = logits; a.logits_csr = logits_csr;
   a.pos_g = pos_g;
   a.n_edges = n_edges;
-  a.gid = gid; a.gptr = gptr; a.g_node = g_node;
+  a.gid = nullptr; a.gptr = gptr; a.g_node = g_node;
+  a.rec_g = rec_g; a.logits_g = logits_g;
   return launch_att_fold_fused_any(d, a, rel_tptr, tiles);
 }
 

@@ -98,6 +98,8 @@ struct AttArgs {
   int64_t n_edges = 0;
   bool needs_memset = true;
   const int32_t* part_tptr = nullptr;  // fused form: tile range per workgroup (grid = number of parts)
+  const int32_t* rec_g = nullptr;      // fused form: packed (source node | group slot << 28) per grouped position
+  float* logits_g = nullptr;           // fused form: logits in grouped order
   bool f32_products = false;           // fused / folded forms: fp32 MFMA products instead of the bf16-piece products
 };
 

@@ -670,32 +670,46 @@ __device__ unsigned long long* g_att_phases = nullptr;
 #endif
 
 // Products at fp32 accuracy on the bf16 matrix pipe (X3 = true in the kernels below; d = k a
-// multiple of 32).  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by truncation
-// (h = the top 16 bits of x, m the top 16 bits of x - h, l the top 16 bits of x - h - m: 8
-// significand bits each, so the three pieces hold all 24 bits of x and the two subtractions are
-// exact), and a product a*b is taken as the six piece products of weight >= 2^-16 (l*h, h*l, m*m,
-// m*h, h*m, h*h; the three dropped ones are <= 2^-24 of a*b, a quarter of an fp32 rounding), each
-// exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  Six MFMAs of 16 cycles for a
+// multiple of 32).  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by rounding to
+// nearest (v_cvt_pk_bf16_f32): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m).  Both subtractions
+// are exact, |m| <= 2^-8 |x| (half an ulp of 8 significand bits), |x - h - m| <= 2^-16 |x| is a
+// multiple of ulp_24(x) below 2^8 ulps, so l holds it exactly: the three pieces sum to x bit for
+// bit, and every piece keeps the fp32 exponent range.  A product a*b is taken as the six piece
+// products of weight >= 2^-16 (l*h, h*l, m*m, m*h, h*m, h*h), each exact in the fp32 accumulator of
+// v_mfma_f32_16x16x32_bf16 and accumulated smallest first; the three dropped ones (m*l, l*m, l*l)
+// are together <= 2 * 2^-8 * 2^-16 + 2^-32 < 2^-23 + 2^-30 of |a*b| - one fp32 ulp, of either sign
+// (the remainders of a round-to-nearest cut are signed, so the dropped terms do not bias a sum; the
+// truncating cut of round 2 left them one-signed and up to 2^-21).  Six MFMAs of 16 cycles for a
 // 16x16x32 block against eight fp32 MFMAs of 32 cycles: 2.7 x fewer matrix-pipe cycles.  W_r's
 // pieces are cut once per relation segment into LDS; the head rows and the tanh values are cut in
-// registers.  Non-finite operands give NaN (Inf - Inf in the cut), where the fp32 products follow
-// IEEE and can give +-Inf.
+// registers (11 VALU instructions per pair of values).  Non-finite operands give NaN (Inf - Inf in
+// the cut), where the fp32 products follow IEEE and can give +-Inf.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 
+// two floats -> packed bf16 pair (a in the low half), round to nearest even.  Inline asm so that
+// the two unpacks below read this one register (the compiler's own lowering of the cast re-converts
+// the low element alone before shifting it).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void split_bf16x3(const float (&x)[8], uintx4& h, uintx4& m, uintx4& l) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const unsigned u0 = __float_as_uint(x[2 * t]), u1 = __float_as_uint(x[2 * t + 1]);
-    h[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // (u1 & 0xffff0000) | (u0 >> 16)
-    const float r0 = x[2 * t] - __uint_as_float(u0 & 0xffff0000u);
-    const float r1 = x[2 * t + 1] - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    m[t] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
-    const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    l[t] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    const float x0 = x[2 * t], x1 = x[2 * t + 1];
+    const unsigned hh = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hh << 16);
+    const float r1 = x1 - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(mm << 16);
+    const float s1 = r1 - __uint_as_float(mm & 0xffff0000u);
+    h[t] = hh;
+    m[t] = mm;
+    l[t] = cvt_pk_bf16(s0, s1);
   }
 }
 
@@ -1015,14 +1029,22 @@ constexpr int kFusedThreads = 512;
 
 // X3: the two products as bf16-piece products (above); W_r's pieces sit in LDS already in fragment
 // order, one 16-byte read per lane per fragment.
-template <int D_, bool LOGITS_EID, bool X3>
+// A grouped position p comes as ONE packed record rec_g[p] = source node | (group slot << 28) (slot =
+// the position's head group inside its 16-group block; kgat_att_pack_records): one 4-byte index load
+// per position instead of three.  OUT selects where the logits go: 0 = grouped order only (logits_g,
+// coalesced 256-byte stores; the softmax reads them through the inverse map), 1 = also CSR order
+// (4-byte scatter through pos_g), 2 = also edge-id order (scatter through perm).
+template <int D_, int OUT, bool X3>
 __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
     const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
-    const int32_t* __restrict__ gid, const int32_t* __restrict__ src_g, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rec_g, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ pos_g, const float* __restrict__ ent, const float* __restrict__ W_R,
     const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr,
-    const int32_t* __restrict__ part_tptr) {
+    float* __restrict__ logits_g, const int32_t* __restrict__ part_tptr) {
+  constexpr bool LOGITS_EID = OUT == 2;
+  constexpr int ROW_SHIFT = D_ == 64 ? 8 : (D_ == 32 ? 7 : 6);  // log2 of a row's bytes
+  static_assert((D_ * 4) == (1 << ROW_SHIFT), "row bytes");
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFusedThreads / kWave;
   constexpr int LPE = kFusedLanesPerEdge<D_>();    // lanes per edge in the edge phase
@@ -1042,14 +1064,14 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   const int lane = tid % kWave, w = tid / kWave;
   const int i = lane & 15, q = lane >> 4;
   const int li = lane % LPE;
-  const int32_t* __restrict__ pos_or_perm = logits_csr ? pos_g : perm;
 
   {  // relation ids outside [0, R): logit 0
     const int64_t n_scored = rel_ptr[n_rel];
     for (int64_t p = n_scored + (int64_t)blockIdx.x * kFusedThreads + tid; p < n_edges;
          p += (int64_t)gridDim.x * kFusedThreads) {
       if (LOGITS_EID) logits[perm[p]] = 0.f;
-      if (logits_csr) logits_csr[pos_g[p]] = 0.f;
+      if (OUT >= 1 && logits_csr) logits_csr[pos_g[p]] = 0.f;
+      if (logits_g) logits_g[p] = 0.f;
     }
   }
   const int32_t n_tiles = rel_tptr[n_rel];
@@ -1132,10 +1154,13 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       int32_t p = p0 + lane;
       p = p < d.w ? p : d.w - 1;
       CIdx c;
-      c.row_off = (int32_t)((uint32_t)src_g[p] * (uint32_t)(D_ * 4));  // byte offset, < 4 GiB (checked by the caller)
-      c.lg = gid[p] - d.y;
+      const uint32_t rec = (uint32_t)rec_g[p];
+      // byte offset of the source row: N * d * 4 < 4 GiB (checked by the caller), so the node id ends
+      // below bit 32 - ROW_SHIFT and the shift drops exactly the slot bits
+      c.row_off = (int32_t)(rec << ROW_SHIFT);
+      c.lg = (int32_t)(rec >> 28);
       c.oe = LOGITS_EID ? perm[p] : 0;
-      c.op = pos_or_perm[p];
+      c.op = (OUT >= 1 && logits_csr) ? pos_g[p] : 0;
       return c;
     };
     struct HBuf { float a[KS]; };
@@ -1269,7 +1294,8 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       }
       if (p0 + lane < pe) {
         if (LOGITS_EID) logits[c.oe] = mine;
-        if (logits_csr) logits_csr[c.op] = mine;
+        if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;
+        if (logits_g) logits_g[p0 + lane] = mine;
       }
     };
 
@@ -1361,24 +1387,26 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
 #endif
 }
 
-template <int D_, bool EID, bool X3>
+template <int D_, int OUT, bool X3>
 static void launch_att_fold_fused_form(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
   const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
-  hipLaunchKernelGGL((att_fold_fused_kernel<D_, EID, X3>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
-                     a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.gid,
-                     a.src_g, a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.part_tptr);
+  hipLaunchKernelGGL((att_fold_fused_kernel<D_, OUT, X3>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
+                     a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.rec_g,
+                     a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr);
+}
+
+template <int D_, bool X3>
+static void launch_att_fold_fused_out(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  if (a.logits) launch_att_fold_fused_form<D_, 2, X3>(a, rel_tptr, tiles);
+  else if (a.logits_csr) launch_att_fold_fused_form<D_, 1, X3>(a, rel_tptr, tiles);
+  else launch_att_fold_fused_form<D_, 0, X3>(a, rel_tptr, tiles);
 }
 
 template <int D_>
 static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
   constexpr bool kCanSplit = D_ % 32 == 0;
-  if (kCanSplit && !a.f32_products) {
-    if (a.logits) launch_att_fold_fused_form<D_, true, kCanSplit>(a, rel_tptr, tiles);
-    else launch_att_fold_fused_form<D_, false, kCanSplit>(a, rel_tptr, tiles);
-  } else {
-    if (a.logits) launch_att_fold_fused_form<D_, true, false>(a, rel_tptr, tiles);
-    else launch_att_fold_fused_form<D_, false, false>(a, rel_tptr, tiles);
-  }
+  if (kCanSplit && !a.f32_products) launch_att_fold_fused_out<D_, kCanSplit>(a, rel_tptr, tiles);
+  else launch_att_fold_fused_out<D_, false>(a, rel_tptr, tiles);
   KGAT_CHECK_LAUNCH("att_fold_fused");
   return KGAT_OK;
 }

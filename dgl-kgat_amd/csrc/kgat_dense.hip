@@ -47,8 +47,8 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t index, uint32_
 template <int DI, int DO, bool TRAIN, bool VEC_NORM>
 __global__ __launch_bounds__(256) void bi_interaction_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
-    float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, float* __restrict__ h_out,
-    float* __restrict__ norm_out, int64_t norm_stride) {
+    float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, uint32_t index0,
+    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride) {
   constexpr int KS = DI / 4, KT = DO / 16;
   // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
   // laid out in B-fragment order so that every wave then pulls its fragments with
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         float z = acc[c][j];
         z = z >= 0.f ? z : z * slope;
         if (TRAIN)
-          z = drop_keep(seed, (uint32_t)row * (uint32_t)DO + (uint32_t)(16 * c + 4 * q + j), drop_threshold)
+          z = drop_keep(seed, index0 + (uint32_t)row * (uint32_t)DO + (uint32_t)(16 * c + 4 * q + j), drop_threshold)
                   ? z * keep_scale : 0.f;
         acc[c][j] = z;
         ss = fmaf(z, z, ss);
@@ -232,10 +232,12 @@ struct DropArgs {
   uint32_t threshold = 0;
   float keep_scale = 1.f;
   uint32_t seed = 0;
+  uint32_t index0 = 0;  // element index of (row 0, column 0): row0 * d_out for a row range of a larger matrix
 };
 
-static DropArgs drop_args(float p, uint64_t seed) {
+static DropArgs drop_args(float p, uint64_t seed, int64_t row0, int d_out) {
   DropArgs a;
+  a.index0 = (uint32_t)((uint64_t)row0 * (uint64_t)d_out);
   double t = (double)p * 4294967296.0;
   a.threshold = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   a.keep_scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
@@ -254,8 +256,8 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
                    ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);
 #define KGAT_BI_LAUNCH(TR, VEC)                                                                                     \
   hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, TR, VEC>), dim3((unsigned)blocks), dim3(256), 0, st,            \
-                     (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, h_out, norm_out,      \
-                     norm_stride)
+                     (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,     \
+                     norm_out, norm_stride)
   if (HN) {
     if (vec) KGAT_BI_LAUNCH(true, true); else KGAT_BI_LAUNCH(true, false);
   } else {
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void bi_bwd_pre_kernel(int64_t n_rows, int d, 
                                                          const float* __restrict__ gA, const float* __restrict__ gB,
                                                          const float* __restrict__ g_norm, int64_t g_norm_stride,
                                                          float slope, uint32_t drop_threshold, float keep_scale,
-                                                         uint32_t seed, float* __restrict__ dZ) {
+                                                         uint32_t seed, uint32_t index0, float* __restrict__ dZ) {
   const int sub = threadIdx.x >> 4, sl = threadIdx.x & 15;
   for (int64_t row = (int64_t)blockIdx.x * 16 + sub; row < n_rows; row += (int64_t)gridDim.x * 16) {
     const float* yr = y + (size_t)row * d;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void bi_bwd_pre_kernel(int64_t n_rows, int d, 
         float g = (gn[c] - yv[c] * proj) * inv;
         if (gA) g += gA[(size_t)row * d + i];
         if (gB) g += gB[(size_t)row * d + i];
-        const bool keep = drop_keep(seed, (uint32_t)row * (uint32_t)d + (uint32_t)i, drop_threshold);
+        const bool keep = drop_keep(seed, index0 + (uint32_t)row * (uint32_t)d + (uint32_t)i, drop_threshold);
         dZ[(size_t)row * d + i] = keep ? g * keep_scale * (yv[c] > 0.f ? 1.f : slope) : 0.f;
       }
     }
@@ -397,9 +399,10 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
 }
 
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
-                                  const float* W2, float negative_slope, float drop_p, uint64_t seed,
+                                  const float* W2, float negative_slope, float drop_p, uint64_t seed, int64_t row0,
                                   float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream) {
-  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX && (uint64_t)n_rows * (uint64_t)d_out < (1ull << 32),
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX && row0 >= 0 &&
+                     (uint64_t)(row0 + n_rows) * (uint64_t)d_out < (1ull << 32),
                  "bi_interaction_train: bad row count");
   KGAT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "bi_interaction_train: dropout probability outside [0, 1)");
   if (n_rows == 0) return KGAT_OK;
@@ -409,26 +412,27 @@ int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const flo
     set_error("bi_interaction_train: unsupported widths %d -> %d", d_in, d_out);
     return KGAT_E_UNSUPPORTED;
   }
-  return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, drop_args(drop_p, seed), h_out, norm_out,
-                     norm_stride, as_stream(stream));
+  return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, drop_args(drop_p, seed, row0, d_out), h_out,
+                     norm_out, norm_stride, as_stream(stream));
 }
 
 int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,
                                     const float* grad_b, const float* grad_norm, int64_t grad_norm_stride,
-                                    float negative_slope, float drop_p, uint64_t seed, float* grad_z,
+                                    float negative_slope, float drop_p, uint64_t seed, int64_t row0, float* grad_z,
                                     kgat_stream_t stream) {
-  KGAT_CHECK_ARG(n_rows >= 0 && d_out > 0 && d_out <= 128 && (uint64_t)n_rows * (uint64_t)d_out < (1ull << 32),
+  KGAT_CHECK_ARG(n_rows >= 0 && d_out > 0 && d_out <= 128 && row0 >= 0 &&
+                     (uint64_t)(row0 + n_rows) * (uint64_t)d_out < (1ull << 32),
                  "bi_interaction_bwd_pre: bad size");
   KGAT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "bi_interaction_bwd_pre: dropout probability outside [0, 1)");
   if (n_rows == 0) return KGAT_OK;
   KGAT_CHECK_ARG(h_out && grad_z, "bi_interaction_bwd_pre: null pointer");
   KGAT_CHECK_ARG(grad_norm == nullptr || grad_norm_stride >= d_out, "bi_interaction_bwd_pre: bad stride");
-  const DropArgs dr = drop_args(drop_p, seed);
+  const DropArgs dr = drop_args(drop_p, seed, row0, d_out);
   int64_t blocks = (n_rows + 15) / 16;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(bi_bwd_pre_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n_rows, d_out, h_out,
                      grad_a, grad_b, grad_norm, grad_norm_stride, negative_slope, dr.threshold, dr.keep_scale, dr.seed,
-                     grad_z);
+                     dr.index0, grad_z);
   KGAT_CHECK_LAUNCH("bi_bwd_pre");
   return KGAT_OK;
 }

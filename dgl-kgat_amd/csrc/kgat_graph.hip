@@ -368,6 +368,24 @@ __global__ void group_ptr_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
   if (r <= n_rel) gptr[r] = ex[rel_ptr[r]];
 }
 
+// ---- packed per-position records of the fused attention kernel (kgat_att_pack_records)
+__global__ void att_pack_records_kernel(int64_t n_edges, int n_rel, const int32_t* __restrict__ rel_ptr,
+                                        const int32_t* __restrict__ gptr, const int32_t* __restrict__ gid,
+                                        const int32_t* __restrict__ src_g, int32_t* __restrict__ rec_g) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_edges) return;
+  uint32_t rec = (uint32_t)src_g[p];
+  if (p < rel_ptr[n_rel]) {
+    int lo = 0, hi = n_rel;  // relation of position p: largest r with rel_ptr[r] <= p
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rel_ptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    rec |= (uint32_t)((gid[p] - gptr[lo]) & 15) << 28;
+  }
+  rec_g[p] = (int32_t)rec;
+}
+
 // ---- work tiles of the fused folded attention kernel (see kgat_fold_tiles in the header)
 __global__ void fold_gstart_kernel(int n_rel, const int32_t* __restrict__ rel_ptr, int64_t n_groups,
                                    const int32_t* __restrict__ gid, int32_t* __restrict__ gstart) {
@@ -628,6 +646,17 @@ int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t*
   hipLaunchKernelGGL(fold_emit_kernel, dim3(blocks_for(n_thr, 256)), dim3(256), 0, st, n_rel, nb_max, cap,
                      (const int32_t*)bptr, gptr, (const int32_t*)gstart, (const int32_t*)cnt, tiles, rel_tptr);
   KGAT_CHECK_LAUNCH("fold_emit");
+  return KGAT_OK;
+}
+
+int kgat_att_pack_records(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* gptr,
+                          const int32_t* gid, const int32_t* src_g, int32_t* rec_g, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0 && n_edges < INT32_MAX && n_rel > 0, "att_pack_records: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(rel_ptr && gptr && gid && src_g && rec_g, "att_pack_records: null pointer");
+  hipLaunchKernelGGL(att_pack_records_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, as_stream(stream), n_edges,
+                     n_rel, rel_ptr, gptr, gid, src_g, rec_g);
+  KGAT_CHECK_LAUNCH("att_pack_records");
   return KGAT_OK;
 }
 

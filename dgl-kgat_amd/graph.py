@@ -58,6 +58,13 @@ class Frame(MutableMapping):
         self._owned = set()  # columns this frame allocated itself (no other view can alias them)
 
     def __getitem__(self, key):
+        # a column that has been handed out may be aliased by the caller: from here on a partial
+        # write goes through a copy again (DGL's out-of-place update_rows semantics)
+        self._owned.discard(key)
+        return self._cols[key]
+
+    def _own(self, key):
+        """The column itself, for the in-place continuation of a partial write (apply_edges)."""
         return self._cols[key]
 
     def __setitem__(self, key, val):
@@ -80,21 +87,39 @@ class Frame(MutableMapping):
     def __len__(self):
         return len(self._cols)
 
+    def __contains__(self, key):  # (the Mapping default goes through __getitem__, which hands the column out)
+        return key in self._cols
+
     def clone(self):
+        # the clone shares the column tensors: neither side may write them in place any more
+        self._owned.clear()
         return Frame(self._n, self._what, self._cols)
 
 
 CSR = namedtuple("CSR", "indptr col eid row_of")
 RelGroups = namedtuple("RelGroups", "rel_ptr perm src_g dst_g pos_g gid gptr g_node n_groups g_tab")
+# g_tab: per-graph scratch and lazily built statics of the attention forms, keyed by name:
+#   "tiles" / "tiles_cost"  work tiles of the fused kernel and the cost they were split with
+#   "rec_g"                 packed per-position records of the fused kernel (ops.att_pack_records)
+#   "gpos_csr"              grouped position of every CSR position (inverse of pos_g): what the softmax
+#                           reads grouped-order logits through
+#   <width>                 per-group table of the two-launch forms; ("form", d, k): the form picked
 
 
 class _Structure:
-    """Edge list + per-device derived structure, shared by a graph and its local_var views."""
+    """Edge list + per-device derived structure, shared by a graph and its local_var views.
+
+    The edge list lives on the host (int64 numpy, what `add_edges` is given by the reference,
+    dataset.py:116) or on a device (int32 tensors: `add_edges` with device tensors, e.g. a graph
+    drawn or sharded on the GPU - no host copy is ever made of those).  Once a read-only graph has
+    its device CSR, the host copy is dropped (3.2 GB at 200 M edges); `_src` / `_dst` rebuild it on
+    demand for the few host-side queries (`edges()`, degrees)."""
 
     def __init__(self):
         self.n_nodes = 0
-        self._src = np.zeros(0, np.int64)
-        self._dst = np.zeros(0, np.int64)
+        self._host = (np.zeros(0, np.int64), np.zeros(0, np.int64))  # None: the device copy is the edge list
+        self._dev_edges = None  # (src, dst) int32 device tensors
+        self._n_edges = 0
         self.readonly = False
         self._dev = {}
 
@@ -108,6 +133,18 @@ class _Structure:
     def add_edges(self, u, v):
         if self.readonly:
             raise DGLError("readonly graph. Mutation is not allowed.")
+        if (isinstance(u, torch.Tensor) and isinstance(v, torch.Tensor) and u.is_cuda and v.is_cuda
+                and self._n_edges == 0 and u.dim() == 1 and u.shape == v.shape
+                and not u.dtype.is_floating_point and not v.dtype.is_floating_point):
+            # device-resident edge list: kept where it is
+            if u.numel() and (int(torch.minimum(u.min(), v.min())) < 0 or
+                              int(torch.maximum(u.max(), v.max())) >= self.n_nodes):
+                raise DGLError("Node id out of range (number of nodes: %d)" % self.n_nodes)
+            self._dev_edges = (u.to(torch.int32).contiguous(), v.to(torch.int32).contiguous())
+            self._host = None
+            self._n_edges = int(u.numel())
+            self._dev.clear()
+            return
         u, v = _as_id_array(u, "u"), _as_id_array(v, "v")
         if len(u) != len(v):
             if len(u) == 1:
@@ -118,13 +155,33 @@ class _Structure:
                 raise DGLError("Expect number of source and destination ids to match")
         if len(u) and (u.min() < 0 or v.min() < 0 or u.max() >= self.n_nodes or v.max() >= self.n_nodes):
             raise DGLError("Node id out of range (number of nodes: %d)" % self.n_nodes)
-        self._src = np.concatenate([self._src, u])
-        self._dst = np.concatenate([self._dst, v])
+        src, dst = self._src, self._dst
+        self._host = (np.concatenate([src, u]), np.concatenate([dst, v]))
+        self._dev_edges = None
+        self._n_edges = len(self._host[0])
         self._dev.clear()
 
     @property
     def n_edges(self):
-        return len(self._src)
+        return self._n_edges
+
+    def _host_edges(self):
+        if self._host is not None:
+            return self._host
+        s, d = self._dev_edges
+        return s.cpu().numpy().astype(np.int64), d.cpu().numpy().astype(np.int64)
+
+    @property
+    def _src(self):
+        return self._host_edges()[0]
+
+    @property
+    def _dst(self):
+        return self._host_edges()[1]
+
+    def edge_device(self):
+        """The device the edge list lives on, or None while it is (also) on the host."""
+        return None if self._host is not None else self._dev_edges[0].device
 
     # ---- per-device caches
     def _cache(self, device):
@@ -138,8 +195,11 @@ class _Structure:
         c = self._cache(device)
         key = ("coo", dtype)
         if key not in c:
-            c[key] = (torch.as_tensor(self._src, dtype=dtype).to(device),
-                      torch.as_tensor(self._dst, dtype=dtype).to(device))
+            if self._dev_edges is not None:
+                c[key] = tuple(t.to(device=torch.device(device), dtype=dtype) for t in self._dev_edges)
+            else:
+                c[key] = (torch.as_tensor(self._host[0], dtype=dtype).to(device),
+                          torch.as_tensor(self._host[1], dtype=dtype).to(device))
         return c[key]
 
     def csr(self, device):
@@ -148,6 +208,10 @@ class _Structure:
         if "csr" not in c:
             src, dst = self.coo(device)
             c["csr"] = CSR(*ops.csr_from_coo(self.n_nodes, src, dst))
+            if self.readonly and self._host is not None and src.is_cuda:
+                # a read-only graph with its structure on the device: the int32 device COO is the
+                # edge list from here on, the int64 host arrays go
+                self._dev_edges, self._host = (src, dst), None
         return c["csr"]
 
     def csr_pos(self, device):
@@ -259,6 +323,15 @@ def _f32_products():
     return os.environ.get("KGAT_ATT_F32_PRODUCTS", "") not in ("", "0")
 
 
+def _fused_statics(groups):
+    """Packed records + the CSR-position -> grouped-position map of the fused path (graph-static)."""
+    rec = groups.g_tab.get("rec_g")
+    if rec is None:
+        rec = groups.g_tab["rec_g"] = ops.att_pack_records(groups.rel_ptr, groups.gptr, groups.gid, groups.src_g)
+        groups.g_tab["gpos_csr"] = ops.invert_permutation(groups.pos_g)
+    return rec, groups.g_tab["gpos_csr"]
+
+
 def _fused_tiles(groups, d):
     """Work tiles of the fused attention kernel and their split over the workgroups, kept with the
     relation grouping (graph-static); the split cost goes with the product form taken at width d."""
@@ -367,11 +440,11 @@ class DGLGraph:
     def edges(self, form="uv", order=None):
         """DGLGraph.edges / all_edges: endpoints (and ids) of all edges, in edge-id order
         (order=None / 'eid') or sorted by (src, dst) (order='srcdst')."""
-        src = torch.as_tensor(self._st._src)
-        dst = torch.as_tensor(self._st._dst)
+        src_h, dst_h = self._st._host_edges()
+        src, dst = torch.as_tensor(src_h), torch.as_tensor(dst_h)
         eid = torch.arange(len(src))
         if order == "srcdst":
-            perm = torch.as_tensor(np.lexsort((self._st._dst, self._st._src)))
+            perm = torch.as_tensor(np.lexsort((dst_h, src_h)))
             src, dst, eid = src[perm], dst[perm], eid[perm]
         elif order not in (None, "eid"):
             raise DGLError("unknown edge order %r" % (order,))
@@ -457,7 +530,7 @@ class DGLGraph:
                 # the column was zero-initialised by an earlier partial write through this very
                 # view (the per-relation loop of models.py:149-152): nothing else can see it, so
                 # the next relation's slice goes in place instead of through an E-sized copy
-                self._edge_frame[key].index_copy_(0, eids.to(val.device), val)
+                self._edge_frame._own(key).index_copy_(0, eids.to(val.device), val)
                 continue
             if key in self._edge_frame:
                 col = self._edge_frame[key].clone()
@@ -557,13 +630,21 @@ class DGLGraph:
         # do the whole relation-space product per group and a d-length dot per edge (one launch
         # with the per-group vectors in LDS / two launches with a table); "split" keeps the
         # reference's contraction order (bit-identical to "one")
+        grouped_out = os.environ.get("KGAT_ATT_SCATTER_CSR", "") in ("", "0")
+
         def run(form):
             if form == "fused":
                 tiles = _fused_tiles(groups, d)  # graph-static work tiles of the fused kernel
-                return ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
-                                           groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
-                                           ent_c, W_c, rel_c, want_eid=False, part_tptr=tiles[2],
-                                           f32_products=_f32_products())[1]
+                rec, _ = _fused_statics(groups)
+                # the logits leave in grouped order (coalesced stores); the softmax reads them through
+                # the inverse position map.  KGAT_ATT_SCATTER_CSR=1: the round-2 form, a 4-byte
+                # scatter into CSR order (73 MB written for 14.6 MB of logits on the benchmark graph)
+                res = ops.att_score_fused(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.pos_g,
+                                          groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
+                                          ent_c, W_c, rel_c, want_eid=False, want_csr=not grouped_out,
+                                          want_grouped=grouped_out, part_tptr=tiles[2],
+                                          f32_products=_f32_products(), rec_g=rec)
+                return res[2] if grouped_out else res[1]
             if form in ("folded", "split"):
                 folded = form == "folded"
                 width = d if folded else k
@@ -585,12 +666,18 @@ class DGLGraph:
         if form is None:
             form = self._pick_attention_form(groups, n_rel, d, k, run if race else None)
             groups.g_tab[("form", d, k)] = form
-        logits_csr = run(form)
+        logits = run(form)
         if form not in ("fused", "folded", "split"):
             form = "one"
         st.last_att_form = (form, groups.n_groups)
-        _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, logits_csr, in_csr_order=True,
-                                    want_out=False, want_csr=True)
+        if form == "fused" and grouped_out:
+            # grouped-order logits: the sweep gathers logits[gpos_csr[q]] for CSR position q (the map
+            # takes the place of `eid` on the input side; no edge-id-ordered output is asked for)
+            _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, _fused_statics(groups)[1], logits,
+                                        in_csr_order=False, want_out=False, want_csr=True)
+        else:
+            _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, logits, in_csr_order=True,
+                                        want_out=False, want_csr=True)
         if lazy is None:
             lazy = not os.environ.get("KGAT_EAGER_EDGE_WEIGHTS")
         a = torch.empty((st.n_edges, 1), dtype=torch.float32, device=dev)

@@ -67,17 +67,19 @@ class KGATConv(nn.Module):
         self._res_type = res_type
         self.res_fc_2 = nn.Linear(entity_in_feats, out_feats, bias=False)
 
-    def forward(self, g, nfeat, fused=None):
+    def forward(self, g, nfeat, fused=None, seed=None):
         part = g.partition
         if fused is None:
             fused = not (torch.is_grad_enabled() and nfeat.requires_grad)
         if part is not None:
             if torch.is_grad_enabled() and (nfeat.requires_grad or self.res_fc_2.weight.requires_grad):
-                # the shard's aggregation runs on detached rows and the exchange is an in-place
-                # collective autograd does not see: gradients would be silently wrong
-                raise NotImplementedError(
-                    "KGATConv on a destination-range shard is forward-only (SURVEY 8e: the reference trains on one "
-                    "device); run it under torch.no_grad() or train on the unsharded graph")
+                # differentiable shard layer (partition._ShardConv): local backward + all-reduce of the
+                # gradients of the replicated operands; dropout is its hash mask, drawn on global rows
+                from .partition import shard_conv
+                p = self.mess_drop.p if self.training else 0.0
+                if seed is None:
+                    seed = int(torch.empty((), dtype=torch.int64).random_()) if p > 0 else 0
+                return shard_conv(part, g, nfeat, self.res_fc_2.weight, 0.01, p, seed)
             out = part.propagate(g, nfeat, self.res_fc_2.weight)
         elif fused:
             # h * h_N formed in the SpMM epilogue (models.py:63 + the th.mul of :66)
@@ -130,8 +132,10 @@ class KGATPropagation(nn.Module):
         return edge_softmax(g, g.edata.pop("att_w"))
 
     def compute_attention(self, g, algo="auto"):
-        """Fused: one attention-logit launch over relation-grouped edges + destination softmax."""
-        return g.kgat_attention(self.entity_embed.weight, self.W_R, self.relation_embed.weight, algo=algo)
+        """Fused: one attention-logit launch over relation-grouped edges + destination softmax.
+        The kernels index the table by node position; `_node_embeddings` is the table itself when
+        ndata['id'] is arange(N) (dataset.py:118) and entity_embed(ids) otherwise (models.py:140-141)."""
+        return g.kgat_attention(self._node_embeddings(g), self.W_R, self.relation_embed.weight, algo=algo)
 
     # -- propagation (models.py:156-168)
     def gnn(self, g, x=None, fused=None):
@@ -148,6 +152,8 @@ class KGATPropagation(nn.Module):
             seed = int(torch.empty((), dtype=torch.int64).random_()) if p > 0 else 0
             return gnn_train(g, self._node_embeddings(g), [layer.res_fc_2.weight for layer in self.layers],
                              0.01, p, seed)
+        if auto and g.partition is not None and torch.is_grad_enabled() and self._can_fuse_training(g, sharded=True):
+            return self._gnn_train_sharded(g)
         g = g.local_var()
         h = self._node_embeddings(g)
         node_embed_cache = [h]
@@ -157,10 +163,27 @@ class KGATPropagation(nn.Module):
             node_embed_cache.append(F.normalize(h, p=2, dim=1))
         return torch.cat(node_embed_cache, 1)
 
-    def _can_fuse_training(self, g):
+    def _gnn_train_sharded(self, g):
+        """Training mode on a destination-range shard (kgat.py:146-168 on N GPUs): every layer is a
+        differentiable shard layer (partition.shard_conv), the readout is assembled from the
+        exchanged layer outputs on every rank.  The dropout seed is drawn as the unsharded training
+        path draws it (one draw from torch's CPU generator per call, layer i uses seed + i), and the
+        hash mask is indexed by global row: with the same torch.manual_seed the shards reproduce the
+        one-GPU run's masks."""
+        from .partition import shard_conv
+        p = self.layers[0].mess_drop.p if self.training else 0.0
+        seed = int(torch.empty((), dtype=torch.int64).random_()) if p > 0 else 0
+        h = self._node_embeddings(g)
+        cache = [h]
+        for li, layer in enumerate(self.layers):
+            h = shard_conv(g.partition, g, h, layer.res_fc_2.weight, 0.01, p, seed + li)
+            cache.append(F.normalize(h, p=2, dim=1))
+        return torch.cat(cache, 1)
+
+    def _can_fuse_training(self, g, sharded=False):
         from . import ops
         w = self.entity_embed.weight
-        return (g.partition is None and w.is_cuda and w.dtype == torch.float32 and "w" in g.edata and
+        return ((g.partition is None) != sharded and w.is_cuda and w.dtype == torch.float32 and "w" in g.edata and
                 not g.edata["w"].requires_grad and
                 all(ops.bi_interaction_supported(layer.res_fc_2.in_features, layer.res_fc_2.out_features) and
                     layer.mess_drop.p < 1.0 for layer in self.layers))
@@ -248,7 +271,7 @@ class KGATPropagation(nn.Module):
         for li, layer in enumerate(self.layers):
             h = part.propagate_fused(g, h, layer.res_fc_2.weight, slot=li)
             blocks.append(h)
-        if all(w % 4 == 0 and w <= 128 for w in widths):
+        if len(blocks) <= 8 and all(w % 4 == 0 and w <= 128 for w in widths):
             return ops.readout_concat(blocks, [False] + [True] * len(self.layers))
         out = torch.empty((h.shape[0], sum(widths)), dtype=torch.float32, device=h.device)
         off = 0

@@ -11,12 +11,21 @@ sector granularity, ~30 us on the amazon-book CKG, 5 % of a step) that nothing o
 device storage from the start; the graph structure keeps the CSR-ordered values next to it and
 hands them to the aggregation without touching this tensor; the first torch operation that could
 observe or alias its *values* (anything but shape / dtype / device style metadata) first runs the
-permutation into the storage it already owns, on the current stream, and from then on it is an
-ordinary tensor (same object, same ``data_ptr``).  What cannot be intercepted is code that takes
-the raw pointer out of a C++ extension without going through a torch operator; set
-``KGAT_EAGER_EDGE_WEIGHTS=1`` (or ``lazy=False``) to get the permutation up front.
+permutation into the storage it already owns, on the current stream, and from then on it IS an
+ordinary tensor: the object is re-classed to ``torch.Tensor`` (same object, same ``data_ptr``), so
+nothing lazy-specific can misbehave afterwards (``copy.deepcopy``, pickling, subclass-unaware
+code).  Value-reading paths that do not go through a torch operator are covered one by one:
+``Tensor.type(dtype)`` (a cast, unlike the argument-less metadata query), ``copy.deepcopy`` /
+pickling, and the legacy ``torch.utils.dlpack.to_dlpack`` (a C function that skips
+``__torch_function__``: wrapped at import).  What remains out of reach is a C++ extension that
+takes the raw pointer of a tensor it was handed inside a container without calling any torch
+operator or ``data_ptr()`` on the Python side; set ``KGAT_EAGER_EDGE_WEIGHTS=1`` (or
+``lazy=False``) to get the permutation up front.
 """
+import copy
+
 import torch
+import torch.utils.dlpack as _dlpack
 
 _T = torch.Tensor
 # operations that only look at metadata: they must not trigger the fill
@@ -26,7 +35,7 @@ _META = {
     _T.grad.__get__, _T.names.__get__, _T.is_sparse.__get__, _T.is_quantized.__get__, _T.is_meta.__get__,
     _T.dim, _T.size, _T.numel, _T.nelement, _T.ndimension, _T.stride, _T.is_contiguous, _T.element_size,
     _T.storage_offset, _T.is_floating_point, _T.is_complex, _T.get_device, _T.__len__, _T.__hash__,
-    _T.is_shared, _T.is_pinned, _T.has_names, _T.is_same_size, _T.is_set_to, _T.type,
+    _T.is_shared, _T.is_pinned, _T.has_names, _T.is_same_size, _T.is_set_to,
 }
 
 
@@ -55,26 +64,62 @@ class LazyEdgeWeights(torch.Tensor):
         return self._kgat_fill is not None
 
     def materialize(self):
-        """Run the deferred permutation (once); afterwards this is an ordinary tensor."""
-        fill = self._kgat_fill
+        """Run the deferred permutation (once) and turn this object into a plain torch.Tensor."""
+        fill = self.__dict__.get("_kgat_fill")
+        self.__dict__.pop("_kgat_fill", None)
+        self.__dict__.pop("_kgat_lazy", None)
+        if type(self) is LazyEdgeWeights:
+            self.__class__ = torch.Tensor
+            self.__dict__["pending"] = False   # `w.pending` keeps answering on the plain tensor
         if fill is not None:
-            self._kgat_fill = None
-            self._kgat_lazy = None
             fill()
         return self
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func not in _META:
-            for t in _lazies(args, kwargs):
-                t.materialize()
+        # Tensor.type() without arguments names the type (metadata); with a dtype it is a cast
+        meta = func in _META or (func is _T.type and len(args) <= 1 and not kwargs)
+        if not meta:
+            for t in list(_lazies(args, kwargs)):
+                if isinstance(t, LazyEdgeWeights):  # (the same tensor may appear twice: w * w)
+                    t.materialize()
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
+
+    # paths that copy or export the values without a torch operator
+    def __deepcopy__(self, memo):
+        self.materialize()
+        return copy.deepcopy(self, memo)      # a plain tensor now
+
+    def __reduce_ex__(self, proto):
+        self.materialize()
+        return self.__reduce_ex__(proto)      # torch.Tensor's
+
+
+def _guard_legacy_to_dlpack():
+    """torch.utils.dlpack.to_dlpack is the C function torch._C._to_dlpack: it exports the storage
+    without consulting __torch_function__.  Wrap it (once) so that a pending tensor is filled first."""
+    inner = _dlpack.to_dlpack
+    if getattr(inner, "_kgat_guarded", False):
+        return
+
+    def to_dlpack(tensor):
+        if isinstance(tensor, LazyEdgeWeights):
+            tensor.materialize()
+        return inner(tensor)
+    to_dlpack.__doc__ = getattr(inner, "__doc__", None)
+    to_dlpack._kgat_guarded = True
+    _dlpack.to_dlpack = to_dlpack
+    if getattr(torch, "to_dlpack", None) is inner:
+        torch.to_dlpack = to_dlpack
+
+
+_guard_legacy_to_dlpack()
 
 
 def pending_csr_weights(w, structure):
     """The CSR-ordered values standing behind `w` if it is a still-pending LazyEdgeWeights of this
     graph structure, else None.  Does not touch `w`'s values."""
-    lz = getattr(w, "_kgat_lazy", None) if isinstance(w, LazyEdgeWeights) else None
+    lz = w.__dict__.get("_kgat_lazy") if isinstance(w, LazyEdgeWeights) else None
     return lz[1] if lz is not None and lz[0] is structure else None

@@ -293,24 +293,43 @@ def att_score_fused_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_fused_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
 
+def att_pack_records(rel_ptr, gptr, gid, src_g):
+    """rec_g[p] = src_g[p] | (slot of p's head group in its 16-group block << 28): the one index the
+    fused attention kernel reads per grouped position (kgat_att_pack_records; graph-static)."""
+    rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr")
+    gptr = _need(gptr, torch.int32, "gptr", rel_ptr.shape)
+    src_g = _need(src_g, torch.int32, "src_g")
+    e = src_g.numel()
+    gid = _need(gid, torch.int32, "gid", (e,))
+    rec = torch.empty(e, dtype=torch.int32, device=src_g.device)
+    check(_lib.load().kgat_att_pack_records(e, rel_ptr.numel() - 1, _ptr(rel_ptr), _ptr(gptr), _ptr(gid), _ptr(src_g),
+                                            _ptr(rec), _stream(src_g)), "kgat_att_pack_records")
+    return rec
+
+
 def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
-                    want_csr=True, want_eid=True, part_tptr=None, f32_products=False):
-    """Attention logits, fused folded form (kgat_att_score_fused_f32).  `part_tptr`: the tile range
-    of every workgroup (fold_tiles); None: equal tile counts, one workgroup per compute unit.
-    `f32_products`: the two products on the fp32 MFMA (KGAT_ATT_F32_PRODUCTS) instead of the
-    three-bf16-piece products the kernel takes by default when d % 32 == 0.
-    Returns (logits edge-id order or None, logits CSR order or None)."""
+                    want_csr=True, want_eid=True, part_tptr=None, f32_products=False, rec_g=None, want_grouped=False):
+    """Attention logits, fused folded form (kgat_att_score_fused_f32).  The kernel reads one packed
+    record per grouped position (`rec_g`, att_pack_records; built here from `src_g` / `gid` when the
+    caller does not keep one).  `part_tptr`: the tile range of every workgroup (fold_tiles); None:
+    equal tile counts, one workgroup per compute unit.  `f32_products`: the two products on the fp32
+    MFMA (KGAT_ATT_F32_PRODUCTS) instead of the three-bf16-piece products the kernel takes by
+    default when d % 32 == 0.  Returns (logits edge-id order, logits CSR order) - unrequested ones
+    None - and, with want_grouped, a third item: the logits in grouped order."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
     rel = _need(rel, torch.float32, "rel", (n_rel, k))
-    perm = _need(perm, torch.int32, "perm")
-    e = perm.numel()
-    for name, t in (("src_g", src_g), ("pos_g", pos_g)):
-        _need(t, torch.int32, name, (e,))
-    _need(gid, torch.int32, "gid")
     _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
     _need(gptr, torch.int32, "gptr", (n_rel + 1,))
+    if rec_g is None:
+        rec_g = att_pack_records(rel_ptr, gptr, gid, src_g)
+    rec_g = _need(rec_g, torch.int32, "rec_g")
+    e = rec_g.numel()
+    if want_eid:
+        perm = _need(perm, torch.int32, "perm", (e,))
+    if want_csr:
+        pos_g = _need(pos_g, torch.int32, "pos_g", (e,))
     _need(rel_tptr, torch.int32, "rel_tptr", (n_rel + 1,))
     _need(g_node, torch.int32, "g_node")
     _need(tiles, torch.int32, "tiles")
@@ -320,14 +339,16 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
         n_parts = part_tptr.numel() - 1
     logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
+    logits_g = torch.empty(e, dtype=torch.float32, device=ent.device) if want_grouped else None
     with _timed("att_score", (e, d, k)):
-        check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm), _ptr(src_g),
-                                                   _ptr(pos_g), _ptr(gid), _ptr(gptr), _ptr(g_node), _ptr(tiles),
-                                                   _ptr(rel_tptr), _ptr(part_tptr), n_parts, _ptr(ent), _ptr(W_R),
-                                                   _ptr(rel), _ptr(logits), _ptr(logits_csr),
-                                                   ATT_F32_PRODUCTS if f32_products else 0, _stream(ent)),
+        check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm) if want_eid else None,
+                                                   _ptr(rec_g), _ptr(pos_g) if want_csr else None, _ptr(gptr),
+                                                   _ptr(g_node), _ptr(tiles), _ptr(rel_tptr), _ptr(part_tptr), n_parts,
+                                                   _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits), _ptr(logits_csr),
+                                                   _ptr(logits_g), ATT_F32_PRODUCTS if f32_products else 0,
+                                                   _stream(ent)),
               "kgat_att_score_fused_f32")
-    return logits, logits_csr
+    return (logits, logits_csr, logits_g) if want_grouped else (logits, logits_csr)
 
 
 def transr_supported(n_nodes, d, k, n_rel, batch):
@@ -480,9 +501,11 @@ def _strided_rows(t, n, d, name):
     return t.stride(0)
 
 
-def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None):
+def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None, row0=0):
     """Training form: h_out = dropout_p(leaky_relu((H * HN) @ W2^T)) and its normalised copy into
-    `norm_out` (kgat_bi_interaction_train_f32; the mask is a hash of (seed, element))."""
+    `norm_out` (kgat_bi_interaction_train_f32; the mask is a hash of (seed, element); `row0`: the
+    global index of row 0 when H holds a row range of a larger matrix, so that a destination shard
+    draws the mask the unsharded layer draws)."""
     H = _need(H, torch.float32, "H")
     HN = _need(HN, torch.float32, "HN", H.shape)
     W2 = _need(W2, torch.float32, "W2")
@@ -495,13 +518,14 @@ def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None)
     with _timed("bi_interaction", (n, d_in, d_out)):
         check(_lib.load().kgat_bi_interaction_train_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2),
                                                         float(negative_slope), float(drop_p), int(seed) & (2 ** 64 - 1),
-                                                        _ptr(h_out), _ptr(norm_out), stride, _stream(H)),
+                                                        int(row0), _ptr(h_out), _ptr(norm_out), stride, _stream(H)),
               "kgat_bi_interaction_train_f32")
     return h_out
 
 
-def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, drop_p, seed):
-    """grad_z of the training layer (kgat_bi_interaction_bwd_pre_f32); grad_a / grad_b / grad_norm may be None."""
+def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, drop_p, seed, row0=0):
+    """grad_z of the training layer (kgat_bi_interaction_bwd_pre_f32); grad_a / grad_b / grad_norm may be
+    None; `row0` as in bi_interaction_train."""
     h_out = _need(h_out, torch.float32, "h_out")
     n, d = h_out.shape
     for name, t in (("grad_a", grad_a), ("grad_b", grad_b)):
@@ -511,7 +535,7 @@ def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, dro
     gz = torch.empty_like(h_out)
     check(_lib.load().kgat_bi_interaction_bwd_pre_f32(n, d, _ptr(h_out), _ptr(grad_a), _ptr(grad_b), _ptr(grad_norm),
                                                       stride, float(negative_slope), float(drop_p),
-                                                      int(seed) & (2 ** 64 - 1), _ptr(gz), _stream(h_out)),
+                                                      int(seed) & (2 ** 64 - 1), int(row0), _ptr(gz), _stream(h_out)),
           "kgat_bi_interaction_bwd_pre_f32")
     return gz
 
@@ -526,13 +550,13 @@ def mul2(a, b, c):
     return ab, ac
 
 
-def dropout_keep_mask(seed, n_rows, d, drop_p):
+def dropout_keep_mask(seed, n_rows, d, drop_p, row0=0):
     """The mask kgat_bi_interaction_train_f32 applies, restated in numpy (tests): element (row, col)
-    is kept iff murmur3-finalised ((row*d + col) * 0x9E3779B1 ^ seed32) >= p * 2^32."""
+    is kept iff murmur3-finalised (((row0 + row)*d + col) * 0x9E3779B1 ^ seed32) >= p * 2^32."""
     import numpy as np
     seed = int(seed) & (2 ** 64 - 1)
     seed32 = np.uint32((seed ^ (seed >> 32)) & 0xFFFFFFFF)
-    x = (np.arange(n_rows * d, dtype=np.uint64) * np.uint64(0x9E3779B1)).astype(np.uint32) ^ seed32
+    x = ((np.arange(n_rows * d, dtype=np.uint64) + np.uint64(int(row0) * d)) * np.uint64(0x9E3779B1)).astype(np.uint32) ^ seed32
     x ^= x >> np.uint32(16)
     x = (x.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
     x ^= x >> np.uint32(13)
@@ -590,6 +614,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]

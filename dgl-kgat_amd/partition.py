@@ -23,15 +23,45 @@ import torch.distributed as dist
 from . import ops
 
 
-def balanced_row_bounds(in_degrees, world):
-    """Row boundaries b[0..world] with ~equal edge counts per range."""
-    deg = np.asarray(in_degrees, dtype=np.int64)
+# What a destination row costs its owner besides its in-edges, in units of one edge: the dense part
+# of every layer and the row's share of the layer-output exchange (a slice exchange is bound by the
+# largest slice; the all-reduce is indifferent).  Measured per-rank costs at P = 8 on the
+# amazon-book-shaped CKG: ~0.37 ns per edge of attention + aggregation, ~0.4 ns per
+# row of bi-interaction + ~2.9 ns per row of slice exchange over one xGMI link -> ~8 edges.
+ROW_WEIGHT = 8
+
+
+def _row_weight(row_weight):
+    if row_weight is None:
+        row_weight = int(os.environ.get("KGAT_PARTITION_ROW_WEIGHT", ROW_WEIGHT))
+    return max(int(row_weight), 0)
+
+
+def balanced_row_bounds(in_degrees, world, row_weight=0):
+    """Row boundaries b[0..world] with ~equal cost per range, cost(v) = in_degree(v) + row_weight
+    (row_weight = 0: equal edge counts)."""
+    deg = np.asarray(in_degrees, dtype=np.int64) + int(row_weight)
     prefix = np.concatenate([[0], np.cumsum(deg)])
     total = int(prefix[-1])
     bounds = [0]
     for r in range(1, world):
         bounds.append(int(np.searchsorted(prefix, (total * r) // world, side="left")))
     bounds.append(len(deg))
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+def balanced_row_bounds_device(dst, n_nodes, world, row_weight=0):
+    """`balanced_row_bounds` from a device-resident destination array (no host copy of the edges)."""
+    deg = torch.bincount(dst.long(), minlength=n_nodes) + int(row_weight)
+    prefix = torch.cumsum(deg, 0)                       # prefix[v] = cost of rows 0..v (inclusive)
+    total = int(prefix[-1]) if n_nodes else 0
+    cuts = torch.tensor([(total * r) // world for r in range(1, world)], dtype=prefix.dtype, device=prefix.device)
+    # first v with exclusive-prefix(v) >= cut  <=>  number of inclusive prefixes < cut
+    idx = torch.searchsorted(prefix, cuts, right=False)
+    # exclusive prefix of row v is prefix[v - 1]: row v starts a range when prefix[v-1] >= cut
+    bounds = [0] + [min(int(i) + (1 if int(c) > 0 else 0), n_nodes) for i, c in zip(idx.tolist(), cuts.tolist())] + [n_nodes]
     for i in range(1, len(bounds)):
         bounds[i] = max(bounds[i], bounds[i - 1])
     return bounds
@@ -159,24 +189,121 @@ class Partition:
         return self.assemble(full)
 
 
-def shard_graph(g, rank, world, group=None, bounds=None):
+def shard_graph(g, rank, world, group=None, bounds=None, row_weight=None, mode=None):
     """The rank's shard of `g`: all nodes, the edges whose destination lies in the rank's row
     range (global edge-id order kept), edge features sliced accordingly.  Returns the shard
-    (with ``.partition`` set) and the global ids of its edges."""
+    (with ``.partition`` set) and the global ids of its edges.  A graph whose edge list lives on a
+    device is sharded there (bounds from a device bincount, the kept edges selected on the device,
+    ids returned as a device tensor); a host-resident one with numpy, as the reference's loader
+    builds it.  `row_weight`: see ROW_WEIGHT (None: the default / KGAT_PARTITION_ROW_WEIGHT)."""
     from .graph import DGLGraph
     st = g._st
-    if bounds is None:
-        bounds = balanced_row_bounds(np.bincount(st._dst, minlength=st.n_nodes), world)
-    part = Partition(rank, world, bounds, st.n_nodes, group)
-    keep = np.nonzero((st._dst >= part.lo) & (st._dst < part.hi))[0]
-    sg = DGLGraph()
-    sg.add_nodes(st.n_nodes)
-    sg.add_edges(st._src[keep], st._dst[keep])
+    dev = st.edge_device()
+    if dev is not None:
+        src, dst = st.coo(dev)
+        if bounds is None:
+            bounds = balanced_row_bounds_device(dst, st.n_nodes, world, _row_weight(row_weight))
+        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode)
+        keep = torch.nonzero((dst >= part.lo) & (dst < part.hi)).reshape(-1)
+        sg = DGLGraph()
+        sg.add_nodes(st.n_nodes)
+        if keep.numel():
+            sg.add_edges(src.index_select(0, keep), dst.index_select(0, keep))
+        keep_t = keep
+    else:
+        if bounds is None:
+            bounds = balanced_row_bounds(np.bincount(st._dst, minlength=st.n_nodes), world, _row_weight(row_weight))
+        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode)
+        keep = np.nonzero((st._dst >= part.lo) & (st._dst < part.hi))[0]
+        sg = DGLGraph()
+        sg.add_nodes(st.n_nodes)
+        sg.add_edges(st._src[keep], st._dst[keep])
+        keep_t = torch.as_tensor(keep)
     sg.readonly()
     for k, v in g.ndata.items():
         sg.ndata[k] = v
-    keep_t = torch.as_tensor(keep)
     for k, v in g.edata.items():
         sg.edata[k] = v.index_select(0, keep_t.to(v.device))
     sg.partition = part
     return sg, keep
+
+
+class _ShardConv(torch.autograd.Function):
+    """One KGATConv (reference models.py:60-70) on a destination-range shard, differentiable
+    (SURVEY 8e "backward"; the CF phase of kgat.py:146-168 on N GPUs).  Parameters and the layer
+    input are replicated, every rank differentiates the same loss on the same batch.
+
+    forward:  h_N and LeakyReLU((h * h_N) W2^T) (+ hash dropout) on the owned rows from the local
+              edges, then the layer-output exchange: every rank ends with all N x D_out rows.
+    backward: the incoming gradient is the same on every rank; each takes the slice of its own
+              rows, runs the dense backward on them, the reversed-CSR SpMM over its local edges, and
+              the per-rank partial gradients of the replicated operands are summed:
+              all_reduce(SUM) of grad_h (N x D_in) and of grad_W2."""
+
+    @staticmethod
+    def forward(ctx, part, g, slope, drop_p, seed, h, weight):
+        st = g._st
+        dev = h.device
+        lo, hi = part.lo, part.hi
+        h_c = h.detach().contiguous()
+        w_c = weight.detach().contiguous()
+        csr = st.csr(dev)
+        ew = g.edata["w"]
+        hn = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, st.csr_weights(ew), rows=(lo, hi - lo),
+                      e_range=(0, st.n_edges))
+        full = part.new_buffer(w_c.shape[0], dev)
+        z = None
+        if hi > lo:
+            # the dropout mask is a hash of (seed, GLOBAL row, column): the shards of a layer draw the
+            # mask the unsharded layer draws
+            z = ops.bi_interaction_train(h_c[lo:hi], hn, w_c, slope, drop_p, seed, row0=lo)
+            full[lo:hi] = z
+        part.assemble(full)
+        ctx.part, ctx.g, ctx.ew = part, g, ew
+        ctx.slope, ctx.drop_p, ctx.seed = slope, drop_p, seed
+        ctx.save_for_backward(h_c, hn, z if z is not None else h_c.new_empty((0, w_c.shape[0])), w_c)
+        return full
+
+    @staticmethod
+    def backward(ctx, grad_full):
+        from .autograd import tall_weight_grad
+        h, hn, z, w = ctx.saved_tensors
+        part, st = ctx.part, ctx.g._st
+        lo, hi = part.lo, part.hi
+        dev = grad_full.device
+        d_in = h.shape[1]
+        grad_h = grad_w = None
+        need_h, need_w = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
+        gh = torch.zeros((h.shape[0], d_in), dtype=torch.float32, device=dev) if need_h else None
+        gw = torch.zeros_like(w) if need_w else None
+        if hi > lo:
+            g_loc = grad_full[lo:hi].contiguous()
+            gz = ops.bi_interaction_bwd_pre(z, g_loc, None, None, ctx.slope, ctx.drop_p, ctx.seed, row0=lo)
+            h_loc = h[lo:hi]
+            if need_w:
+                gw = tall_weight_grad(gz, h_loc * hn)
+            if need_h:
+                gp = gz @ w
+                t, g_b = ops.mul2(gp, h_loc, hn)     # grad_P * h (aggregated back to the sources), grad_P * h_N
+                rev = st.csr_rev(dev)
+                # the local edges' destinations all lie in [lo, hi): only those rows of the operand are read
+                t_full = torch.empty((h.shape[0], d_in), dtype=torch.float32, device=dev)
+                t_full[lo:hi] = t
+                gh = ops.spmm(rev.indptr, rev.col, rev.row_of, t_full, st.rev_weights(ctx.ew))
+                gh[lo:hi] += g_b
+        if part.world > 1 and part.exchange_enabled:
+            if need_h:
+                dist.all_reduce(gh, op=dist.ReduceOp.SUM, group=part.group)
+            if need_w:
+                dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=part.group)
+        if need_h:
+            grad_h = gh
+        if need_w:
+            grad_w = gw
+        return None, None, None, None, None, grad_h, grad_w
+
+
+def shard_conv(part, g, h, weight, slope=0.01, drop_p=0.0, seed=0):
+    """Differentiable KGATConv on the shard `g` of partition `part`; returns the assembled N x D_out
+    layer output (every rank holds all rows)."""
+    return _ShardConv.apply(part, g, float(slope), float(drop_p), int(seed), h, weight)

@@ -149,3 +149,15 @@ def build_graph(n_nodes, triplets, device=None):
     g.ndata["id"] = ids
     g.edata["type"] = et
     return g
+
+
+def build_graph_device(n_nodes, src, dst, etype):
+    """The same graph from device-resident int32 endpoint / type arrays (`power_law_coo_device`):
+    the edge list stays on the device, no host copy is made."""
+    g = DGLGraph()
+    g.add_nodes(n_nodes)
+    g.add_edges(src, dst)
+    g.readonly()
+    g.ndata["id"] = torch.arange(n_nodes, dtype=torch.long, device=src.device)
+    g.edata["type"] = etype.long()
+    return g

@@ -8,6 +8,14 @@ negative) drawn with torch on the device instead of DGL's C++ EdgeSampler.
 
   python examples/train_kgat.py --data_dir datasets/amazon-book/data      # reference file format
   python examples/train_kgat.py --synthetic 0.01 --epochs 2              # amazon-book-shaped toy
+  python examples/train_kgat.py --synthetic 0.01 --gpus 2                # CF phase on destination shards
+
+``--gpus N``: one process per GPU (started here as a child ``torch.distributed.run``),
+parameters replicated, the training graph sharded by destination range.  Every rank draws the same
+batches (same seed); the attention refresh and the CF forward run on the local shard with one
+layer-output exchange per layer, the CF backward sums the per-rank gradients of the replicated
+operands (all-reduce), so all ranks apply the one-GPU run's update.  The KG phase (dense TransR
+batches, no graph) runs replicated.
 """
 import argparse
 import os
@@ -83,17 +91,42 @@ def main():
     ap.add_argument("--batch_size_kg", type=int, default=2048)
     ap.add_argument("--max_iters", type=int, default=0, help="cap on iterations per phase (0 = full epoch)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--grad_digest", action="store_true",
+                    help="print |grad| sums of the first CF step (to compare an N-GPU run with the one-GPU run)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        if args.data_dir is None:   # every rank must read the same files
+            args.data_dir = synthetic_data_dir(args.synthetic, args.seed)
+            sys.argv += ["--data_dir", args.data_dir]
+        sys.exit(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                 str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                 os.path.abspath(__file__)] + sys.argv[1:]).returncode)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     torch.manual_seed(args.seed)
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", int(os.environ.get("KGAT_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("KGAT_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    say = print if rank == 0 else (lambda *a, **k: None)
     ds = ckg_io.CKGDataset(args.data_dir or synthetic_data_dir(args.synthetic, args.seed))
-    print("users %d items %d | CKG: %d entities, %d relations, %d train triplets" % (
+    say("users %d items %d | CKG: %d entities, %d relations, %d train triplets" % (
         ds.n_users, ds.n_items, ds.n_KG_entity, ds.n_KG_relation, len(ds.train_KG_triplet)))
     model = K.KGATPropagation(ds.n_KG_entity, ds.n_KG_relation, args.entity_embed_dim, args.relation_embed_dim,
                               args.gnn_num_layer, args.gnn_hidden_size, args.dropout_rate).to(dev)
     # one Adam over all parameters (kgat.py:85); torch's single-kernel implementation of the same update
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, fused=dev.type == "cuda")
     train_g, test_g = ds.train_graph(dev), ds.test_graph(dev)
+    if world > 1:
+        from dgl_kgat_amd import partition
+        train_g, test_g = partition.shard_graph(train_g, rank, world)[0], partition.shard_graph(test_g, rank, world)[0]
     trip = torch.as_tensor(ds.train_KG_triplet.astype(np.int64), device=dev)
     pairs = torch.as_tensor(ds.train_pairs.astype(np.int64), device=dev)
     off = ds.n_users
@@ -118,13 +151,13 @@ def main():
             opt.step()
             opt.zero_grad()
             total += loss.item()
-        print("Epoch %04d | KGE %.1fs loss %.4f" % (epoch, time.time() - t0, total / n_it))
+        say("Epoch %04d | KGE %.1fs loss %.4f" % (epoch, time.time() - t0, total / n_it))
         # ---- attention refresh (kgat.py:139-145)
         t0 = time.time()
         with torch.no_grad():
             train_g.edata["w"] = model.compute_attention(train_g)
         torch.cuda.synchronize()
-        print("           | attention %.4fs" % (time.time() - t0))
+        say("           | attention %.4fs" % (time.time() - t0))
         # ---- CF phase (kgat.py:146-168): full-graph gnn for every batch
         t0 = time.time()
         total, n_it = 0.0, cap(len(pairs) // args.batch_size + 1)
@@ -135,10 +168,14 @@ def main():
             emb = model.gnn(train_g, train_g.ndata["id"])
             loss = model.get_loss(emb, users, pos_items, neg_items)
             loss.backward()
+            if args.grad_digest and epoch == 1 and _ == 0:
+                say("           | grad digest: loss %.9g  " % loss.item() + "  ".join(
+                    "%s %.9g" % (k, p.grad.double().abs().sum().item()) for k, p in model.named_parameters()
+                    if p.grad is not None))
             opt.step()
             opt.zero_grad()
             total += loss.item()
-        print("           | GNN %.1fs loss %.4f" % (time.time() - t0, total / n_it))
+        say("           | GNN %.1fs loss %.4f" % (time.time() - t0, total / n_it))
         # ---- evaluation (kgat.py:53-62, 171-196)
         t0 = time.time()
         with torch.no_grad():
@@ -146,9 +183,11 @@ def main():
                 g.edata["w"] = model.compute_attention(g)
                 emb = model.gnn(g, g.ndata["id"])
                 rec, ndcg = metrics.calc_recall_ndcg(emb, seen, held, ds.item_id_range, K=20)
-                print("           | %s recall@20 %.5f ndcg@20 %.5f" % (name, rec, ndcg))
+                say("           | %s recall@20 %.5f ndcg@20 %.5f" % (name, rec, ndcg))
             train_g.edata["w"] = model.compute_attention(train_g)
-        print("           | eval %.2fs" % (time.time() - t0))
+        say("           | eval %.2fs" % (time.time() - t0))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

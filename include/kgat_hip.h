@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 3
+#define KGAT_ABI_VERSION 4
 
 enum {
   KGAT_OK = 0,
@@ -65,10 +65,12 @@ enum {
 enum {
   KGAT_ATT_F32_PRODUCTS = 1 /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead of
                              * the default where a kernel has it (fused: d % 32 == 0; folded: d = 128):
-                             * every fp32 operand cut into three bf16 pieces that together hold its 24
-                             * significand bits, the six piece products of weight >= 2^-16 accumulated
-                             * in fp32 by v_mfma_f32_16x16x32_bf16 (dropped: <= 2^-24 of a product;
-                             * error against fp64 measured no larger than the fp32 form's) */
+                             * every fp32 operand cut by round-to-nearest into three bf16 pieces that
+                             * sum to it exactly (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|), the six piece
+                             * products of weight >= 2^-16 accumulated in fp32 by
+                             * v_mfma_f32_16x16x32_bf16; the three dropped products are together
+                             * < 2^-23 of |a*b| (one fp32 ulp), of either sign; error against fp64
+                             * measured no larger than the fp32 form's */
 };
 
 typedef void* kgat_stream_t; /* hipStream_t */
@@ -200,15 +202,26 @@ int kgat_fold_tile_parts(int64_t t_max, int n_rel, const int32_t* tiles, const i
                          int cost_tile, int cost_chunk, int cost_relation, int32_t* part_tptr, void* workspace,
                          size_t workspace_bytes, kgat_stream_t stream);
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
+/* What the fused kernel reads per grouped position, packed into one int32 (graph-static):
+ *   rec_g[p] = src_g[p] | (((gid[p] - gptr[relation of p]) & 15) << 28)
+ * i.e. the source (tail) node and the slot of the position's head group inside its 16-group block
+ * (tiles are cut out of such blocks, whatever the cap).  Needs n_nodes <= 2^28.  Positions past
+ * rel_ptr[R] (never scored) get their source node and slot 0. */
+int kgat_att_pack_records(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* gptr,
+                          const int32_t* gid, const int32_t* src_g, int32_t* rec_g, kgat_stream_t stream);
 /* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
- * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_F32_PRODUCTS. */
+ * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_F32_PRODUCTS.
+ * Outputs (any non-empty subset): logits_g[E] in grouped order (position p of the relation-grouped
+ * list; coalesced stores - the form the propagation path takes: kgat_edge_softmax_f32 then reads
+ * them through the CSR-position -> grouped-position map, see there), logits_csr[E] in CSR order
+ * (needs pos_g), logits[E] in edge-id order (needs perm).  Never-scored positions get 0. */
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
-                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* src_g,
-                             const int32_t* pos_g, const int32_t* gid, const int32_t* gptr,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                             const int32_t* pos_g, const int32_t* gptr,
                              const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
                              const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
-                             float* logits_csr, int flags, kgat_stream_t stream);
+                             float* logits_csr, float* logits_g, int flags, kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
@@ -311,10 +324,12 @@ int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t*
  * Forward of one KGATConv under autograd (reference models.py:63-70 with mess_drop active):
  *   h_out = dropout_p(LeakyReLU((H * HN) W2^T)),  norm_out = F.normalize(h_out)
  * H * HN is formed while the rows are loaded.  The dropout mask is a counter-based hash of
- * (seed, row * d_out + column): keep <=> hash >= p * 2^32, kept values scaled by 1/(1-p); the
- * backward recomputes it from the same seed.  Widths as kgat_bi_interaction_supported. */
+ * (seed, (row0 + row) * d_out + column): keep <=> hash >= p * 2^32, kept values scaled by 1/(1-p);
+ * the backward recomputes it from the same seed.  row0 = global index of the first row when H is a
+ * row range of a larger matrix (a destination shard draws the mask of the unsharded layer; 0
+ * otherwise).  Widths as kgat_bi_interaction_supported. */
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
-                                  const float* W2, float negative_slope, float drop_p, uint64_t seed,
+                                  const float* W2, float negative_slope, float drop_p, uint64_t seed, int64_t row0,
                                   float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream);
 /* Backward head of the same layer: with y = h_out saved by the forward,
  *   grad_z = [grad_a + grad_b + normalize_bwd(grad_norm; y)] * mask/(1-p) * LeakyReLU'(z)
@@ -324,7 +339,7 @@ int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const flo
  * grad_H = grad_P * HN + A^T (grad_P * H) (kgat_mul2_f32 + the SpMM on the reversed CSR). */
 int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,
                                     const float* grad_b, const float* grad_norm, int64_t grad_norm_stride,
-                                    float negative_slope, float drop_p, uint64_t seed, float* grad_z,
+                                    float negative_slope, float drop_p, uint64_t seed, int64_t row0, float* grad_z,
                                     kgat_stream_t stream);
 /* ab = a * b and ac = a * c elementwise in one pass (n a multiple of 4). */
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,

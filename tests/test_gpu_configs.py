@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import blocks, parity_8c, rel_err
+from conftest import blocks, parity_8c, rel_err, rel_err_inf
 from oracle import c_oracle as co
 from oracle import kgat_oracle as orc
 
@@ -38,7 +38,8 @@ def _model(n, n_rel, d, layers, hidden, dev, seed=1234):
 
 
 def _oracles(n, trip, params, n_layers):
-    """(attention fp32-C, readout fp32-C, attention fp64, readout fp64) of one full step."""
+    """(attention fp32-C, readout fp32-C, attention fp64, readout fp64, un-normalised layer outputs
+    fp64) of one full step."""
     src, dst, et = trip[:, 2], trip[:, 0], trip[:, 1]
     ent, W_R, rel = params["entity_embed.weight"], params["W_R"], params["relation_embed.weight"]
     W2 = [params["layers.%d.res_fc_2.weight" % i] for i in range(n_layers)]
@@ -50,8 +51,12 @@ def _oracles(n, trip, params, n_layers):
         cache.append(co.l2_normalize(h))
     out_c = np.concatenate(cache, 1)
     a_64 = orc.compute_attention(n, src, dst, et, ent, W_R, rel).reshape(-1)
-    out_64 = orc.gnn_forward(n, src, dst, a_64, ent, W2, spmm=orc.spmm_u_mul_e_sum_sparse)
-    return a_c, out_c, a_64, out_64
+    h64, cache64, layers64 = np.asarray(ent, np.float64), [np.asarray(ent, np.float64)], []
+    for W in W2:   # orc.gnn_forward (models.py:156-168), keeping the un-normalised layer outputs too
+        h64 = orc.bi_interaction(h64, orc.spmm_u_mul_e_sum_sparse(n, src, dst, h64, a_64), W)
+        layers64.append(h64)
+        cache64.append(orc.l2_normalize(h64))
+    return a_c, out_c, a_64, np.concatenate(cache64, 1), layers64
 
 
 def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
@@ -65,13 +70,30 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
     torch.cuda.synchronize()
     if expect_form is not None:
         assert g._st.last_att_form[0] == expect_form, g._st.last_att_form
-    a_c, out_c, a_64, out_64 = _oracles(n, trip, params, layers)
+    a_c, out_c, a_64, out_64, layers_64 = _oracles(n, trip, params, layers)
     a_h, out_h = a.cpu().numpy().reshape(-1), out.cpu().numpy()
     assert a_h.shape == a_64.shape and out_h.shape == out_64.shape
-    parity_8c(tag + " attention", a_h, a_c, a_64)
+    # Bars (round-2 review: hold the device to what it achieves, not to twice the CPU fp32 run):
+    #  * the 8c elementwise metric: 1e-4, or no further from fp64 than the CPU fp32 forward (factor 1);
+    #  * every tensor at its own scale (max|x - y| / max|y|): 1e-5 - the "<= 1e-4 relative fp32" of the
+    #    north star with a decade to spare; the attention additionally under the raw 8c bar of 1e-4;
+    #  * every layer's UN-normalised output (what the next layer consumes) at tensor scale: 1e-5.
+    e_att, _ = parity_8c(tag + " attention", a_h, a_c, a_64, factor=1.0)
+    assert e_att <= 1e-4, e_att
+    assert rel_err_inf(a_h, a_64) <= 1e-5
     widths = [d] + [model.layers[i].res_fc_2.out_features for i in range(layers)]
     for bi, (x, c, y) in enumerate(zip(blocks(out_h, widths), blocks(out_c, widths), blocks(out_64, widths))):
-        parity_8c("%s readout block %d" % (tag, bi), x, c, y)
+        parity_8c("%s readout block %d" % (tag, bi), x, c, y, factor=1.0)
+        e_inf = rel_err_inf(x, y)
+        print("[scale] %s readout block %d gpu %.3e (max|x-y| / max|y|; bar 1e-5)" % (tag, bi, e_inf))
+        assert e_inf <= 1e-5, (bi, e_inf)
+    with torch.no_grad():
+        h = model.entity_embed.weight.detach()
+        for li, layer in enumerate(model.layers):
+            h = layer(g, h, fused=True)
+            e_inf = rel_err_inf(h.cpu().numpy(), layers_64[li])
+            print("[scale] %s layer %d un-normalised output gpu %.3e (bar 1e-5)" % (tag, li, e_inf))
+            assert e_inf <= 1e-5, (li, e_inf)
     # zero in-degree destinations: exact zeros after every layer (and their normalised copies)
     iso = np.bincount(trip[:, 0], minlength=n) == 0
     if iso.any():
@@ -443,6 +465,72 @@ def test_two_ranks_sharded_forward_over_gloo_on_one_gpu(dev, tmp_path):
     script = tmp_path / "rank_worker.py"
     script.write_text(_RANK_WORKER % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    env.pop("KGAT_EXCHANGE", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+_GRAD_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import dgl_kgat_amd as K
+from dgl_kgat_amd import partition, synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda:0")                      # the ranks share the one GPU of the test box
+n, trip, R = synth.amazon_book_ckg(scale=0.05)
+for drop in (0.0, 0.1):
+    torch.manual_seed(11)
+    model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=drop).to(dev)
+    model.train()
+    g = synth.build_graph(n, trip, dev)
+    with torch.no_grad():
+        g.edata["w"] = model.compute_attention(g)
+    users = torch.arange(0, 4000, device=dev) %% n
+    pos, neg = (users * 7 + 3) %% n, (users * 13 + 5) %% n
+
+    def grads(graph):
+        model.zero_grad()
+        torch.manual_seed(5)                      # the dropout seed is drawn from torch's CPU generator
+        loss = model.get_loss(model.gnn(graph), users, pos, neg)
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    loss1, g1 = grads(g)                          # the one-GPU training stack (_GNNTrain)
+    sg, keep = partition.shard_graph(g, rank, world)
+    assert sg.partition.hi > sg.partition.lo
+    lossP, gP = grads(sg)                         # shard layers: local backward + all-reduce
+    assert abs(loss1 - lossP) <= 1e-5 * abs(loss1), (drop, loss1, lossP)
+    assert set(g1) == set(gP) and "entity_embed.weight" in g1 and "layers.0.res_fc_2.weight" in g1
+    for k in g1:
+        scale = float(g1[k].abs().max())
+        err = float((g1[k] - gP[k]).abs().max())
+        assert scale > 0 and err <= 1e-5 * scale, (drop, k, err, scale)
+    digest = [float(gP[k].double().abs().sum()) for k in sorted(gP)]
+    both = [None] * world
+    dist.all_gather_object(both, digest)
+    assert all(b == both[0] for b in both), "ranks hold different gradients"
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_ranks_sharded_backward_matches_one_gpu_gradients(dev, tmp_path):
+    """SURVEY 8e 'backward': the CF step (kgat.py:146-168) on destination shards.  Two processes
+    share cuda:0 over gloo; loss and every parameter gradient of the sharded training path
+    (partition._ShardConv: local reversed-CSR SpMM + all_reduce of grad_h / grad_W2) equal the
+    one-GPU fused training stack's to 1e-5 of each tensor's scale - with dropout off and with
+    dropout 0.1 (the hash mask is drawn on global rows, so the shards reproduce the one-GPU mask) -
+    and both ranks end with the same gradients."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "grad_worker.py"
+    script.write_text(_GRAD_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2")
     env.pop("KGAT_EXCHANGE", None)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]

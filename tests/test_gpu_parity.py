@@ -412,6 +412,21 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
         even = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
                                    tf(ent, dev), tf(W, dev), tf(rel, dev), want_eid=False)[1]
         assert torch.equal(even, fused_csr)
+        # grouped-order output (coalesced stores; what the propagation path takes): the same values at
+        # the grouped positions, alone or beside the scattered outputs, never-scored positions zero
+        rec = ops.att_pack_records(rel_ptr, gptr, gid, src_g)
+        rec_h, n_scored = rec.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, int(rel_ptr[-1])
+        assert np.array_equal(rec_h & 0x0FFFFFFF, src_g.cpu().numpy())
+        rel_of = np.searchsorted(rel_ptr.cpu().numpy(), np.arange(n_scored), side="right") - 1
+        assert np.array_equal(rec_h[:n_scored] >> 28, (gid.cpu().numpy()[:n_scored] - gptr.cpu().numpy()[rel_of]) & 15)
+        assert np.all(rec_h[n_scored:] >> 28 == 0)
+        for kw in (dict(want_eid=False, want_csr=False), dict(want_eid=want_eid, want_csr=True)):
+            g_out = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                        tf(ent, dev), tf(W, dev), tf(rel, dev), part_tptr=part_tptr, rec_g=rec,
+                                        want_grouped=True, **kw)
+            assert torch.equal(g_out[2], fused_csr[pos_g.long()])
+            assert kw["want_csr"] is False or torch.equal(g_out[1], fused_csr)
+            assert float(g_out[2][n_scored:].abs().max()) == 0 if n_scored < e else True
     assert rel_err_inf(fused_csr.cpu().numpy(), ref[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].cpu().numpy()]) < 1e-5
 
 
@@ -454,8 +469,14 @@ def test_att_fused_product_forms(K, dev, d):
     tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, n_parts=19)
     W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
     rel = rng.standard_normal((R, d)).astype(np.float32)
-    for case in ("normal", "wide range", "tiny", "signed zeros"):
+    W0, rel0 = W, rel
+    for case in ("normal", "wide range", "tiny", "signed zeros", "all positive", "large W"):
         ent = rng.standard_normal((n, d)).astype(np.float32)
+        W, rel = W0, rel0
+        if case == "all positive":   # same-sign operands everywhere: a one-sided error per product would add up
+            ent, W, rel = np.abs(ent), np.abs(W0) * np.float32(0.25), np.abs(rel0) * np.float32(0.1)
+        elif case == "large W":      # |W| near 1: d-term sums of O(1) products, tanh saturating
+            W = np.sign(W0) * (np.float32(0.75) + np.float32(0.25) * np.abs(W0) * np.float32(np.sqrt(d)))
         if case == "wide range":   # rows scaled by 2^-60 .. 2^+10; elements by up to 2^-12 more
             ent *= np.exp2(rng.integers(-60, 11, (n, 1))).astype(np.float32)
             ent *= np.exp2(-rng.integers(0, 13, (n, d))).astype(np.float32)
@@ -481,6 +502,14 @@ def test_att_fused_product_forms(K, dev, d):
               % (d, case, e_new / scale, e_f32 / scale, rel_err(got[False], ref), rel_err(got[True], ref)))
         assert e_new <= max(2.0 * e_f32, 2e-7 * scale), (case, e_new, e_f32)
         assert rel_err(got[False], ref) <= max(1e-4, 2.0 * rel_err(got[True], ref)), case
+        if case in ("all positive", "large W"):
+            # round-to-nearest pieces: the dropped piece products are two-signed and below one fp32 ulp of
+            # a product, so same-sign sums do not drift: the mean signed error stays far below the fp32
+            # chain's rounding level, and the piece form is no worse than the fp32-MFMA form
+            bias = abs(float(np.mean(got[False].astype(np.float64) - ref))) / scale
+            bias32 = abs(float(np.mean(got[True].astype(np.float64) - ref))) / scale   # (shares the tanh evaluation)
+            print("    mean signed error / max|ref|: bf16 pieces %.3e  fp32 products %.3e" % (bias, bias32))
+            assert e_new <= 1.0 * e_f32 + 1e-7 * scale and bias <= max(2.0 * bias32, 3e-8), (case, e_new, e_f32, bias)
 
 
 def test_att_folded_d128(K, dev):
