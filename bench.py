@@ -128,7 +128,7 @@ def hbm_resident_spmm_leg(args, dev):
     ws = ops.spmm_workspace(e, D, dev)
     # Where the 2.56 GB gathered table lands PHYSICALLY moves this launch by 10-14 % on one box with
     # the same bytes: fresh allocations of the same size at the same virtual address fall into a fast
-    # (9.2-9.4 ms) or a slow (10.3-10.5 ms) mode, allocation by allocation (scripts/placement_probe2.py;
+    # (9.2-9.4 ms) or a slow (10.3-10.5 ms) mode, allocation by allocation (scripts/placement_study.py;
     # DESIGN.md 3.1).  A long-lived table is allocated once, so the leg does what a deployment can do
     # once: it draws up to eight candidate allocations, times two launches on each, keeps the fastest and
     # frees the others - and reports every candidate's time, so the slow mode is on the line too.

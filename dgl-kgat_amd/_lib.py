@@ -64,7 +64,7 @@ SIGNATURES = {
     "kgat_edge_softmax_bwd_f32": (_i32, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
     "kgat_spmm_workspace_bytes": (_sz, [_i64, _i32]),
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
-                                       _p, _sz, _u32, _i32, _p]),
+                                       _p, _sz, _u32, _i32, _p, _i64, _p]),
     "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
     "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _i64, _p,
                                              _p, _i64, _p]),

@@ -747,6 +747,7 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
   __shared__ int32_t s_tptr[kAttMaxRelLds + 1];
   __shared__ __attribute__((aligned(16))) float s_w[X3 ? 4 : D_ * LD];
   __shared__ __attribute__((aligned(16))) unsigned char s_img[X3 ? 3 * IMG : 16];
+  __shared__ __attribute__((aligned(16))) float s_rel[K_];
   const int tid = threadIdx.x;
   for (int r = tid; r < n_rel; r += kFoldLdsThreads) s_tptr[r + 1] = (gptr[r + 1] - gptr[r] + 15) >> 4;
   __syncthreads();
@@ -813,14 +814,10 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
         *reinterpret_cast<float4*>(s_w + (idx / K_) * LD + (idx % K_)) = v;
       }
     }
+    // e_r * 2 log2(e), staged in LDS: at d = 128 holding the lane's 32 values in registers across the
+    // tile pushed the bf16-piece form over the 256-register budget (36 bytes of scratch in round 2)
+    for (int u = tid; u < K_; u += kFoldLdsThreads) s_rel[u] = rel[(size_t)r * K_ + u] * kTwoLog2e;
     __syncthreads();
-    float relv[KT][4];
-#pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      const float4 v = *reinterpret_cast<const float4*>(rel + (size_t)r * K_ + 16 * c + 4 * q);
-      relv[c][0] = v.x * kTwoLog2e; relv[c][1] = v.y * kTwoLog2e;
-      relv[c][2] = v.z * kTwoLog2e; relv[c][3] = v.w * kTwoLog2e;
-    }
     auto row_of_tile = [&](int32_t n) -> int32_t {
       n = n < seg_end ? n : seg_end - 1;
       int32_t g = rbeg + ((n - tfirst) << 4) + i;
@@ -891,9 +888,13 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
       }
       KGAT_ATT_PHASE_T(pt1);
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
+      for (int c = 0; c < KT; ++c) {
+        const float4 rv = *reinterpret_cast<const float4*>(s_rel + 16 * c + 4 * q);
+        acc[c][0] = att_tanh_scaled(fmaf(acc[c][0], kTwoLog2e, rv.x));
+        acc[c][1] = att_tanh_scaled(fmaf(acc[c][1], kTwoLog2e, rv.y));
+        acc[c][2] = att_tanh_scaled(fmaf(acc[c][2], kTwoLog2e, rv.z));
+        acc[c][3] = att_tanh_scaled(fmaf(acc[c][3], kTwoLog2e, rv.w));
+      }
 #pragma unroll
       for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_sched_barrier(0);

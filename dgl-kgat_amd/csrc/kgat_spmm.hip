@@ -47,11 +47,24 @@ struct SpmmGeom {
   static constexpr int U = LPR >= 4 ? 4 : LPR;     // X-row loads in flight per subgroup
 };
 
+// Where a launch also copies the rows' own features (KGAT_SPMM_MUL_SELF reads X[v] anyway): the ego
+// block of Model.gnn's readout, out[:, :d] = h0 (models.py:159,168), written from the register that
+// holds X[v] instead of by a separate 2 x N x d x 4-byte copy pass.
+struct SelfCopy {
+  float4* out;      // nullptr: off
+  int64_t stride4;  // row stride in float4 units
+};
+
 // Final store of a complete row.
-template <int LPR, bool MUL_SELF>
+template <int LPR, bool MUL_SELF, bool COPY_SELF = false>
 __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4* __restrict__ X,
-                                          int32_t row, int32_t row0, int sl, float4 v) {
-  if (MUL_SELF) v = mul4(v, X[(size_t)row * LPR + sl]);
+                                          int32_t row, int32_t row0, int sl, float4 v,
+                                          const SelfCopy sc = SelfCopy{nullptr, 0}) {
+  if (MUL_SELF) {
+    const float4 x = X[(size_t)row * LPR + sl];
+    v = mul4(v, x);
+    if (COPY_SELF) sc.out[(size_t)(row - row0) * sc.stride4 + sl] = x;
+  }
   out[(size_t)(row - row0) * LPR + sl] = v;
 }
 
@@ -196,11 +209,11 @@ struct alignas(16) EdgeRec {
   int32_t pad;
 };
 
-template <int LPR, int C, bool MUL_SELF>
+template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false>
 __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
     int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
     const int32_t* __restrict__ row_of, const float4* __restrict__ X, const float* __restrict__ w,
-    float4* __restrict__ out, float4* __restrict__ bpart) {
+    float4* __restrict__ out, float4* __restrict__ bpart, const SelfCopy sc) {
   constexpr int NSUB = SpmmGeom<LPR>::NSUB;
   constexpr int TE = NSUB * C;
 #ifndef KGAT_SPMM_GROUP
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
       if (sl == 0) s_row[sub][0] = cur_row;
       head_done = true;
     } else {
-      store_row<LPR, MUL_SELF>(out, X, cur_row, row0, sl, acc);
+      store_row<LPR, MUL_SELF, COPY_SELF>(out, X, cur_row, row0, sl, acc, sc);
     }
     a01 = (float2v){0.f, 0.f};
     a23 = (float2v){0.f, 0.f};
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
     auto emit = [&](int32_t rr, const float4& v) {
       if (rr == first_row) bp[sl] = v;
       else if (rr == last_row) bp[LPR + sl] = v;
-      else store_row<LPR, MUL_SELF>(out, X, rr, row0, sl, v);
+      else store_row<LPR, MUL_SELF, COPY_SELF>(out, X, rr, row0, sl, v, sc);
     };
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -435,12 +448,12 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
 // first form, spent 0.3 ms of a 200 M-edge launch on waves that returned at once; one item per
 // LANE, tried next, serialised up to 64 latency-bound chains in a wave: 9 -> 30 us on the
 // amazon-book graph.)
-template <int LPR, int C, bool MUL_SELF>
+template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false>
 __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
     int64_t e0, int64_t e1, int32_t row0, int32_t n_rows, int32_t n_tiles,
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
     const float4* __restrict__ X, float4* __restrict__ out, const float4* __restrict__ bpart,
-    int32_t fix_blocks) {
+    int32_t fix_blocks, const SelfCopy sc) {
   constexpr int NSUB = SpmmGeom<LPR>::NSUB;
   constexpr int TE = NSUB * C;
   constexpr int SPW = kWave / LPR >= 1 ? kWave / LPR : 1;  // subgroups per wave
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
     if (my_row >= 0 && !is_long) {
       float4 acc = bpart[((size_t)b * 2 + s) * LPR + sl];
       for (int32_t bb = b + 1; bb <= my_bl; ++bb) acc = add4(acc, bpart[((size_t)bb * 2) * LPR + sl]);
-      store_row<LPR, MUL_SELF>(out, X, my_row, row0, sl, acc);
+      store_row<LPR, MUL_SELF, COPY_SELF>(out, X, my_row, row0, sl, acc, sc);
     }
     unsigned long long todo = __ballot(is_long && sl == 0);
     while (todo) {
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
         o.w = __shfl_xor(acc.w, off, kWave);
         acc = add4(acc, o);
       }
-      if (q == 0) store_row<LPR, MUL_SELF>(out, X, r, row0, sl, acc);
+      if (q == 0) store_row<LPR, MUL_SELF, COPY_SELF>(out, X, r, row0, sl, acc, sc);
     }
   } else {
     // rows without in-edges: one LANE tests one row (coalesced indptr loads, 64 rows per step); the
@@ -531,7 +544,10 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
       while (m) {
         const int b = __ffsll((long long)m) - 1;
         m &= m - 1;
-        if (turn == q) out[(size_t)(v0 + b) * LPR + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (turn == q) {
+          out[(size_t)(v0 + b) * LPR + sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (COPY_SELF) sc.out[(size_t)(v0 + b) * sc.stride4 + sl] = X[(size_t)(row0 + v0 + b) * LPR + sl];
+        }
         turn = turn + 1 == SPW ? 0 : turn + 1;
       }
     }
@@ -620,6 +636,8 @@ struct SpmmArgs {
   int algo;
   int32_t e0_host, e1_host;  // CSR position range of the row range
   hipStream_t st;
+  float* self_out = nullptr;  // MUL_SELF launches of the merge algorithm: also copy X[v] here (SelfCopy)
+  int64_t self_stride = 0;    // row stride of self_out in floats (a multiple of 4)
 };
 
 // C: edges per lane-group run in the merge kernels; tiles are NSUB * C <= 2048 edges (the
@@ -664,8 +682,10 @@ static bool use_mid_runs(int64_t n_edges) {
   return merge_tiles_c<LPR, mid_run_len(LPR)>(n_edges) <= kMidRunTileLimit;
 }
 
-template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
+template <int LPR, int C, bool MUL_SELF, bool HAS_EID, bool COPY_SELF = false>
 static int launch_merge_c(const SpmmArgs& a) {
+  if (MUL_SELF && !HAS_EID && !COPY_SELF && a.self_out != nullptr) return launch_merge_c<LPR, C, MUL_SELF, HAS_EID, MUL_SELF && !HAS_EID>(a);
+  const SelfCopy sc{reinterpret_cast<float4*>(a.self_out), a.self_stride / 4};
   const int64_t e0 = a.e0_host, e1 = a.e1_host;
   const int64_t tiles = merge_tiles_c<LPR, C>(e1 - e0);
   const size_t need = (size_t)tiles * 2 * LPR * sizeof(float4);
@@ -676,9 +696,9 @@ static int launch_merge_c(const SpmmArgs& a) {
   float4* bpart = static_cast<float4*>(a.ws);
   if (tiles > 0) {
     if (!HAS_EID && a.algo != KGAT_SPMM_ALGO_MERGE1) {
-      hipLaunchKernelGGL((spmm_merge2_kernel<LPR, C, MUL_SELF>), dim3((unsigned)tiles),
+      hipLaunchKernelGGL((spmm_merge2_kernel<LPR, C, MUL_SELF, COPY_SELF>), dim3((unsigned)tiles),
                          dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
-                         (const float4*)a.X, a.w, (float4*)a.out, bpart);
+                         (const float4*)a.X, a.w, (float4*)a.out, bpart, sc);
     } else {
       hipLaunchKernelGGL((spmm_merge_kernel<LPR, C, MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
                          dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
@@ -691,10 +711,10 @@ static int launch_merge_c(const SpmmArgs& a) {
   int64_t nz_blocks = (a.n_rows + kSpmmThreads - 1) / kSpmmThreads;  // one lane per row
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
-  hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF>),
+  hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF, COPY_SELF>),
                      dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kSpmmThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
-                     (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks);
+                     (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks, sc);
   KGAT_CHECK_LAUNCH("spmm_finish");
   return KGAT_OK;
 }
@@ -805,7 +825,8 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
                             const int32_t* indptr, const int32_t* col, const int32_t* row_of,
                             const int32_t* eid, const float* X, const float* w, float* out,
                             const int32_t* order, void* workspace, size_t workspace_bytes,
-                            unsigned flags, int algo, kgat_stream_t stream) {
+                            unsigned flags, int algo, float* self_out, int64_t self_stride,
+                            kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_rows >= 0 && row0 >= 0 && D > 0, "spmm: bad size (n_rows=%lld row0=%lld D=%d)",
                  (long long)n_rows, (long long)row0, D);
   KGAT_CHECK_ARG(row0 + n_rows < INT32_MAX, "spmm: row range exceeds int32");
@@ -824,7 +845,14 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
                  "spmm: merge algorithm needs row_of");
   KGAT_CHECK_ARG(order == nullptr || algo == KGAT_SPMM_ALGO_ROWS,
                  "spmm: a row order only applies to the rows algorithm");
+  if (self_out != nullptr) {
+    KGAT_CHECK_ARG((flags & KGAT_SPMM_MUL_SELF) && eid == nullptr && algo == KGAT_SPMM_ALGO_MERGE,
+                   "spmm: self_out goes with KGAT_SPMM_MUL_SELF, CSR-ordered weights and the merge algorithm");
+    KGAT_CHECK_ARG(self_stride >= D && self_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(self_out) & 15u) == 0,
+                   "spmm: self_out must be 16-byte aligned with a row stride that is a multiple of 4 floats >= D");
+  }
   SpmmArgs a;
+  a.self_out = self_out; a.self_stride = self_stride;
   a.n_rows = n_rows; a.row0 = row0; a.D = D;
   a.indptr = indptr; a.col = col; a.row_of = row_of; a.eid = eid; a.order = order;
   a.X = X; a.w = w; a.out = out; a.ws = workspace; a.ws_bytes = workspace_bytes;

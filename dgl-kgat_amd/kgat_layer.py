@@ -14,6 +14,7 @@ Two ways through every step:
   and the SpMM with the ``h * h_N`` product in its epilogue.  Same results, fewer passes.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -217,8 +218,20 @@ class KGATPropagation(nn.Module):
         h0 = h
         off = widths[0]
         w = g.edata["w"]
+        # the first aggregation also writes the ego block (kgat_spmm_umule_sum_f32's self_out: X[v] is in a
+        # register for the h * h_N product anyway) instead of an N x d copy pass at the end: step 0.491 ->
+        # 0.481 ms on the benchmark graph (the copy launch was 18 us; the aggregation grows by 3.5 us, and
+        # the attention launch of the next step by 3.5 us because the pass no longer ends on the embedding
+        # table).  KGAT_GNN_COPY_SELF=0 restores the separate copy.
+        copy_self = os.environ.get("KGAT_GNN_COPY_SELF", "1") not in ("", "0") and widths[0] % 4 == 0
+        st = g._st
         for li, layer in enumerate(self.layers):
-            prod = u_mul_e_sum(g, h, w, mul_self=True)
+            if li == 0 and copy_self:
+                csr = st.csr(h.device)
+                prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.contiguous(), st.csr_weights(w), mul_self=True,
+                                self_out=out[:, :widths[0]])
+            else:
+                prod = u_mul_e_sum(g, h, w, mul_self=True)
             last = li + 1 == len(self.layers)
             h = ops.bi_interaction(prod, layer.res_fc_2.weight.detach(), 0.01,
                                    norm_out=out[:, off:off + widths[li + 1]], want_h=not last)
@@ -227,7 +240,8 @@ class KGATPropagation(nn.Module):
         # is what the next attention refresh gathers from (a step's working set is about the size
         # of the 256 MiB Infinity Cache; written first, the table was the oldest resident by then:
         # the attention launch measured 0.231 ms inside the step against 0.19 ms on its own)
-        out[:, :widths[0]] = h0
+        if not copy_self:
+            out[:, :widths[0]] = h0
         return out
 
     def transR(self, h, r, pos_t, neg_t, reg_lambda_kg=0.01, fused=None):

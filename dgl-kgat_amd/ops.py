@@ -431,10 +431,11 @@ def spmm_workspace(n_edges, D, device):
 
 
 def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=False, algo="auto",
-         rows=None, e_range=None, workspace=None):
+         rows=None, e_range=None, workspace=None, self_out=None):
     """out[v - row0] = sum_p w_p X[col[p]] over the CSR rows `rows` = (row0, n_rows) whose CSR
     positions are `e_range` (defaults: the whole graph).  w is in CSR order, or in edge-id
-    order when `eid` is given."""
+    order when `eid` is given.  `self_out` (with mul_self): an (n_rows, D) column slice of a wider
+    row-major buffer that also receives X[v] (the ego block of the readout)."""
     X = _need(X, torch.float32, "X")
     if X.dim() != 2:
         raise ValueError("X must be (N, D)")
@@ -456,11 +457,15 @@ def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=Fal
         out = _need(out, torch.float32, "out", (n_rows, D))
     if workspace is None:
         workspace = spmm_workspace(e1 - e0, D, X.device)
+    self_stride = 0
+    if self_out is not None:
+        self_stride = _strided_rows(self_out, n_rows, D, "self_out")
     with _timed("spmm", (e1 - e0, n_rows, D)):
         check(_lib.load().kgat_spmm_umule_sum_f32(n_rows, row0, e0, e1, D, _ptr(indptr), _ptr(col), _ptr(row_of),
                                                   _ptr(eid), _ptr(X), _ptr(w), _ptr(out), _ptr(order),
                                                   _ptr(workspace), workspace.numel(),
-                                                  SPMM_MUL_SELF if mul_self else 0, SPMM_ALGO[algo], _stream(X)),
+                                                  SPMM_MUL_SELF if mul_self else 0, SPMM_ALGO[algo],
+                                                  _ptr(self_out), self_stride, _stream(X)),
               "kgat_spmm_umule_sum_f32")
     return out
 

@@ -273,13 +273,18 @@ int kgat_edge_softmax_bwd_f32(int64_t n_rows, int64_t row0, const int32_t* indpt
  * row_of (destination per CSR position) is required by the MERGE algorithm; `order` (a row
  * schedule from kgat_row_order_by_degree over the same row range, entries relative to
  * row0) only applies to ROWS.  workspace: kgat_spmm_workspace_bytes(e_end - e_begin, D).
+ * self_out (may be NULL; with KGAT_SPMM_MUL_SELF, CSR-ordered weights, MERGE / AUTO): the launch also
+ * writes X[v, :] to self_out[(v - row0) * self_stride + 0..D) - the ego block [h0 | ...] of
+ * Model.gnn's readout (models.py:159,168) from the register that already holds the row, instead of a
+ * separate copy pass; self_stride in floats, a multiple of 4, self_out 16-byte aligned.
  * Backward w.r.t. X (S1b) is this same call on the CSR of the reversed graph. */
 size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D);
 int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64_t e_end, int D,
                             const int32_t* indptr, const int32_t* col, const int32_t* row_of,
                             const int32_t* eid, const float* X, const float* w, float* out,
                             const int32_t* order, void* workspace, size_t workspace_bytes,
-                            unsigned flags, int algo, kgat_stream_t stream);
+                            unsigned flags, int algo, float* self_out, int64_t self_stride,
+                            kgat_stream_t stream);
 
 /* Gradient of the aggregation w.r.t. the edge weight (DGL backward_rhs of the same op):
  *   grad_w[e] = < X[src e, :], grad_out[dst e, :] >,  edge-id order. */

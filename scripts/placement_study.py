@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Why does the HBM-resident SpMM run in a fast or a slow mode depending on the ALLOCATION of the
+gathered table?  One tool (it replaces the round-2 probes placement_probe{,2,3}.py,
+interleave_probe.py, pl_step_probe.py):
+
+  python scripts/placement_study.py modes [--tries 16]
+      fresh allocations of the 2.56 GB table, two launches each: the distribution of the two modes on
+      this box; then the same launch with the table inside arenas of 4 / 8 / 16 GiB and with a
+      sequential read and a copy of the fast and the slow table (streaming is mode-blind).
+
+  rocprofv3 --pmc <counters> -d <dir> --output-format csv -- python3 scripts/placement_study.py pmc --sidecar <dir>/sidecar.json
+      finds one fast and one slow allocation, then launches the SpMM `--reps` times on each,
+      alternating, and writes the label of every spmm_merge2_kernel dispatch (in dispatch order) to
+      the sidecar, so that the per-dispatch counter rows can be told apart afterwards.
+
+  python scripts/placement_study.py report <dir> [<dir> ...]
+      per counter: mean over the fast and over the slow dispatches and their ratio.
+
+The stride hypothesis (rows padded to 320 B) is probed without the rest of the stack by
+scripts/micro/gather_modes.hip."""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def setup(n, e):
+    import torch
+    from dgl_kgat_amd import ops, synth
+    dev = torch.device("cuda:0")
+    src, dst, _ = synth.power_law_coo_device(n, e, 64, dev)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
+    del src, dst, eid, _
+    w = torch.rand(e, device=dev)
+    out = torch.empty((n, 64), device=dev)
+    ws = ops.spmm_workspace(e, 64, dev)
+
+    def launch(X):
+        ops.spmm(indptr, col, row_of, X, w, out=out, workspace=ws)
+    return dev, launch
+
+
+def time_launches(launch, X, k):
+    import torch
+    ev = []
+    for _ in range(k):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch(X)
+        b.record()
+        ev.append((a, b))
+    torch.cuda.synchronize()
+    return np.array([a.elapsed_time(b) for a, b in ev])
+
+
+def find_modes(launch, n, dev, tries, log):
+    """Fresh tables until one fast and one slow one are in hand (or `tries` are spent).  Returns
+    (fast table or None, slow table or None, all first-pair times)."""
+    import torch
+    torch.cuda.empty_cache()
+    held, times = [], []
+    for i in range(tries):
+        X = torch.empty((n, 64), dtype=torch.float32, device=dev)
+        X.normal_()
+        t = float(time_launches(launch, X, 2).min())
+        times.append(round(t, 3))
+        held.append((t, X))
+        log.append("table")
+        log.append("table")
+        lo, hi = min(times), max(times)
+        if hi > 1.06 * lo and i >= 1:
+            break
+    held.sort(key=lambda p: p[0])
+    lo, hi = held[0][0], held[-1][0]
+    if hi <= 1.06 * lo:
+        return None, None, times, held[0][1]
+    fast, slow = held[0][1], held[-1][1]
+    return fast, slow, times, None
+
+
+def cmd_modes(args):
+    import torch
+    dev, launch = setup(args.nodes, args.edges)
+    fast, slow, times, only = find_modes(launch, args.nodes, dev, args.tries, [])
+    print("first-pair times of fresh 2.56 GB tables (ms):", times)
+    if fast is None:
+        print("one mode only on this box in %d allocations (%.2f ms)" % (len(times), min(times)))
+        fast = slow = only
+    for name, X in (("fast", fast), ("slow", slow)):
+        t = time_launches(launch, X, 10)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        s = X.sum()
+        b.record()
+        c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        Y = torch.empty_like(X)
+        c.record()
+        Y.copy_(X)
+        d.record()
+        torch.cuda.synchronize()
+        print("%s table: SpMM median %.3f ms | sequential read %.3f ms | copy %.3f ms | ptr %x" % (
+            name, np.median(t), a.elapsed_time(b), c.elapsed_time(d), X.data_ptr()))
+        del Y, s
+
+
+def cmd_pmc(args):
+    dev, launch = setup(args.nodes, args.edges)
+    log = []
+    fast, slow, times, only = find_modes(launch, args.nodes, dev, args.tries, log)
+    rec = {"first_pair_ms": times, "both_modes": fast is not None}
+    if fast is None:
+        fast = slow = only
+    per = {"fast": [], "slow": []}
+    for _ in range(args.rounds):
+        for name, X in (("fast", fast), ("slow", slow)):
+            t = time_launches(launch, X, args.reps)
+            per[name] += [float(x) for x in t]
+            log += [name] * args.reps
+    rec["labels"] = log
+    rec["ms"] = {k: [round(x, 4) for x in v] for k, v in per.items()}
+    os.makedirs(os.path.dirname(os.path.abspath(args.sidecar)), exist_ok=True)  # (the profiler creates it at exit)
+    with open(args.sidecar, "w") as f:
+        json.dump(rec, f)
+    print("modes found: %s; fast median %.3f ms, slow median %.3f ms (under the profiler)" % (
+        rec["both_modes"], np.median(per["fast"]), np.median(per["slow"])))
+
+
+def cmd_report(args):
+    for d in args.dirs:
+        side = json.load(open(os.path.join(d, "sidecar.json")))
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            print(d, ": no counter_collection.csv")
+            continue
+        rows = list(csv.DictReader(open(files[0])))
+        name_key = next(k for k in rows[0] if k.lower() in ("kernel_name", "kernel-name"))
+        disp_key = next(k for k in rows[0] if k.lower() in ("dispatch_id", "dispatch-id"))
+        cnt_key = next(k for k in rows[0] if k.lower() in ("counter_name", "counter-name"))
+        val_key = next(k for k in rows[0] if k.lower() in ("counter_value", "counter-value"))
+        per_disp = {}
+        for r in rows:
+            if "spmm_merge2_kernel" not in r[name_key]:
+                continue
+            per_disp.setdefault(int(r[disp_key]), {})[r[cnt_key]] = float(r[val_key])
+        order = sorted(per_disp)
+        labels = side["labels"]
+        print("%s: %d spmm_merge2 dispatches, %d labels, both modes: %s, ms fast %.3f slow %.3f" % (
+            d, len(order), len(labels), side["both_modes"], np.median(side["ms"]["fast"]), np.median(side["ms"]["slow"])))
+        if len(order) != len(labels):
+            print("  dispatch / label count mismatch: not attributed")
+            continue
+        agg = {}
+        for disp, lab in zip(order, labels):
+            if lab not in ("fast", "slow"):
+                continue
+            for c, v in per_disp[disp].items():
+                agg.setdefault(c, {"fast": [], "slow": []})[lab].append(v)
+        for c, v in sorted(agg.items()):
+            f, s = np.mean(v["fast"]), np.mean(v["slow"])
+            print("  %-44s fast %.6g  slow %.6g  slow/fast %.3f" % (c, f, s, s / f if f else float("nan")))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name in ("modes", "pmc"):
+        p = sub.add_parser(name)
+        p.add_argument("--nodes", type=int, default=10_000_000)
+        p.add_argument("--edges", type=int, default=200_000_000)
+        p.add_argument("--tries", type=int, default=16)
+        if name == "pmc":
+            p.add_argument("--sidecar", required=True)
+            p.add_argument("--reps", type=int, default=3)
+            p.add_argument("--rounds", type=int, default=2)
+    p = sub.add_parser("report")
+    p.add_argument("dirs", nargs="+")
+    args = ap.parse_args()
+    {"modes": cmd_modes, "pmc": cmd_pmc, "report": cmd_report}[args.cmd](args)
+
+
+if __name__ == "__main__":
+    main()

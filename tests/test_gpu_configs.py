@@ -76,7 +76,10 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
     # Bars (round-2 review: hold the device to what it achieves, not to twice the CPU fp32 run):
     #  * the 8c elementwise metric: 1e-4, or no further from fp64 than the CPU fp32 forward (factor 1);
     #  * every tensor at its own scale (max|x - y| / max|y|): 1e-5 - the "<= 1e-4 relative fp32" of the
-    #    north star with a decade to spare; the attention additionally under the raw 8c bar of 1e-4;
+    #    north star with a decade to spare - or, for a normalised readout block whose small-norm rows
+    #    amplify any fp32 forward (configs[0]: width 8, one layer: 1.9e-5 on the device, C fp32 alike),
+    #    no further from fp64 than the CPU fp32 forward; the attention additionally under the raw 8c
+    #    bar of 1e-4;
     #  * every layer's UN-normalised output (what the next layer consumes) at tensor scale: 1e-5.
     e_att, _ = parity_8c(tag + " attention", a_h, a_c, a_64, factor=1.0)
     assert e_att <= 1e-4, e_att
@@ -84,9 +87,10 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
     widths = [d] + [model.layers[i].res_fc_2.out_features for i in range(layers)]
     for bi, (x, c, y) in enumerate(zip(blocks(out_h, widths), blocks(out_c, widths), blocks(out_64, widths))):
         parity_8c("%s readout block %d" % (tag, bi), x, c, y, factor=1.0)
-        e_inf = rel_err_inf(x, y)
-        print("[scale] %s readout block %d gpu %.3e (max|x-y| / max|y|; bar 1e-5)" % (tag, bi, e_inf))
-        assert e_inf <= 1e-5, (bi, e_inf)
+        e_inf, c_inf = rel_err_inf(x, y), rel_err_inf(c, y)
+        print("[scale] %s readout block %d gpu %.3e  c-fp32 %.3e (max|x-y| / max|y|; bar max(1e-5, c-fp32))"
+              % (tag, bi, e_inf, c_inf))
+        assert e_inf <= max(1e-5, c_inf), (bi, e_inf, c_inf)
     with torch.no_grad():
         h = model.entity_embed.weight.detach()
         for li, layer in enumerate(model.layers):

@@ -184,6 +184,32 @@ def test_spmm_row_range_shard(K, dev):
             assert sum_err(out, ref[lo:hi], ref_abs[lo:hi]) < TOL, (lo, hi, algo)
 
 
+@pytest.mark.parametrize("D", [16, 32, 64, 128])
+def test_spmm_self_copy_epilogue(K, dev, D):
+    """kgat_spmm_umule_sum_f32's self_out: the h * h_N launch also writes X[v] into a column slice of
+    a wider buffer (the ego block of the readout) - same bits in `out` as without it, every row of the
+    slice equal to X (rows finished in a tile, rows finished by the finish launch, rows without
+    in-edges), nothing outside the slice touched; whole graph and a row-range shard."""
+    from dgl_kgat_amd import ops
+    n, e = 3000, 90000
+    src, dst = random_graph(50 + D, n, e, hub=20000, isolated_tail=40)
+    rng = np.random.default_rng(51)
+    X = tf(rng.standard_normal((n, D)).astype(np.float32), dev)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w_csr = tf(rng.random(e).astype(np.float32), dev)
+    ip = indptr.cpu().numpy()
+    for lo, hi in [(0, n), (5, 1700)]:
+        kw = dict(rows=(lo, hi - lo), e_range=(int(ip[lo]), int(ip[hi])))
+        plain = ops.spmm(indptr, col, row_of, X, w_csr, mul_self=True, **kw)
+        wide = torch.full((hi - lo, D + 24), 7.0, device=dev)
+        got = ops.spmm(indptr, col, row_of, X, w_csr, mul_self=True, self_out=wide[:, 8:8 + D], **kw)
+        assert torch.equal(got, plain)
+        assert torch.equal(wide[:, 8:8 + D], X[lo:hi])
+        assert bool((wide[:, :8] == 7.0).all()) and bool((wide[:, 8 + D:] == 7.0).all())
+    with pytest.raises(Exception):   # the copy reads the row the product reads: it needs KGAT_SPMM_MUL_SELF
+        ops.spmm(indptr, col, row_of, X, w_csr, self_out=torch.empty((n, D), device=dev))
+
+
 @pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
 def test_edge_softmax_vs_oracle(K, dev, name, n, e, hub, iso):
     from dgl_kgat_amd import ops
@@ -632,7 +658,12 @@ def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
             assert blocks_rel_err_inf(out.cpu().numpy(), g["gnn_out"], widths) < TOL, fused
             for bi, (x, c, y) in enumerate(zip(blocks(out.cpu().numpy(), widths), blocks(out_c, widths),
                                                blocks(g["gnn_out"], widths))):
+                # (50-200-node graphs: the maximum of the 8c metric over a few thousand elements is an extreme
+                # value of a small sample and moves 2-3 x between two fp32 summation orders of the dense
+                # product alone, scripts/error_attribution.py; hence 4 x here, 1 x at config size, and the
+                # tensor-scale bound below)
                 parity_8c("%s readout block %d (%s)" % (case, bi, "fused" if fused else "surface"), x, c, y, factor=4.0)
+                assert rel_err_inf(x, y) <= 1e-5
         h = model.entity_embed(graph.ndata["id"])
         for i, layer in enumerate(model.layers):
             h = layer(graph, h, fused=False)
@@ -763,9 +794,10 @@ def test_att_product_flag_is_validated(K, dev):
     p = lambda t: t.data_ptr()  # noqa: E731
     st = torch.cuda.current_stream().cuda_stream
     for flags, want in ((0, 0), (1, 0), (2, -1), (-1, -1)):
-        rc = lib.kgat_att_score_fused_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(src_g), p(pos_g), p(gid), p(gptr),
+        rec = ops.att_pack_records(rel_ptr, gptr, gid, src_g)
+        rc = lib.kgat_att_score_fused_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(rec), p(pos_g), p(gptr),
                                           p(g_node), p(tiles), p(rel_tptr), p(part_tptr), part_tptr.numel() - 1, p(ent),
-                                          p(W), p(rel), p(out), None, flags, st)
+                                          p(W), p(rel), p(out), None, None, flags, st)
         assert rc == want, (flags, rc, lib.kgat_last_error())
         if want:
             assert b"unknown flag" in lib.kgat_last_error()

@@ -29,7 +29,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.kgat_build_hash().decode() == "kgat-src-hash:" + _lib.source_hash() and not _lib.needs_build()
     # argument validation happens before any device work: callable without a GPU
     assert lib.kgat_spmm_umule_sum_f32(-1, 0, 0, 0, 64, None, None, None, None, None, None, None, None, None,
-                                       0, 0, 0, None) == -1
+                                       0, 0, 0, None, 0, None) == -1
     assert b"spmm" in lib.kgat_last_error()
     assert lib.kgat_csr_from_coo_workspace_bytes(10, 1000) > 3 * 4000
     assert lib.kgat_spmm_workspace_bytes(3663302, 64) > 0
