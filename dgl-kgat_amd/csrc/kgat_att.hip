@@ -525,7 +525,10 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
 }
 
 int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel) {
-  return kgat_att_score_split_supported(n_nodes, d, k, n_rel);
+  // d = k = 128 (round 3): bf16-piece products only (KGAT_ATT_F32_PRODUCTS at that width is
+  // KGAT_E_UNSUPPORTED here; the two-launch folded form has it)
+  return d == k && (d == 16 || d == 32 || d == 64 || d == 128) && n_rel > 0 && n_rel <= kAttMaxRelLds &&
+         n_nodes <= (1ll << 28) && (unsigned long long)n_nodes * (unsigned long long)d * 4ull < (1ull << 32);
 }
 
 int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
@@ -539,8 +542,12 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   KGAT_CHECK_ARG((flags & ~KGAT_ATT_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_fused_supported(n_nodes, d, k, n_rel)) {
-    set_error("att_score_fused: needs d == k in {16,32,64}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
+    set_error("att_score_fused: needs d == k in {16,32,64,128}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
               kAttMaxRelLds, d, k, n_rel);
+    return KGAT_E_UNSUPPORTED;
+  }
+  if (d == 128 && (flags & KGAT_ATT_F32_PRODUCTS)) {
+    set_error("att_score_fused: d = 128 runs the bf16-piece products only (the folded form has KGAT_ATT_F32_PRODUCTS)");
     return KGAT_E_UNSUPPORTED;
   }
   KGAT_CHECK_ARG(n_nodes <= (1ll << 28), "att_score_fused: packed records hold node ids below 2^28");

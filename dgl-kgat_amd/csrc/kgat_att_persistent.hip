@@ -1412,6 +1412,333 @@ static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, cons
   return KGAT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused folded form at d = k = 128 (round 3): what att_fold_fused_kernel is at d <= 64, built on the
+// LDS-resident piece images of att_fold_head_lds_kernel<128, true>.  One 512-thread workgroup per
+// CU; per relation segment W_r's three bf16 piece images (96 KB) are cut into LDS; a wavefront takes
+// the tiles t + w, t + w + 8, ... of the workgroup's segment, computes the 16 V rows of a tile (two
+// chained piece products, 384 MFMAs), parks them in its own 16 x 128 LDS patch (8 KB; with the images
+// exactly the CU's 160 KB) and walks the tile's positions itself: 8 lanes per edge, tail row from
+// global memory (512 B), V row from the patch, lane l ends with position p0 + l, logits stored in
+// grouped order (coalesced).  No V table: the two-launch form wrote n_groups x 512 B and read it back
+// per edge (0.5 GB each way on the benchmark graph).  The register file is full during the MFMA phase,
+// so a chunk's rows (64 positions = 128 registers) are gathered after it, not ahead of it as at
+// d <= 64; the two waves of a SIMD run out of phase, one in its MFMA phase while the other waits for
+// rows.  e_r enters as the initial value of the first product's
+// accumulators (no registers or LDS for it).
+constexpr int kFused128Threads = 512;
+
+template <int OUT>
+__global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
+    int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
+    const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const int32_t* __restrict__ rec_g, const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g,
+    const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
+    float* __restrict__ logits, float* __restrict__ logits_csr, float* __restrict__ logits_g,
+    const int32_t* __restrict__ part_tptr) {
+  constexpr int D_ = 128, K_ = 128, KS = D_ / 4, KT = K_ / 16, NW = kFused128Threads / kWave;
+  constexpr int S3 = D_ / 32, ROWB = D_ * 2, IMG = D_ * ROWB;
+  constexpr int LPE = 8, VPL = D_ / (4 * LPE);
+#ifndef KGAT_F128_PASSES
+#define KGAT_F128_PASSES 1
+#endif
+  constexpr int NPASS = KGAT_F128_PASSES, HALF = LPE / NPASS;  // row-gather passes per 64-position chunk
+  constexpr bool LOGITS_EID = OUT == 2;
+  constexpr int ROW_SHIFT = 9;  // 512-byte rows
+  __shared__ __attribute__((aligned(16))) unsigned char s_img[3 * IMG];
+  __shared__ __attribute__((aligned(16))) float s_v[NW][16 * D_];
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave, w = tid / kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int li = lane % LPE;
+
+  {  // relation ids outside [0, R): logit 0
+    const int64_t n_scored = rel_ptr[n_rel];
+    for (int64_t p = n_scored + (int64_t)blockIdx.x * kFused128Threads + tid; p < n_edges;
+         p += (int64_t)gridDim.x * kFused128Threads) {
+      if (LOGITS_EID) logits[perm[p]] = 0.f;
+      if (OUT >= 1 && logits_csr) logits_csr[pos_g[p]] = 0.f;
+      if (logits_g) logits_g[p] = 0.f;
+    }
+  }
+  const int32_t n_tiles = rel_tptr[n_rel];
+  const int32_t t_begin = part_tptr ? part_tptr[blockIdx.x] : (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
+  const int32_t t_end = part_tptr ? part_tptr[blockIdx.x + 1]
+                                  : (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  float* vrow = s_v[w];
+
+  struct HBuf { float a[KS]; };
+  auto load_head = [&](HBuf& f, int32_t row) {
+    const char* base = reinterpret_cast<const char*>(ent);
+    const uint32_t o = (uint32_t)row * (uint32_t)(D_ * 4) + (uint32_t)(q * 16);
+#pragma unroll
+    for (int m = 0; m < D_ / 16; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(base + o + m * 64);
+      f.a[4 * m + 0] = v.x; f.a[4 * m + 1] = v.y; f.a[4 * m + 2] = v.z; f.a[4 * m + 3] = v.w;
+    }
+  };
+
+  int32_t t = t_begin;
+  while (t < t_end) {  // workgroup-uniform loop over relation segments
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rel_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int32_t rend = gptr[r + 1];
+    int32_t seg_end = rel_tptr[r + 1];
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    __syncthreads();  // every wave is done with the previous relation's images
+    {
+      const float* W = W_R + (size_t)r * D_ * K_;
+      int u0 = tid;
+      asm volatile("" : "+v"(u0));  // recompute the per-thread offsets per segment: hoisted out of the segment loop they were kept (spilled) across the whole tile loop
+      for (int u = u0; u < D_ * (K_ / 8); u += kFused128Threads) {
+        const int row = u / (K_ / 8), ch = u % (K_ / 8);
+        const float4 w0 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch);
+        const float4 w1 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch + 4);
+        const float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        uintx4 h, m, l;
+        split_bf16x3(x, h, m, l);
+        const int off = ROWB * row + 16 * (ch ^ (((row & 7) << 1) | ((row >> 3) & 1)));
+        *reinterpret_cast<uintx4*>(s_img + off) = h;
+        *reinterpret_cast<uintx4*>(s_img + IMG + off) = m;
+        *reinterpret_cast<uintx4*>(s_img + 2 * IMG + off) = l;
+      }
+    }
+    __syncthreads();
+    const float* relr = rel + (size_t)r * K_ + 4 * q;
+
+    auto desc_of = [&](int32_t n) -> int4 {  // wave-uniform: kept in scalar registers
+      n = n < seg_end ? n : seg_end - 1;
+      const int4 d = tiles[n];
+      return make_int4(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y),
+                       __builtin_amdgcn_readfirstlane(d.z), __builtin_amdgcn_readfirstlane(d.w));
+    };
+    auto head_idx = [&](const int4& d) -> int32_t {
+      int32_t g = d.y + i;
+      g = g < rend ? g : rend - 1;
+      return g_node[g];
+    };
+    struct CIdx { int32_t row_off, lg, oe, op; };
+    auto chunk_idx = [&](const int4& d, int32_t p0) -> CIdx {
+      int32_t p = p0 + lane;
+      p = p < d.w ? p : d.w - 1;
+      CIdx c;
+      const uint32_t rec = (uint32_t)rec_g[p];
+      c.row_off = (int32_t)(rec << ROW_SHIFT);
+      c.lg = (int32_t)(rec >> 28);
+      c.oe = LOGITS_EID ? perm[p] : 0;
+      c.op = (OUT >= 1 && logits_csr) ? pos_g[p] : 0;
+      return c;
+    };
+
+    // the two chained products of one tile: V rows of the tile's 16 groups -> the wave's LDS patch
+    auto mfma_phase = [&](const HBuf& f) {
+      floatx4 acc[KT];
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {  // e_r is where the accumulation starts: acc = e_r + e_h W_r
+        const float4 rv = *reinterpret_cast<const float4*>(relr + 16 * c);
+        acc[c] = (floatx4){rv.x, rv.y, rv.z, rv.w};
+      }
+      floatx4 v[KT];
+      {
+        typedef short shortx4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) shortx4 lds_shortx4;
+        const int qq = i >> 2, p = i & 3;
+        const int base1 = ROWB * (4 * q + qq) + 8 * (p & 1);
+        const int sw1 = ((4 * (q & 1) + qq) << 1) | (q >> 1);
+        auto frag1 = [&](int n, uintx4 (&ap)[3]) {
+          const int s = n / KT, c = n % KT;
+          const int o = base1 + 16 * ((2 * c + (p >> 1)) ^ sw1) + ROWB * 32 * s;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const shortx4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o));
+            const shortx4 hi4 =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o + ROWB * 16));
+            ap[pc] = __builtin_bit_cast(uintx4, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        };
+        auto pieces1 = [&](int s, uintx4 (&b)[3]) {
+          float x[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = f.a[8 * s + jj];
+          split_bf16x3(x, b[0], b[1], b[2]);
+        };
+        uintx4 fa[2][3], fb[2][3];
+        frag1(0, fa[0]);
+        pieces1(0, fb[0]);
+#pragma unroll
+        for (int n = 0; n < S3 * KT; ++n) {
+          const int s = n / KT, c = n % KT;
+          if (n + 1 < S3 * KT) frag1(n + 1, fa[(n + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c == KT - 1 && s + 1 < S3) pieces1(s + 1, fb[(s + 1) & 1]);
+          const uintx4(&ap)[3] = fa[n & 1];
+          const uintx4(&bp)[3] = fb[s & 1];
+          acc[c] = mfma_bf16(ap[2], bp[0], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[2], acc[c]);
+          acc[c] = mfma_bf16(ap[1], bp[1], acc[c]);
+          acc[c] = mfma_bf16(ap[1], bp[0], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[1], acc[c]);
+          acc[c] = mfma_bf16(ap[0], bp[0], acc[c]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(acc[c][j] * kTwoLog2e);
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int base2 = ROWB * i + 8 * (q & 1);
+        const int sw2 = ((i & 7) << 1) | (i >> 3);
+        auto frag2 = [&](int n, uintx4 (&ap)[3]) {
+          const int s = n / KT, c2 = n % KT;
+          const int o0 = base2 + 16 * (((4 * s) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
+          const int o1 = base2 + 16 * (((4 * s + 2) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const uintx2 l2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o0);
+            const uintx2 h2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o1);
+            ap[pc] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3);
+          }
+        };
+        auto pieces2 = [&](int s, uintx4 (&b)[3]) {
+          float x[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
+          split_bf16x3(x, b[0], b[1], b[2]);
+        };
+        uintx4 fa[2][3], fb[2][3];
+        frag2(0, fa[0]);
+        pieces2(0, fb[0]);
+#pragma unroll
+        for (int n = 0; n < S3 * KT; ++n) {
+          const int s = n / KT, c2 = n % KT;
+          if (n + 1 < S3 * KT) frag2(n + 1, fa[(n + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c2 == KT - 1 && s + 1 < S3) pieces2(s + 1, fb[(s + 1) & 1]);
+          const uintx4(&ap)[3] = fa[n & 1];
+          const uintx4(&bp)[3] = fb[s & 1];
+          v[c2] = mfma_bf16(ap[2], bp[0], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[2], v[c2]);
+          v[c2] = mfma_bf16(ap[1], bp[1], v[c2]);
+          v[c2] = mfma_bf16(ap[1], bp[0], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[1], v[c2]);
+          v[c2] = mfma_bf16(ap[0], bp[0], v[c2]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // v[c2][j] = V[group i][16c2 + 4q + j] -> the wave's patch, row = group slot; the 16-byte chunks
+      // of a row are swizzled by the slot's parity (chunk ^ 8) so that the edge phase's reads of two
+      // different slots by one 16-lane group fall into different bank halves
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tile's reads are done
+#pragma unroll
+      for (int c2 = 0; c2 < KT; ++c2) {
+        float4 o;
+        o.x = v[c2][0]; o.y = v[c2][1]; o.z = v[c2][2]; o.w = v[c2][3];
+        *reinterpret_cast<float4*>(vrow + i * D_ + 4 * ((4 * c2 + q) ^ ((i & 1) << 3))) = o;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+
+    // 64 positions starting at p0, their rows gathered in NPASS passes (1: all 8 steps of the 8-lane
+    // groups at once, 128 registers - free during the edge phase, the MFMA phase's are dead by then)
+    const char* eb = reinterpret_cast<const char*>(ent) + li * 16;
+    auto edge_chunk = [&](const CIdx& c, int32_t p0, int32_t pe) {
+      float mine = 0.f;
+#pragma unroll
+      for (int h = 0; h < NPASS; ++h) {
+        float4 rowv[HALF][VPL];
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) {
+          const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - li + h * HALF + s) << 2, c.row_off);
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) rowv[s][v] = *reinterpret_cast<const float4*>(eb + eo + v * (LPE * 16));
+        }
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) {
+          const int32_t lg = __builtin_amdgcn_ds_bpermute((lane - li + h * HALF + s) << 2, c.lg);
+          const float* vr = vrow + lg * D_;
+          const int sw = (lg & 1) << 3;
+          float d = 0.f;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            const float4 b = *reinterpret_cast<const float4*>(vr + 4 * ((li + LPE * v) ^ sw));
+            d = v == 0 ? rowv[s][v].x * b.x : fmaf(rowv[s][v].x, b.x, d);
+            d = fmaf(rowv[s][v].y, b.y, d);
+            d = fmaf(rowv[s][v].z, b.z, d);
+            d = fmaf(rowv[s][v].w, b.w, d);
+          }
+          d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+          d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+          d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
+          mine = li == h * HALF + s ? d : mine;
+        }
+      }
+      if (p0 + lane < pe) {
+        if (LOGITS_EID) logits[c.oe] = mine;
+        if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;
+        if (logits_g) logits_g[p0 + lane] = mine;
+      }
+    };
+
+    int32_t n = t + w;
+    if (n < seg_end) {
+      // One head-row buffer: the next tile's rows, descriptor and first-chunk records are requested right
+      // AFTER the current tile's MFMA phase (which is done with the buffer by then) and arrive during its
+      // edge phase; nothing is in flight across an MFMA phase, whose registers are all its own.
+      int4 d0 = desc_of(n), d1 = desc_of(n + NW);
+      HBuf hb;
+      load_head(hb, head_idx(d0));
+      int32_t h1 = head_idx(d1);
+      CIdx c0 = chunk_idx(d0, d0.z);
+      while (true) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(hb);
+        __builtin_amdgcn_sched_barrier(0);
+        const int4 d2 = desc_of(n + 2 * NW);
+        const CIdx c1 = chunk_idx(d1, d1.z);
+        load_head(hb, h1);
+        __builtin_amdgcn_sched_barrier(0);
+        edge_chunk(c0, d0.z, d0.w);
+        for (int32_t p0 = d0.z + kWave; p0 < d0.w; p0 += kWave) {
+          const CIdx cx = chunk_idx(d0, p0);
+          edge_chunk(cx, p0, d0.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h1 = head_idx(d2);
+        d0 = d1; d1 = d2;
+        c0 = c1;
+        n += NW;
+        if (n >= seg_end) break;
+      }
+    }
+    t = seg_end;
+  }
+}
+
+template <int OUT>
+static void launch_att_fold_fused128_form(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
+  hipLaunchKernelGGL((att_fold_fused128_kernel<OUT>), dim3(grid), dim3(kFused128Threads), 0, a.st, a.n_rel, a.n_edges,
+                     a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.rec_g, a.perm,
+                     a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr);
+}
+
+static int launch_att_fold_fused128(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  if (a.logits) launch_att_fold_fused128_form<2>(a, rel_tptr, tiles);
+  else if (a.logits_csr) launch_att_fold_fused128_form<1>(a, rel_tptr, tiles);
+  else launch_att_fold_fused128_form<0>(a, rel_tptr, tiles);
+  KGAT_CHECK_LAUNCH("att_fold_fused128");
+  return KGAT_OK;
+}
+
 #ifdef KGAT_ATT_STAMPS
 extern "C" int kgat_debug_set_att_stamps(void* dev_ptr) {
   return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
@@ -1426,6 +1753,7 @@ int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, 
     case 16: return launch_att_fold_fused<16>(a, rel_tptr, tiles);
     case 32: return launch_att_fold_fused<32>(a, rel_tptr, tiles);
     case 64: return launch_att_fold_fused<64>(a, rel_tptr, tiles);
+    case 128: return a.f32_products ? KGAT_E_UNSUPPORTED : launch_att_fold_fused128(a, rel_tptr, tiles);
     default: return KGAT_E_UNSUPPORTED;
   }
 }

@@ -248,16 +248,26 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
   float* px = s_patch[wv];
   int32_t* pr = reinterpret_cast<int32_t*>(s_patch[wv]);
-  // striped, coalesced loads; positions past `end` repeat the last row with a huge negative logit
+  // striped, coalesced loads; positions past `end` repeat the last row with a huge negative logit.
+  // Branch-free (clamped positions instead of predicated loads): all row ids and input indices are
+  // requested together, then all logits - with a load under a condition per position the compiler
+  // waited for every index before it issued the dependent gather, sixteen serial round trips per
+  // wavefront on the indexed input path (round 3: that path now carries the grouped-order logits).
   const int32_t r_last = row_of[end - 1];
-  int32_t rs[kSmEPL];
+  int32_t rs[kSmEPL], gi[kSmEPL];
   float xs[kSmEPL];
 #pragma unroll
   for (int j = 0; j < kSmEPL; ++j) {
     const int64_t p = base + j * kWave + lane;
-    const bool valid = p < end;
-    rs[j] = valid ? row_of[p] : r_last;
-    xs[j] = valid ? (IN_CSR ? logits[p] : logits[eid[p]]) : kSmNegBig;
+    const int64_t pc = p < end ? p : end - 1;
+    rs[j] = row_of[pc];  // (= r_last past the end)
+    gi[j] = IN_CSR ? (int32_t)(pc - e0) : eid[pc];
+  }
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int64_t p = base + j * kWave + lane;
+    const float x = IN_CSR ? logits[p < end ? p : end - 1] : logits[gi[j]];
+    xs[j] = p < end ? x : kSmNegBig;
   }
   // neighbours of the range (is the first / last row cut?) and the extent of the two rows at its ends
   const int32_t r_first = row_of[base];
@@ -442,10 +452,15 @@ __device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float
     int64_t e[U];
     float x[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {  // all indices first, then all logits (see softmax_local_kernel)
       const int64_t p = p0 + u * kWave + lane;
       const int64_t pc = p < hi ? p : hi - 1;
       e[u] = eid ? eid[pc] : pc;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = p0 + u * kWave + lane;
+      const int64_t pc = p < hi ? p : hi - 1;
       x[u] = IN_CSR ? logits[pc] : logits[e[u]];
     }
 #pragma unroll

@@ -578,7 +578,7 @@ class DGLGraph:
         (opt-in: a wall-clock race is not reproducible across processes)."""
         st = self._st
         shares = 4 * groups.n_groups <= 3 * st.n_edges
-        fused_ok = shares and ops.att_score_fused_supported(st.n_nodes, d, k, n_rel)
+        fused_ok = shares and ops.att_score_fused_supported(st.n_nodes, d, k, n_rel) and not (d == 128 and _f32_products())
         folded_ok = shares and ops.att_score_folded_supported(st.n_nodes, d, k, n_rel)
         if fused_ok and folded_ok:
             if race_run is not None:

@@ -254,10 +254,17 @@ FOLD_TILE_CAP = 256
 # products 1,459 / 267 / 10,630.  Both in units of a 64th of a tile.
 FOLD_TILE_COST = (64, 38, 1051)
 FOLD_TILE_COST_F32 = (64, 12, 466)
+# d = 128 (att_fold_fused128_kernel): a tile's two products are ~4.5 x the d = 64 tile's, a later chunk
+# moves twice the bytes, a relation change cuts four times the matrix.  Scanned on the amazon-book-shaped
+# CKG (scripts/micro/att_variants_ab.py): (64,20,600) 0.440 ms, (64,12,700) 0.421, (64,12,1200) 0.430,
+# (64,8,900) 0.450, (64,6,400) 0.466.
+FOLD_TILE_COST_128 = (64, 12, 700)
 
 
 def fold_tile_cost(d, f32_products=False):
     """The split cost that goes with the product form att_score_fused takes at width d."""
+    if d == 128:
+        return FOLD_TILE_COST_128
     return FOLD_TILE_COST if (d % 32 == 0 and not f32_products) else FOLD_TILE_COST_F32
 
 

@@ -179,7 +179,9 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
  * A wavefront computes a tile's V rows (as kgat_att_score_folded_f32), keeps them in LDS and
  * takes the dot products of the tile's positions itself.  Same logits as the folded form up to
  * the summation order of the d-length dot product (fp32 rounding).  cap: a positive multiple of
- * 64 (128 is the default of the host code).  Needs d == k in {16,32,64}. */
+ * 64 (256 is the default of the host code).  Needs d == k in {16,32,64,128}; at d = k = 128 (one
+ * 512-thread workgroup per CU holding W_r's three bf16 piece images, 96 KB, and a 16 x 128 V patch
+ * per wave in LDS) only the bf16-piece products exist. */
 int64_t kgat_fold_tiles_max(int64_t n_edges, int64_t n_groups, int n_rel, int cap);
 size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel);
 int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,

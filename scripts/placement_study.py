@@ -148,7 +148,8 @@ def cmd_report(args):
         for r in rows:
             if "spmm_merge2_kernel" not in r[name_key]:
                 continue
-            per_disp.setdefault(int(r[disp_key]), {})[r[cnt_key]] = float(r[val_key])
+            # a counter asked for without _sum comes as one row per hardware instance (TCC channel, ...)
+            per_disp.setdefault(int(r[disp_key]), {}).setdefault(r[cnt_key], []).append(float(r[val_key]))
         order = sorted(per_disp)
         labels = side["labels"]
         print("%s: %d spmm_merge2 dispatches, %d labels, both modes: %s, ms fast %.3f slow %.3f" % (
@@ -163,8 +164,14 @@ def cmd_report(args):
             for c, v in per_disp[disp].items():
                 agg.setdefault(c, {"fast": [], "slow": []})[lab].append(v)
         for c, v in sorted(agg.items()):
-            f, s = np.mean(v["fast"]), np.mean(v["slow"])
-            print("  %-44s fast %.6g  slow %.6g  slow/fast %.3f" % (c, f, s, s / f if f else float("nan")))
+            f, s = np.mean([np.sum(x) for x in v["fast"]]), np.mean([np.sum(x) for x in v["slow"]])
+            line = "  %-44s fast %.6g  slow %.6g  slow/fast %.3f" % (c, f, s, s / f if f else float("nan"))
+            n_inst = len(v["fast"][0])
+            if n_inst > 1:   # spread over the instances: max / mean per dispatch, averaged
+                def spread(xs):
+                    return float(np.mean([np.max(x) / max(np.mean(x), 1e-30) for x in xs]))
+                line += "  | %d instances: max/mean fast %.3f slow %.3f" % (n_inst, spread(v["fast"]), spread(v["slow"]))
+            print(line)
 
 
 def main():

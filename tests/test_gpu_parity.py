@@ -522,6 +522,13 @@ def test_att_fused_product_forms(K, dev, d):
                                           tf(W, dev), tf(rel, dev), want_csr=False, folded=True, f32_products=f32p)[0]
             got[f32p] = out.cpu().numpy()
             assert np.isfinite(got[f32p]).all()
+        if d == 128:   # the fused one-launch form at d = 128 has the piece products only: same bar
+            out = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                      tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False, part_tptr=part_tptr)[0]
+            fused128 = out.cpu().numpy()
+            assert np.isfinite(fused128).all()
+            assert np.abs(fused128 - ref).max() <= max(2.0 * np.abs(got[True] - ref).max(),
+                                                       2e-7 * max(float(np.abs(ref).max()), 1e-30)), case
         scale = max(float(np.abs(ref).max()), 1e-30)
         e_new, e_f32 = np.abs(got[False] - ref).max(), np.abs(got[True] - ref).max()
         print("[att products d=%d %-12s] max|err|/max|ref|: bf16 pieces %.3e  fp32 products %.3e ; 8c %.3e  %.3e"
@@ -561,6 +568,23 @@ def test_att_folded_d128(K, dev):
     assert torch.equal(fold_csr, fold[eid.long()])
     full, _ = ops.att_score(n, rel_ptr, perm, src_g, dst_g, tf(ent, dev), tf(W, dev), tf(rel, dev), pos_g=pos_g)
     assert rel_err_inf(fold.cpu().numpy(), full.cpu().numpy()) < 1e-5
+    # the one-launch fused form at d = 128 (round 3): same V rows, the per-edge dot split over 8 lanes
+    # as in the two-launch form's tail kernel; every output order, any split of the tiles, small caps
+    assert ops.att_score_fused_supported(n, d, d, R)
+    for cap, n_parts in ((64, 5), (256, 37)):
+        tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=n_parts,
+                                                    cost=ops.fold_tile_cost(d))
+        fe, fc, fg = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
+                                         tf(ent, dev), tf(W, dev), tf(rel, dev), part_tptr=part_tptr, want_grouped=True)
+        assert rel_err_inf(fe.cpu().numpy(), ref) < 1e-5 and rel_err_inf(fe.cpu().numpy(), fold.cpu().numpy()) < 2e-6
+        assert np.all(fe.cpu().numpy()[(et < 0) | (et >= R)] == 0)
+        assert torch.equal(fc, fe[eid.long()]) and torch.equal(fg, fc[pos_g.long()])
+        only_g = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, tf(ent, dev),
+                                     tf(W, dev), tf(rel, dev), want_eid=False, want_csr=False, want_grouped=True)[2]
+        assert torch.equal(only_g, fg)   # equal tile counts per workgroup instead of the cost split: same bits
+    with pytest.raises(Exception, match="bf16-piece products only"):
+        ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, tf(ent, dev), tf(W, dev),
+                            tf(rel, dev), f32_products=True)
 
 
 @pytest.mark.parametrize("d,k", [(8, 8), (16, 32), (32, 8), (8, 5), (16, 17)])
