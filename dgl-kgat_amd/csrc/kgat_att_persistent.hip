@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
   constexpr int S3 = D_ / 32, ROWB = D_ * 2, IMG = D_ * ROWB;
   constexpr int LPE = 8, VPL = D_ / (4 * LPE);
 #ifndef KGAT_F128_PASSES
-#define KGAT_F128_PASSES 1
+#define KGAT_F128_PASSES 2
 #endif
   constexpr int NPASS = KGAT_F128_PASSES, HALF = LPE / NPASS;  // row-gather passes per 64-position chunk
   constexpr bool LOGITS_EID = OUT == 2;
