@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
 // stream and twice the wavefronts with half the chain each finish sooner (amazon-book graph: sweep
 // 22 -> 17 us, cut rows 13 -> 12 us; 4 per lane was slower again: 36 us for both)
 constexpr int kSmMaxEPL = 16;
-constexpr int64_t kSmSmallEdges = 8 << 20;
+#ifndef KGAT_SM_SMALL_EDGES
+#define KGAT_SM_SMALL_EDGES (8 << 20)
+#endif
+constexpr int64_t kSmSmallEdges = KGAT_SM_SMALL_EDGES;  // (a macro for A/B builds: scripts/micro/softmax_ab.py)
 template <int EPL> struct SmGeom {
   static constexpr int EPW = kWave * EPL;   // positions per wavefront
   static constexpr int Pad = EPL + 4;       // floats per lane in the LDS patch (conflict-free b128 for 8 and 16)
@@ -216,13 +219,15 @@ __device__ __forceinline__ float sm_exp(float x) {
   return __builtin_amdgcn_exp2f(t) * fmaf(lo, 0.693147180559945309f, 1.0f);
 }
 
+// (m, s) <- (m, s) (+) (m2, s2): the smaller maximum's sum is rescaled by exp(-|m - m2|).  Branch-free
+// (one exp, selects): the scans below call it in every lane at every step, and a divergent if / else
+// cost two exec-mask switches and both exp paths per call.  Same arithmetic as the branchy form.
 __device__ __forceinline__ void sm_combine(float& m, float& s, float m2, float s2) {
-  if (m >= m2) {
-    s = fmaf(s2, sm_exp(m2 - m), s);
-  } else {
-    s = fmaf(s, sm_exp(m - m2), s2);
-    m = m2;
-  }
+  const bool keep = m >= m2;
+  const float e = sm_exp(keep ? m2 - m : m - m2);
+  const float big = keep ? s : s2, small = keep ? s2 : s;
+  s = fmaf(small, e, big);
+  m = keep ? m : m2;
 }
 
 __device__ __forceinline__ int64_t sm_wave_index() {
@@ -330,23 +335,22 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
     for (int d = 1; d < kWave; d <<= 1) {
       const float m2 = __shfl_up(im, d, kWave), s2 = __shfl_up(is, d, kWave);
       const int f2 = __shfl_up(stop, d, kWave);
-      if (lane >= d && !stop) {
-        float cm = m2, cs = s2;
-        sm_combine(cm, cs, im, is);
-        im = cm; is = cs;
-        stop = f2;
-      }
+      const bool act = lane >= d && !stop;  // (selects, not a branch: every lane runs the combine)
+      float cm = m2, cs = s2;
+      sm_combine(cm, cs, im, is);
+      im = act ? cm : im;
+      is = act ? cs : is;
+      stop = act ? f2 : stop;
     }
   }
   // the row that is the lane's FIRST run: finished total if it ends in this lane
   float fm = M[0], fs = S[0];
   {
     const float pm = __shfl_up(im, 1, kWave), ps = __shfl_up(is, 1, kWave);
-    if (multi && link) {
-      float cm = pm, cs = ps;
-      sm_combine(cm, cs, fm, fs);
-      fm = cm; fs = cs;
-    }
+    float cm = pm, cs = ps;
+    sm_combine(cm, cs, fm, fs);
+    fm = (multi && link) ? cm : fm;
+    fs = (multi && link) ? cs : fs;
   }
   // E = finished total of the row that is the lane's first run (copy scan from the lane where it ends)
   float em = multi ? fm : im, es = multi ? fs : is;
@@ -356,10 +360,10 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
     for (int d = 1; d < kWave; d <<= 1) {
       const float m2 = __shfl_down(em, d, kWave), s2 = __shfl_down(es, d, kWave);
       const int f2 = __shfl_down(stop, d, kWave);
-      if (lane + d < kWave && !stop) {
-        em = m2; es = s2;
-        stop = f2;
-      }
+      const bool act = lane + d < kWave && !stop;
+      em = act ? m2 : em;
+      es = act ? s2 : es;
+      stop = act ? f2 : stop;
     }
   }
   const float nm = __shfl_down(em, 1, kWave), ns = __shfl_down(es, 1, kWave);
@@ -393,7 +397,8 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
 #pragma unroll
   for (int i = 0; i < kSmEPL; ++i) {
     const bool first = r[i] == key_f, last = r[i] == key_l;
-    x[i] = (first || last) ? x[i] * (first ? scale_f : scale_l) : x[i] / S[i];
+    // (hardware reciprocal, 1 ulp: two instructions per position where the IEEE division took ten)
+    x[i] = x[i] * ((first || last) ? (first ? scale_f : scale_l) : __builtin_amdgcn_rcpf(S[i]));
   }
   sm_wave_sync();
 #pragma unroll
@@ -405,17 +410,198 @@ __global__ __launch_bounds__(256) void softmax_local_kernel(
   sm_wave_sync();
   const int64_t skip_lo = cut_start ? base + c0 : base;     // [base, skip_lo) belongs to the cut first row
   const int64_t skip_hi = cut_end ? end - cl : end;         // [skip_hi, end) belongs to the cut last row
+  float av[kSmEPL];
 #pragma unroll
   for (int j = 0; j < kSmEPL; ++j) {
-    const int64_t p = base + j * kWave + lane;
     const int idx = j * kWave + lane;
-    const float a = px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)];
-    if (p >= skip_lo && p < skip_hi) {
-      if (out_csr) out_csr[p] = a;
-      if (out) out[eid ? eid[p] : p] = a;
+    av[j] = px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)];
+  }
+  if (out_csr) {  // (the wave-uniform tests outside the per-position loops)
+#pragma unroll
+    for (int j = 0; j < kSmEPL; ++j) {
+      const int64_t p = base + j * kWave + lane;
+      if (p >= skip_lo && p < skip_hi) out_csr[p] = av[j];
+    }
+  }
+  if (out) {
+#pragma unroll
+    for (int j = 0; j < kSmEPL; ++j) {
+      const int64_t p = base + j * kWave + lane;
+      if (p >= skip_lo && p < skip_hi) out[eid ? eid[p] : p] = av[j];
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Round 3 experiment, NOT the shipped sweep (built only with -DKGAT_SOFTMAX_SLOTS; kept as the record of
+// a negative result and as a third implementation for cross-checks): the sweep without scans.  The scan
+// form above spends ~1,500 instructions per wavefront (two LDS transposes, lane-local run loops,
+// thirteen cross-lane scan steps with an exp each) and is bound by instruction issue, not by memory:
+// 7 waves per SIMD x 1,500 instructions ~ 25 us.  This form has ~1,150 instructions and no scans - and
+// is slower: 48.6 us against 32.4 us stand-alone on the amazon-book graph (51.6 against 35.0 in the
+// step).  Its twenty LDS atomics per wavefront mostly hit a handful of addresses (a row is ~23
+// consecutive positions, striped over neighbouring lanes), and the LDS serialises same-address
+// read-modify-writes lane by lane: with 28 resident wavefronts per CU the LDS pipe, not the issue
+// port, becomes the bound.  What it does:
+// a wavefront keeps one LDS slot per destination row of its range (row - first row; at most one
+// row per position) and lets the LDS do the reductions:
+//   1. striped coalesced loads (no transpose), ds_max_f32 of every logit into its row's slot;
+//   2. e = exp(x - slot max), added into the slot in 2^-40 fixed point with ds_add_u64 - integer
+//      adds are associative, so the sum does not depend on the order the LDS serialises the lanes
+//      in: bitwise reproducible by construction (the 3-pass form does the same in global memory);
+//   3. one reciprocal per slot; 4. a = e * slot scale, coalesced stores.
+// ~350 instructions per wavefront.  Rows cut by the range boundaries: every wavefront also reads a
+// halo of 64 positions on either side into two extra accumulators.  A cut row that lies entirely
+// inside range + halo is finished here (own positions normalised with the merged statistics); its
+// carry entry is still written - a neighbour may need it for a row it cannot finish - with pad0 = 1,
+// which tells softmax_cut_rows_kernel to skip it.  Only rows reaching further out (hubs) are left to
+// the second launch, whose wavefronts otherwise return after reading their two entries.
+constexpr int kSmHalo = 64;
+constexpr float kSmFix = 1099511627776.0f;         // 2^40
+constexpr float kSmFixInv = 1.0f / 1099511627776.0f;
+
+#ifdef KGAT_SOFTMAX_SLOTS
+template <bool IN_CSR, int kSmEPL>
+__global__ __launch_bounds__(256) void softmax_slots_kernel(
+    int64_t e0, int64_t e1, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
+    const int32_t* __restrict__ eid, const float* __restrict__ logits, float* __restrict__ out,
+    float* __restrict__ out_csr, SmCarry* __restrict__ carry) {
+  constexpr int EPW = kWave * kSmEPL, NS = EPW + 3;  // slots: rows of the range, halo before, halo after, discard
+  __shared__ float s_m[256 / kWave][NS];
+  __shared__ unsigned long long s_s[256 / kWave][NS];
+  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  const int64_t w = sm_wave_index();
+  const int64_t base = e0 + w * EPW;
+  if (base >= e1) return;
+  const int64_t end = base + EPW < e1 ? base + EPW : e1;
+  float* pm = s_m[wv];
+  unsigned long long* ps = s_s[wv];
+  // ---- loads: row ids and input indices of the own positions and of the two halos, then the logits
+  const int32_t R0 = row_of[base], RL = row_of[end - 1];
+  int32_t slot[kSmEPL], gi[kSmEPL];
+  float x[kSmEPL];
+  const int64_t pb = base - 1 - lane, pa = end + lane;
+  const bool hb = pb >= e0, ha = pa < e1;
+  const int64_t pbc = hb ? pb : base, pac = ha ? pa : end - 1;
+  const int32_t rb = row_of[pbc], ra = row_of[pac];
+  const int32_t gb = IN_CSR ? 0 : eid[pbc], ga = IN_CSR ? 0 : eid[pac];
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {  // (clamped positions, unconditional loads: nothing here may sit under a branch)
+    const int64_t p = base + j * kWave + lane;
+    const int64_t pc = p < end ? p : end - 1;
+    slot[j] = row_of[pc];
+    gi[j] = IN_CSR ? 0 : eid[pc];
+  }
+  const int64_t first_beg = indptr[R0], first_end = indptr[R0 + 1];
+  const int64_t last_beg = indptr[RL], last_end = indptr[RL + 1];
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int64_t p = base + j * kWave + lane;
+    x[j] = IN_CSR ? logits[p < end ? p : end - 1] : logits[gi[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j)  // positions past the end go to the discard slot: no branches in the reductions
+    slot[j] = base + j * kWave + lane < end ? slot[j] - R0 : EPW + 2;
+  const float xb = IN_CSR ? logits[pbc] : logits[gb], xa = IN_CSR ? logits[pac] : logits[ga];
+  for (int k = lane; k < NS; k += kWave) {
+    pm[k] = kSmNegBig;
+    ps[k] = 0ull;
+  }
+  sm_wave_sync();
+  // ---- 1. row maxima
+  const int sb = (hb && rb == R0) ? EPW : EPW + 2, sa = (ha && ra == RL) ? EPW + 1 : EPW + 2;
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j)
+    __hip_atomic_fetch_max(&pm[slot[j]], x[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_max(&pm[sb], xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_max(&pm[sa], xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  sm_wave_sync();
+  // ---- 2. exp(x - row max) and the row sums, in 2^-40 fixed point (exact integer adds)
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    x[j] = sm_exp(x[j] - pm[slot[j]]);
+    __hip_atomic_fetch_add(&ps[slot[j]], (unsigned long long)(x[j] * kSmFix), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __hip_atomic_fetch_add(&ps[sb], (unsigned long long)(sm_exp(xb - pm[sb]) * kSmFix), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_add(&ps[sa], (unsigned long long)(sm_exp(xa - pm[sa]) * kSmFix), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+  sm_wave_sync();
+  // ---- 3. the rows cut by the range (lane 0; statistics read before the slots turn into scales)
+  const int64_t fb = first_beg > e0 ? first_beg : e0, fe = first_end < e1 ? first_end : e1;
+  const int64_t lb = last_beg > e0 ? last_beg : e0, le = last_end < e1 ? last_end : e1;
+  const bool cut_start = fb < base, cut_end = le > end;
+  const int c0 = (int)((fe < end ? fe : end) - base);
+  const int cl = (int)(end - (lb > base ? lb : base));
+  const int sl = RL - R0;
+  // can this wavefront see the whole row?  (first row: starts inside the halo before; if it is also the
+  // last row and continues, it must end inside the halo after)
+  const bool whole0 = fb >= base - kSmHalo && fe <= end + kSmHalo;
+  const bool wholeL = lb >= base - kSmHalo && le <= end + kSmHalo;
+  float sc0 = 0.f, scL = 0.f;  // scales of the first / last row's own positions when finished here
+  if (lane == 0) {
+    const float m0 = pm[0], s0 = (float)ps[0] * kSmFixInv;
+    const float mL = pm[sl], sL = (float)ps[sl] * kSmFixInv;
+    const float mB = pm[EPW], sB = (float)ps[EPW] * kSmFixInv;
+    const float mA = pm[EPW + 1], sA = (float)ps[EPW + 1] * kSmFixInv;
+    SmCarry a, b;
+    a.row = b.row = -1;
+    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f;
+    a.head = b.head = a.last = b.last = 0; a.pad0 = a.pad1 = b.pad0 = b.pad1 = 0;
+    if (cut_start) {  // a follower entry of the first row's chain (the row may also fill the whole range)
+      a.row = R0; a.count = c0; a.m = m0; a.s = s0;
+      a.head = (int32_t)((fb - e0) / EPW); a.last = (int32_t)((fe - 1 - e0) / EPW);
+      a.pad0 = whole0 ? 1 : 0;
+    }
+    if (cut_end && !(cut_start && R0 == RL)) {  // the head entry of the last row's chain
+      b.row = RL; b.count = cl; b.m = mL; b.s = sL;
+      b.head = (int32_t)((lb - e0) / EPW); b.last = (int32_t)((le - 1 - e0) / EPW);
+      b.pad0 = wholeL ? 1 : 0;
+    }
+    carry[2 * w] = a;
+    carry[2 * w + 1] = b;
+    if ((cut_start || (cut_end && R0 == RL)) && whole0) {  // first row: own positions + halo before (+ halo after)
+      float M = m0, S = s0;
+      if (fb < base) sm_combine(M, S, mB, sB);
+      if (R0 == RL && fe > end) sm_combine(M, S, mA, sA);
+      sc0 = sm_exp(m0 - M) / S;
+    }
+    if (cut_end && R0 != RL && wholeL) {  // last row: own positions + halo after
+      float M = mL, S = sL;
+      sm_combine(M, S, mA, sA);
+      scL = sm_exp(mL - M) / S;
+    }
+  }
+  sc0 = __shfl(sc0, 0, kWave);
+  scL = __shfl(scL, 0, kWave);
+  sm_wave_sync();
+  // slot -> scale (1 / row sum), in place of the maxima
+  for (int k = lane; k < EPW; k += kWave) {
+    const float S = (float)ps[k] * kSmFixInv;
+    pm[k] = S > 0.f ? 1.0f / S : 0.f;
+  }
+  sm_wave_sync();
+  // ---- 4. normalise and store; positions of cut rows that were not finished here are left to the
+  // second launch
+  const bool cut0 = cut_start || (cut_end && R0 == RL), cutL = cut_end && R0 != RL;
+  const bool skip0 = cut0 && !whole0, skipL = cutL && !wholeL;
+#pragma unroll
+  for (int j = 0; j < kSmEPL; ++j) {
+    const int64_t p = base + j * kWave + lane;
+    if (p >= end) continue;
+    const bool in0 = slot[j] == 0, inL = slot[j] == sl;
+    if ((in0 && skip0) || (inL && skipL)) continue;
+    float scale = pm[slot[j]];
+    if (in0 && cut0) scale = sc0;
+    if (inL && cutL) scale = scL;
+    const float a = x[j] * scale;
+    if (out_csr) out_csr[p] = a;
+    if (out) out[eid ? eid[p] : p] = a;
+  }
+}
+
+#endif  // KGAT_SOFTMAX_SLOTS
 
 // (M, S) of a cut row from the carries of its chain: the head wavefront's `b` entry, then the `a`
 // entries of the followers head+1 .. last in blocks of 64 (ordered tree inside a block).  Every
@@ -492,7 +678,7 @@ __global__ __launch_bounds__(256) void softmax_cut_rows_kernel(
   const int64_t pb = end - 1 - lane >= base ? end - 1 - lane : base;
   const int64_t ea = eid ? eid[pa] : pa, eb = eid ? eid[pb] : pb;
   const float xa = IN_CSR ? logits[pa] : logits[ea], xb = IN_CSR ? logits[pb] : logits[eb];
-  if (ca.row >= 0) {
+  if (ca.row >= 0 && !ca.pad0) {  // (pad0: the sweep saw the whole row through its halo and finished its own positions)
     float M, S;
     sm_chain_total(carry, ca.head, ca.last, lane, M, S);
     if (lane < ca.count) {
@@ -502,7 +688,7 @@ __global__ __launch_bounds__(256) void softmax_cut_rows_kernel(
     }
     fix_span<IN_CSR>(base + kWave, base + ca.count, lane, M, S, eid, logits, out, out_csr);
   }
-  if (cb.row >= 0) {
+  if (cb.row >= 0 && !cb.pad0) {
     float M, S;
     sm_chain_total(carry, cb.head, cb.last, lane, M, S);
     if (lane < cb.count) {
@@ -552,8 +738,13 @@ static void launch_softmax_sweep(int64_t e_begin, int64_t e_end, const int32_t* 
                                  hipStream_t st) {
   const int64_t n_waves = (e_end - e_begin + SmGeom<EPL>::EPW - 1) / SmGeom<EPL>::EPW;
   const unsigned blocks = (unsigned)((n_waves + 3) / 4);
+#ifdef KGAT_SOFTMAX_SLOTS  // A/B builds: the LDS-atomic sweep (slower, see softmax_slots_kernel)
+  hipLaunchKernelGGL((softmax_slots_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
+                     eid, logits, out, out_csr, carry);
+#else
   hipLaunchKernelGGL((softmax_local_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
                      eid, logits, out, out_csr, carry);
+#endif
   hipLaunchKernelGGL((softmax_cut_rows_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
                      out, out_csr, (const SmCarry*)carry);
 }

@@ -249,14 +249,17 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
 FOLD_TILE_CAP = 256
 # per-tile cost model of the fused kernel (kgat_fold_tile_parts; from per-workgroup clock stamps,
 # scripts/micro/att_stamps.py): a tile, a chunk of 64 positions past the first 64, a relation
-# change inside a workgroup's range.  With the bf16-piece products (d % 32 == 0) the round-2 fit was
-# 649 ticks of workgroup time per tile, 389 per later chunk, 10,661 per relation change (64 : 38 :
-# 1051); with the fp32 products 1,459 / 267 / 10,630.  Both in units of a 64th of a tile.  Round 3
-# (one packed index per position, coalesced logit stores: later chunks and the restart after a
-# relation change got cheaper) re-scanned the triple on both benchmark shapes
-# (scripts/micro/att_variants_ab.py): amazon-book 0.1510 ms at (64,38,1051), 0.1455 at (64,30,1051),
-# 0.1453 at (64,24,800), 0.1505 at (64,20,1051); last-fm 0.1319 -> 0.1224.
-FOLD_TILE_COST = (64, 24, 800)
+# change inside a workgroup's range.  With the bf16-piece products (d % 32 == 0) the fit is 649
+# ticks of workgroup time per tile, 389 per later chunk, 10,661 per relation change; with the fp32
+# products 1,459 / 267 / 10,630.  Both in units of a 64th of a tile.  Round 3 re-scanned the triple
+# for the kernel with packed records and coalesced stores.  Stand-alone launches (variants
+# alternating, every launch with another tile split: scripts/micro/att_variants_ab.py) preferred
+# cheaper chunks - (64,24,800) 0.145 ms against 0.151 - but INSIDE the step, where the launch starts
+# with the table and the index arrays partly evicted, the order is the opposite (KGAT_FOLD_TILE_COST
+# A/B of bench.py on one box: (64,38,1051) 142.5-144.0 us, (64,30,1051) 145.2-146.4, (64,30,800)
+# 146.4-146.5, (64,24,800) 154.1-154.6): later chunks, whose rows are not requested ahead, cost
+# more there.  The step is what counts: the fitted triple stays.
+FOLD_TILE_COST = (64, 38, 1051)
 FOLD_TILE_COST_F32 = (64, 12, 466)
 # d = 128 (att_fold_fused128_kernel): a tile's two products are ~4.5 x the d = 64 tile's, a later chunk
 # moves twice the bytes, a relation change cuts four times the matrix.  Scanned on the amazon-book-shaped
@@ -266,7 +269,12 @@ FOLD_TILE_COST_128 = (64, 12, 700)
 
 
 def fold_tile_cost(d, f32_products=False):
-    """The split cost that goes with the product form att_score_fused takes at width d."""
+    """The split cost that goes with the product form att_score_fused takes at width d
+    (``KGAT_FOLD_TILE_COST="tile,chunk,relation"`` overrides it: A/B runs of the whole step)."""
+    import os
+    env = os.environ.get("KGAT_FOLD_TILE_COST")
+    if env:
+        return tuple(int(x) for x in env.split(","))
     if d == 128:
         return FOLD_TILE_COST_128
     return FOLD_TILE_COST if (d % 32 == 0 and not f32_products) else FOLD_TILE_COST_F32

@@ -107,6 +107,24 @@ def parity_8c(name, gpu, c32, ref64, tol=1e-4, factor=2.0):
     return e_gpu, e_c
 
 
+def err_8c(x, y):
+    """The elementwise quantity whose maximum is `rel_err`: |x - y| / max(|y|, 1e-3 * max|y|)."""
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    return np.abs(x - y) / np.maximum(np.abs(y), 1e-3 * max(np.abs(y).max(), 1e-30))
+
+
+def parity_8c_mean(name, gpu, c32, ref64, factor=1.25, floor=1e-7):
+    """The MEAN of the 8c metric, device vs CPU fp32 run.  The maximum (`parity_8c`) sits on one element of
+    the row with the smallest norm and moves by tens of percent with any change of summation order on
+    either machine (scripts/error_attribution.py); the mean over 10^6-10^7 elements does not, so it
+    is the statistic a factor close to 1 can be asked of."""
+    e_gpu, e_c = float(err_8c(gpu, ref64).mean()), float(err_8c(c32, ref64).mean())
+    print("[8c mean] %-30s gpu %.3e   c-fp32 %.3e   (bar max(%.0e, %gx c-fp32))" % (name, e_gpu, e_c, floor, factor))
+    assert e_gpu <= max(floor, factor * e_c), (name, e_gpu, e_c)
+    return e_gpu, e_c
+
+
 def blocks(x, widths):
     """Column blocks of a Model.gnn output [h0 | n(h1) | n(h2) | ...]."""
     out, o = [], 0

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import blocks, parity_8c, rel_err, rel_err_inf
+from conftest import blocks, parity_8c, parity_8c_mean, rel_err, rel_err_inf
 from oracle import c_oracle as co
 from oracle import kgat_oracle as orc
 
@@ -74,7 +74,9 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
     a_h, out_h = a.cpu().numpy().reshape(-1), out.cpu().numpy()
     assert a_h.shape == a_64.shape and out_h.shape == out_64.shape
     # Bars (round-2 review: hold the device to what it achieves, not to twice the CPU fp32 run):
-    #  * the 8c elementwise metric: 1e-4, or no further from fp64 than the CPU fp32 forward (factor 1);
+    #  * the 8c elementwise metric: its maximum under 1e-4 or within 1.5 x of the CPU fp32 forward's (the
+    #    maximum is one element of the smallest-norm row: on configs[0] the device has measured 0.94 x and
+    #    1.09 x the CPU run's depending on the softmax's summation order), its MEAN within 1.25 x;
     #  * every tensor at its own scale (max|x - y| / max|y|): 1e-5 - the "<= 1e-4 relative fp32" of the
     #    north star with a decade to spare - or, for a normalised readout block whose small-norm rows
     #    amplify any fp32 forward (configs[0]: width 8, one layer: 1.9e-5 on the device, C fp32 alike),
@@ -86,7 +88,8 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
     assert rel_err_inf(a_h, a_64) <= 1e-5
     widths = [d] + [model.layers[i].res_fc_2.out_features for i in range(layers)]
     for bi, (x, c, y) in enumerate(zip(blocks(out_h, widths), blocks(out_c, widths), blocks(out_64, widths))):
-        parity_8c("%s readout block %d" % (tag, bi), x, c, y, factor=1.0)
+        parity_8c("%s readout block %d" % (tag, bi), x, c, y, factor=1.5)
+        parity_8c_mean("%s readout block %d" % (tag, bi), x, c, y)
         e_inf, c_inf = rel_err_inf(x, y), rel_err_inf(c, y)
         print("[scale] %s readout block %d gpu %.3e  c-fp32 %.3e (max|x-y| / max|y|; bar max(1e-5, c-fp32))"
               % (tag, bi, e_inf, c_inf))
