@@ -167,25 +167,39 @@ def hbm_resident_spmm_leg(args, dev):
     pick = torch.unique(torch.cat([torch.topk(deg, min(6, n)).indices, torch.nonzero(deg == 0).reshape(-1)[:3],
                                    torch.randint(0, n, (2000,), generator=gen, device=dev)]))
     lens = deg[pick]
-    seg = torch.repeat_interleave(torch.arange(pick.numel(), device=dev), lens)
-    first = torch.cumsum(lens, 0) - lens
-    pos = indptr[pick].long()[seg] + (torch.arange(seg.numel(), device=dev) - first[seg])
     ref = torch.zeros((pick.numel(), D), dtype=torch.float64, device=dev)
     mag = torch.zeros_like(ref)
-    for lo_p in range(0, pos.numel(), 1 << 22):   # 4 M gathered rows at a time (fp64: 2 GB)
-        pp, ss = pos[lo_p:lo_p + (1 << 22)], seg[lo_p:lo_p + (1 << 22)]
-        term = X[col[pp].long()].double() * w[pp].double().unsqueeze(1)
-        ref.index_add_(0, ss, term)
-        mag.index_add_(0, ss, term.abs())
-        del term
+    # long rows one by one (a plain fp64 sum; an index_add_ of 10^6 terms into one row serialises on its
+    # atomics: 18 s per call in round 3's first version), the short ones together
+    long_rows = torch.nonzero(lens > 4096).reshape(-1).tolist()
+    for k in long_rows:
+        a_, b_ = int(indptr[pick[k]]), int(indptr[pick[k] + 1])
+        for lo_p in range(a_, b_, 1 << 22):
+            hi_p = min(lo_p + (1 << 22), b_)
+            term = X[col[lo_p:hi_p].long()].double() * w[lo_p:hi_p].double().unsqueeze(1)
+            ref[k] += term.sum(0)
+            mag[k] += term.abs().sum(0)
+            del term
+    short = lens <= 4096
+    s_rows = torch.nonzero(short).reshape(-1)
+    s_lens = lens[s_rows]
+    seg = torch.repeat_interleave(s_rows, s_lens)
+    first = torch.cumsum(s_lens, 0) - s_lens
+    pos = indptr[pick[s_rows]].long().repeat_interleave(s_lens) + \
+        (torch.arange(seg.numel(), device=dev) - first.repeat_interleave(s_lens))
+    term = X[col[pos].long()].double() * w[pos].double().unsqueeze(1)
+    ref.index_add_(0, seg, term)
+    mag.index_add_(0, seg, term.abs())
+    n_checked_edges = int(lens.sum())
+    del term, pos, seg
     got = out[pick].double()
     empty_exact = bool((got[lens == 0] == 0).all())
     sum_err = float(((got - ref).abs() / mag.clamp_min(1e-300))[mag > 0].max())
-    verified = {"rows": int(pick.numel()), "edges": int(pos.numel()), "max_in_degree_checked": int(lens.max()),
+    verified = {"rows": int(pick.numel()), "edges": n_checked_edges, "max_in_degree_checked": int(lens.max()),
                 "empty_rows_checked": int((lens == 0).sum()), "empty_rows_exact_zero": empty_exact,
                 "sum_err": sum_err, "bar": 1e-5}
     assert empty_exact and sum_err <= 1e-5, verified
-    del ref, mag, got, pos, seg
+    del ref, mag, got
     # same-run calibration of this box's HBM: a 4 GiB device-to-device copy (torch's copy kernel)
     a_ = torch.empty(1 << 30, dtype=torch.float32, device=dev).normal_()
     b_ = torch.empty_like(a_)

@@ -63,9 +63,9 @@ def main():
         ref[idx] = (t * torch.tanh(h + r64[r])).sum(1)
     out = {}
     fused = ops.att_score_fused_supported(n, D, D, R)
-    g_tab = None if fused else torch.empty((max(n_groups, 1), D), device=dev)
+    g_tab = torch.empty((max(n_groups, 1), D), device=dev) if (not fused or D == 128) else None
     for name, f32p in (("bf16x3 pieces", False), ("fp32 products", True)):
-        if fused:
+        if fused and not (D == 128 and f32p):   # (the one-launch form at d = 128 has the piece products only)
             fn = lambda: ops.att_score_fused(n, rp2, perm2, sg2, idx2, gid, gptr, g_node, tl, tp, ent, W, rel,  # noqa: E731
                                              want_csr=False, part_tptr=pp, f32_products=f32p)[0]
         else:  # two-launch folded form (d = 128)
