@@ -437,14 +437,31 @@ def main():
 
     def timed_steps():
         """W untimed + EXACTLY K timed steps between barrier + synchronize brackets; max over ranks."""
+        res = None
         for _ in range(args.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+            # (the result is held exactly as in the timed loop: while step k+1 runs, step k's output is
+            # still alive, so the allocator needs TWO output buffers; a warm-up that dropped its results
+            # left the second one to be hipMalloc'ed - a device-synchronising call - inside the second
+            # timed step: 0.4 ms on the benchmark graph, 60-180 ms with the 7 GB readout of the 10 M-node
+            # graph; KGAT_BENCH_TRACE=1 prints the per-step times that showed it)
             res = step()
         sync()
+        t0 = time.perf_counter()
+        trace = [] if os.environ.get("KGAT_BENCH_TRACE") else None
+        for _ in range(args.steps):
+            if trace is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            res = step()
+            if trace is not None:
+                ev[1].record()
+                trace.append((ev, time.perf_counter() - t0))
+        sync()
         el = time.perf_counter() - t0
+        if trace is not None and rank == 0:  # developer aid: where inside the timed region the time went
+            print("trace: wall %.2f ms | device ms per step: %s | host enqueue done at ms: %s" % (
+                el * 1e3, " ".join("%.2f" % a.elapsed_time(b) for (a, b), _ in trace),
+                " ".join("%.1f" % (h * 1e3) for _, h in trace)), file=sys.stderr, flush=True)
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,6 +472,14 @@ def main():
     # head groups, work tiles) and, for N > 1, creates the RCCL communicator - none of which belongs
     # to a step, whatever --warmup says
     out, a = step()
+    sync()
+    # ... and a clock / cache / allocator pre-warm: KGAT_BENCH_TRACE shows the first ~15 steps after an
+    # idle gap running 5-10 % slower than the steady state (0.53 ms falling to 0.47-0.48), far more than
+    # the driver's 5 warm-up steps cover; 30 untimed steps (15 ms; 3 on graphs beyond 20 M edges) put the
+    # warm-up and the timed steps into the steady state.  Reported as `config.setup_steps`.
+    setup_steps = 30 if E <= 20_000_000 else 3
+    for _ in range(setup_steps):
+        out, a = step()
     sync()
     dt, (out, a) = timed_steps()          # N > 1: the north_star exchange (all-reduce of the zero-padded layer output)
     ms_per_step = dt / args.steps * 1e3
@@ -674,6 +699,7 @@ def main():
                                % (name, n, E, n_rel, args.layers, D, args.layers),
                    "partition": "none" if world == 1 else "dst-range x%d, all-reduce of layer outputs" % world,
                    "edges_counted_per_step": args.layers * E,
+                   "setup_steps": 1 + setup_steps,
                    "edge_id_order_attention": "returned as a lazy tensor (values written on first read; the step's "
                                               "update_all reads the CSR-ordered copy); eager variant: %.4f ms per step"
                                               % eager_ms},
