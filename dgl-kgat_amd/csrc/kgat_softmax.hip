@@ -164,31 +164,34 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-sweep form (default).  A wavefront takes 1,024 consecutive CSR positions, 16 per lane
-// (coalesced loads, transposed through a wave-private LDS patch), and finishes every destination
-// row that lies completely inside its range:
-//   * inside a lane, runs of equal row id are reduced with forward/backward sweeps over the 16
-//     registers (static indexing): run max, then run sum of exp(x - max);
-//   * across lanes, the aggregate (m, s) of a row spanning several lanes is a segmented
-//     forward scan (combine: s <- s1 e^{m1-m} + s2 e^{m2-m}) and the finished total travels
-//     back to the lanes of the row with a segmented copy scan, so that all positions of a row
-//     are normalised with the same (M, S);
-//   * the row cut by the start / the end of the wavefront's range is not finished here: its
-//     partial (m, s) goes to a carry entry together with the indices of the first and the last
-//     wavefront the row touches (from indptr).  softmax_cut_rows_kernel then lets every
-//     wavefront combine, for each of its (at most two) cut rows, the carries of the row's whole
-//     chain - head entry first, then the followers in blocks of 64 with an ordered tree, the same
-//     sequence in every wavefront of the chain, hence the same bits - and normalise its own
-//     positions of that row.  (Until round 2 a separate one-wave-per-boundary chain launch wrote
-//     the totals back into the entries; three dependent launches of 5-23 us were latency.)
+// One-sweep form (default).  A wavefront takes 512 (1,024) consecutive CSR positions, 8 (16) per lane in
+// BLOCKED order - lane l holds positions 8l .. 8l+7, so row ids, index map, CSR-ordered logits and results
+// move as 16-byte loads / stores and nothing is transposed - and finishes every destination row that lies
+// completely inside its range:
+//   * inside a lane, runs of equal row id are reduced with forward sweeps over the registers (static
+//     indexing) and the finished values travel back with a copy sweep;
+//   * across lanes, the row of a lane's LAST run is a segmented inclusive scan over the lanes (DPP row
+//     shifts inside a 16-lane row, row broadcasts across rows; which lane may take which neighbour is
+//     decided once from a ballot of the segment heads and reused by both passes), and the total of a row
+//     is fetched from the lane in which the row ends with ONE ds_bpermute (that lane again from a ballot);
+//   * two passes of that: the row maxima first, so that every position is exponentiated ONCE against the
+//     maximum of its row inside the range (no rescaling of partial sums, no exp inside a scan), then the
+//     row sums;
+//   * the row cut by the start / the end of the wavefront's range is not finished here: its partial
+//     (m, s) goes to a carry entry together with the indices of the first and the last wavefront the row
+//     touches (from indptr), and its positions are stored PROVISIONALLY as exp(x - m).
+//     softmax_cut_rows_kernel then lets every wavefront combine, for each of its (at most two) cut rows,
+//     the carries of the row's whole chain - head entry first, then the followers in blocks of 64 with an
+//     ordered tree, the same sequence in every wavefront of the chain, hence the same bits - and rescale
+//     its own provisional positions of that row by exp(m - M) / S.  It reads neither logits nor indices.
 // No atomics, fixed combination order: bitwise reproducible, and no bound on a row's length.
-// LDS: one 5 KB patch per wavefront, used for the logits, then the row ids, then the results
-// (40 KB per workgroup with two patches limited a CU to 3 workgroups = 768 of the benchmark
-// graph's 895: a second, almost empty round doubled the kernel's time).
+// Round 3 (second half): the sweep had been ~1,200 instructions per wavefront (two LDS transposes, 64-bit
+// address arithmetic per load, thirteen ds_bpermute scan steps carrying (m, s) pairs with an exp in every
+// combine, a compare pair per stored position) at 7 wavefronts per SIMD - bound by instruction issue.  This
+// form is ~350.
 // positions per lane: 16 (1,024 per wavefront), or 8 for launches over fewer than kSmSmallEdges
-// positions, where the sweep is a latency chain (load, transpose, scans, store) rather than a
-// stream and twice the wavefronts with half the chain each finish sooner (amazon-book graph: sweep
-// 22 -> 17 us, cut rows 13 -> 12 us; 4 per lane was slower again: 36 us for both)
+// positions, where the sweep is a latency chain rather than a stream and twice the wavefronts with half
+// the chain each finish sooner.
 constexpr int kSmMaxEPL = 16;
 #ifndef KGAT_SM_SMALL_EDGES
 #define KGAT_SM_SMALL_EDGES (8 << 20)
@@ -196,7 +199,6 @@ constexpr int kSmMaxEPL = 16;
 constexpr int64_t kSmSmallEdges = KGAT_SM_SMALL_EDGES;  // (a macro for A/B builds: scripts/micro/softmax_ab.py)
 template <int EPL> struct SmGeom {
   static constexpr int EPW = kWave * EPL;   // positions per wavefront
-  static constexpr int Pad = EPL + 4;       // floats per lane in the LDS patch (conflict-free b128 for 8 and 16)
 };
 constexpr float kSmNegBig = -3.0e38f;     // stands in for -inf (keeps the combine NaN-free)
 
@@ -220,8 +222,7 @@ __device__ __forceinline__ float sm_exp(float x) {
 }
 
 // (m, s) <- (m, s) (+) (m2, s2): the smaller maximum's sum is rescaled by exp(-|m - m2|).  Branch-free
-// (one exp, selects): the scans below call it in every lane at every step, and a divergent if / else
-// cost two exec-mask switches and both exp paths per call.  Same arithmetic as the branchy form.
+// (one exp, selects).  Used where partial results of different wavefronts meet (the chains of cut rows).
 __device__ __forceinline__ void sm_combine(float& m, float& s, float m2, float s2) {
   const bool keep = m >= m2;
   const float e = sm_exp(keep ? m2 - m : m - m2);
@@ -230,378 +231,293 @@ __device__ __forceinline__ void sm_combine(float& m, float& s, float m2, float s
   m = keep ? m : m2;
 }
 
+// index of the wavefront in the launch, as a scalar (the compiler cannot see that threadIdx.x / 64 is
+// uniform; with it in an SGPR the range base is one, and loads take the base + 32-bit lane offset form)
 __device__ __forceinline__ int64_t sm_wave_index() {
-  return (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  return (int64_t)blockIdx.x * (256 / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
 }
 
-__device__ __forceinline__ void sm_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+// DPP lane moves (gfx9 controls): row_shr:n = 0x110 + n, wave_shl:1 = 0x130, wave_shr:1 = 0x138,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.  A lane without a valid source keeps `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sm_dpp(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int32_t sm_dpp_i(int32_t old, int32_t src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, 0xf, false);
+}
+
+// Lane predicates are kept as 64-bit lane masks in scalar registers (ballot -> empty asm that pins the value
+// -> inverse ballot at the use): left to itself the compiler re-issued the compare in front of every select
+// (a VALU write of an SGPR pair costs two wait states before a VALU may read it) and turned chains of
+// selects over the same predicates into indexed-choice code.
+typedef unsigned long long sm_mask;
+__device__ __forceinline__ sm_mask sm_pin(bool c) {
+  sm_mask m = __builtin_amdgcn_ballot_w64(c);
+  asm volatile("" : "+s"(m));
+  return m;
+}
+__device__ __forceinline__ float sm_sel(sm_mask m, float a, float b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
+// max without the quieting v_max x, x the compiler puts in front of every fmaxf operand it did not produce
+// itself (loads, selects).  Plain VALU asm; its results reach DPP moves only through selects.
+__device__ __forceinline__ float sm_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// the value lane `l` holds, as a scalar (the builtin moves integers: bit casts, not conversions)
+__device__ __forceinline__ float sm_lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// How the runs at the two ends of a lane's block of positions continue into the neighbouring lanes; computed
+// once per wavefront, used by the maximum pass and by the sum pass.
+struct SmLinks {
+  sm_mask multi;                   // the block holds more than one row (first run != last run)
+  sm_mask link, link_n;            // first run continues lane-1's last run / last run continues into lane+1
+  sm_mask p1, p2, p4, p8, p15, p31;  // scan steps in which the lane takes the value offered from its left
+  int zaddr;                       // 4 x the lane in which the row of the lane's FIRST run ends
+};
+
+__device__ __forceinline__ SmLinks sm_links(int32_t key_f, int32_t key_l, int lane) {
+  SmLinks k;
+  const bool multi = key_f != key_l;
+  const int32_t prev_l = sm_dpp_i<0x138>(key_l, key_l), next_f = sm_dpp_i<0x130>(key_f, key_f);
+  const bool link = lane > 0 && prev_l == key_f;
+  const bool link_n = lane < kWave - 1 && key_l == next_f;
+  // the scan runs over the lanes' LAST runs; a lane whose last run starts inside it (multi) or does not
+  // continue its left neighbour's heads a segment
+  const unsigned long long heads = __ballot(multi || !link);
+  const unsigned long long upto = (lane == kWave - 1) ? ~0ull : ((2ull << lane) - 1ull);  // bits 0..lane
+  const int start = 63 - __clzll(heads & upto);
+  const int in_row = lane & 15;
+  k.multi = sm_pin(multi);
+  k.link = sm_pin(link);
+  k.link_n = sm_pin(link_n);
+  k.p1 = sm_pin(in_row >= 1 && lane - 1 >= start);
+  k.p2 = sm_pin(in_row >= 2 && lane - 2 >= start);
+  k.p4 = sm_pin(in_row >= 4 && lane - 4 >= start);
+  k.p8 = sm_pin(in_row >= 8 && lane - 8 >= start);
+  k.p15 = sm_pin((lane & 16) != 0 && start < (lane & 48));   // rows 1 and 3 take lane 15 / 47
+  k.p31 = sm_pin(lane >= 32 && start < 32);                  // rows 2 and 3 take lane 31
+  // a row handed from lane to lane ends in the first lane at or after this one that holds a second run
+  // (the row ends inside it, as its first run) or whose run does not continue (the row ends with it)
+  const unsigned long long stops = __ballot(multi || !link_n);  // (lane 63 always stops)
+  k.zaddr = 4 * (lane + (int)__builtin_ctzll(stops >> lane));
+  return k;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ float sm_op(float left, float right) { return IS_MAX ? fmaxf(left, right) : left + right; }
+
+// a_f / a_l: aggregate of the lane's first / last run (the same number when the lane holds one run).
+// t_f / t_l: aggregate of those runs' ROWS over the whole range of the wavefront; incl: the inclusive scan
+// value (the lane's last row from its start inside the range to the end of the lane).
+template <bool IS_MAX>
+__device__ __forceinline__ void sm_rows_across_lanes(const SmLinks& k, float a_f, float a_l, float& t_f, float& t_l,
+                                                     float& incl) {
+  float v = a_l, t;
+  t = sm_dpp<0x111, 0xf>(v, v); v = sm_sel(k.p1, sm_op<IS_MAX>(t, v), v);
+  t = sm_dpp<0x112, 0xf>(v, v); v = sm_sel(k.p2, sm_op<IS_MAX>(t, v), v);
+  t = sm_dpp<0x114, 0xf>(v, v); v = sm_sel(k.p4, sm_op<IS_MAX>(t, v), v);
+  t = sm_dpp<0x118, 0xf>(v, v); v = sm_sel(k.p8, sm_op<IS_MAX>(t, v), v);
+  t = sm_dpp<0x142, 0xa>(v, v); v = sm_sel(k.p15, sm_op<IS_MAX>(t, v), v);
+  t = sm_dpp<0x143, 0xc>(v, v); v = sm_sel(k.p31, sm_op<IS_MAX>(t, v), v);
+  incl = v;
+  const float prev = sm_dpp<0x138, 0xf>(v, v);                          // lane-1's scan value
+  const float fin_f = sm_sel(k.link, sm_op<IS_MAX>(prev, a_f), a_f);   // the first run's row, if it ends in this lane
+  const float own = sm_sel(k.multi, fin_f, v);                          // what this lane can offer as a finished total
+  const float e = __int_as_float(__builtin_amdgcn_ds_bpermute(k.zaddr, __float_as_int(own)));
+  const float nxt = sm_dpp<0x130, 0xf>(e, e);                           // lane+1's finished first-run row
+  t_f = e;
+  t_l = sm_sel(k.multi, sm_sel(k.link_n, nxt, v), e);
+}
+
+template <bool IN_CSR, int kSmEPL, bool FAST>
+__device__ __forceinline__ void sm_sweep(int64_t e0, int64_t e1, int64_t w, int64_t base, int64_t end,
+                                         const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
+                                         const int32_t* __restrict__ eid, const float* __restrict__ logits,
+                                         float* __restrict__ out, float* __restrict__ out_csr,
+                                         SmCarry* __restrict__ carry) {
+  constexpr int kSmEPW = SmGeom<kSmEPL>::EPW;
+  const int lane = threadIdx.x % kWave;
+  const int n_valid = (int)(end - base);
+  const int32_t* ro = row_of + base;
+  // ---- loads: lane l takes positions kSmEPL * l .. + kSmEPL - 1 of the range.  FAST (a full range,
+  // 16-byte aligned): dwordx4.  Otherwise per position, clamped to the last valid one (whose row the
+  // positions past the end then repeat, with a huge negative logit) - nothing under a per-position branch.
+  int32_t r[kSmEPL], gi[kSmEPL];
+  float x[kSmEPL];
+  const bool need_gi = !IN_CSR || out != nullptr;
+  if (FAST) {
+#pragma unroll
+    for (int v = 0; v < kSmEPL / 4; ++v) {
+      const int4 b = *reinterpret_cast<const int4*>(ro + lane * kSmEPL + 4 * v);
+      r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
+    }
+    if (need_gi) {
+      const int32_t* ei = eid + base;
+#pragma unroll
+      for (int v = 0; v < kSmEPL / 4; ++v) {
+        const int4 b = *reinterpret_cast<const int4*>(ei + lane * kSmEPL + 4 * v);
+        gi[4 * v] = b.x; gi[4 * v + 1] = b.y; gi[4 * v + 2] = b.z; gi[4 * v + 3] = b.w;
+      }
+    }
+    if (IN_CSR) {
+      const float* lg = logits + base;
+#pragma unroll
+      for (int v = 0; v < kSmEPL / 4; ++v) {
+        const float4 a = *reinterpret_cast<const float4*>(lg + lane * kSmEPL + 4 * v);
+        x[4 * v] = a.x; x[4 * v + 1] = a.y; x[4 * v + 2] = a.z; x[4 * v + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kSmEPL; ++i) x[i] = logits[gi[i]];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kSmEPL; ++i) {
+      const int q = lane * kSmEPL + i;
+      const int qc = q < n_valid ? q : n_valid - 1;
+      r[i] = ro[qc];
+      gi[i] = need_gi ? eid[base + qc] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kSmEPL; ++i) {
+      const int q = lane * kSmEPL + i;
+      const int qc = q < n_valid ? q : n_valid - 1;
+      const float v = IN_CSR ? logits[base + qc] : logits[gi[i]];
+      x[i] = q < n_valid ? v : kSmNegBig;
+    }
+  }
+  // ---- the rows at the two ends of the range: cut by it?
+  const int32_t R0 = __builtin_amdgcn_readfirstlane(r[0]);
+  const int32_t RL = __builtin_amdgcn_readlane(r[kSmEPL - 1], kWave - 1);
+  const bool cut_start = base > e0 && row_of[base - 1] == R0;
+  const bool cut_end = end < e1 && row_of[end] == RL;
+  // ---- runs inside the lane: eq[i] = position i continues the run of position i-1
+  sm_mask eq[kSmEPL];
+  eq[0] = 0;
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) eq[i] = sm_pin(r[i] == r[i - 1]);
+  const int32_t key_f = r[0], key_l = r[kSmEPL - 1];
+  const SmLinks k = sm_links(key_f, key_l, lane);
+  // ---- pass 1: row maxima.  Forward max sweep, backward copy sweep (every position then holds the maximum
+  // of its run; [0] / [last] those of the lane's first / last run), the rows of those two runs across the
+  // lanes, and the two results handed back through their runs by one more copy sweep each way.
+  float M[kSmEPL];
+  M[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) M[i] = sm_sel(eq[i], sm_vmax(M[i - 1], x[i]), x[i]);
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) M[i] = sm_sel(eq[i + 1], M[i + 1], M[i]);
+  float mf, ml, mi;
+  sm_rows_across_lanes<true>(k, M[0], M[kSmEPL - 1], mf, ml, mi);
+  M[kSmEPL - 1] = ml;
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) M[i] = sm_sel(eq[i + 1], M[i + 1], M[i]);
+  M[0] = mf;
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) M[i] = sm_sel(eq[i], M[i - 1], M[i]);
+  // ---- pass 2: x <- exp(x - row max inside the range), row sums the same way
+#pragma unroll
+  for (int i = 0; i < kSmEPL; ++i) x[i] = sm_exp(x[i] - M[i]);
+  float S[kSmEPL];
+  S[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) S[i] = sm_sel(eq[i], S[i - 1] + x[i], x[i]);
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) S[i] = sm_sel(eq[i + 1], S[i + 1], S[i]);
+  float sf, sl, si;
+  sm_rows_across_lanes<false>(k, S[0], S[kSmEPL - 1], sf, sl, si);
+  // ---- carries of the cut rows (first row within the range: lane 0's finished first-run row; last row
+  // within the range: lane 63's scan value); their positions inside the range follow from indptr
+  if (cut_start || cut_end) {  // (wave-uniform)
+    const float t0m = sm_lane_f(mf, 0), t0s = sm_lane_f(sf, 0);
+    const float tlm = sm_lane_f(mi, kWave - 1), tls = sm_lane_f(si, kWave - 1);
+    SmCarry a, b;
+    a.row = b.row = -1;
+    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f;
+    a.head = b.head = a.last = b.last = 0; a.pad0 = a.pad1 = b.pad0 = b.pad1 = 0;
+    if (cut_start) {  // a follower entry of the first row's chain (the row may also fill the whole range)
+      const int64_t first_beg = indptr[R0], first_end = indptr[R0 + 1];
+      const int64_t fb = first_beg > e0 ? first_beg : e0, fe = first_end < e1 ? first_end : e1;
+      a.row = R0; a.count = (int)((first_end < end ? first_end : end) - base); a.m = t0m; a.s = t0s;
+      a.head = (int32_t)((fb - e0) / kSmEPW); a.last = (int32_t)((fe - 1 - e0) / kSmEPW);
+    }
+    if (cut_end && !(cut_start && R0 == RL)) {  // the head entry of the last row's chain
+      const int64_t last_beg = indptr[RL], last_end = indptr[RL + 1];
+      const int64_t lb = last_beg > e0 ? last_beg : e0, le = last_end < e1 ? last_end : e1;
+      b.row = RL; b.count = (int)(end - (last_beg > base ? last_beg : base)); b.m = tlm; b.s = tls;
+      b.head = (int32_t)((lb - e0) / kSmEPW); b.last = (int32_t)((le - 1 - e0) / kSmEPW);
+    }
+    if (lane == 0) {
+      carry[2 * w] = a;
+      carry[2 * w + 1] = b;
+    }
+    // positions of a cut row leave as exp(x - m), m the carry's: a "sum" of one
+    const bool of = (cut_start && key_f == R0) || (cut_end && key_f == RL);
+    const bool ol = (cut_start && key_l == R0) || (cut_end && key_l == RL);
+    sf = of ? 1.0f : sf;
+    sl = ol ? 1.0f : sl;
+  } else if (lane == 0) {
+    SmCarry a;
+    a.row = -1; a.count = 0; a.m = kSmNegBig; a.s = 0.f; a.head = a.last = 0; a.pad0 = a.pad1 = 0;
+    carry[2 * w] = a;
+    carry[2 * w + 1] = a;
+  }
+  S[kSmEPL - 1] = sl;
+#pragma unroll
+  for (int i = kSmEPL - 2; i >= 0; --i) S[i] = sm_sel(eq[i + 1], S[i + 1], S[i]);
+  S[0] = sf;
+#pragma unroll
+  for (int i = 1; i < kSmEPL; ++i) S[i] = sm_sel(eq[i], S[i - 1], S[i]);
+  // ---- normalise (hardware reciprocal, 1 ulp) and store
+#pragma unroll
+  for (int i = 0; i < kSmEPL; ++i) x[i] *= __builtin_amdgcn_rcpf(S[i]);
+  if (FAST) {
+    if (out_csr) {
+      float* oc = out_csr + base;
+#pragma unroll
+      for (int v = 0; v < kSmEPL / 4; ++v) {
+        float4 a;
+        a.x = x[4 * v]; a.y = x[4 * v + 1]; a.z = x[4 * v + 2]; a.w = x[4 * v + 3];
+        *reinterpret_cast<float4*>(oc + lane * kSmEPL + 4 * v) = a;
+      }
+    }
+    if (out) {
+#pragma unroll
+      for (int i = 0; i < kSmEPL; ++i) out[gi[i]] = x[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kSmEPL; ++i) {
+      const int q = lane * kSmEPL + i;
+      if (q < n_valid) {
+        if (out_csr) out_csr[base + q] = x[i];
+        if (out) out[gi[i]] = x[i];
+      }
+    }
+  }
 }
 
 template <bool IN_CSR, int kSmEPL>
 __global__ __launch_bounds__(256) void softmax_local_kernel(
-    int64_t e0, int64_t e1, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
+    int64_t e0, int64_t e1, int aligned, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
     const int32_t* __restrict__ eid, const float* __restrict__ logits, float* __restrict__ out,
     float* __restrict__ out_csr, SmCarry* __restrict__ carry) {
-  constexpr int kSmEPW = SmGeom<kSmEPL>::EPW, kSmPad = SmGeom<kSmEPL>::Pad;
-  __shared__ __attribute__((aligned(16))) float s_patch[256 / kWave][kWave * kSmPad];
-  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
+  constexpr int kSmEPW = SmGeom<kSmEPL>::EPW;
   const int64_t w = sm_wave_index();
   const int64_t base = e0 + w * kSmEPW;
   if (base >= e1) return;
   const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
-  float* px = s_patch[wv];
-  int32_t* pr = reinterpret_cast<int32_t*>(s_patch[wv]);
-  // striped, coalesced loads; positions past `end` repeat the last row with a huge negative logit.
-  // Branch-free (clamped positions instead of predicated loads): all row ids and input indices are
-  // requested together, then all logits - with a load under a condition per position the compiler
-  // waited for every index before it issued the dependent gather, sixteen serial round trips per
-  // wavefront on the indexed input path (round 3: that path now carries the grouped-order logits).
-  const int32_t r_last = row_of[end - 1];
-  int32_t rs[kSmEPL], gi[kSmEPL];
-  float xs[kSmEPL];
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int64_t p = base + j * kWave + lane;
-    const int64_t pc = p < end ? p : end - 1;
-    rs[j] = row_of[pc];  // (= r_last past the end)
-    gi[j] = IN_CSR ? (int32_t)(pc - e0) : eid[pc];
-  }
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int64_t p = base + j * kWave + lane;
-    const float x = IN_CSR ? logits[p < end ? p : end - 1] : logits[gi[j]];
-    xs[j] = p < end ? x : kSmNegBig;
-  }
-  // neighbours of the range (is the first / last row cut?) and the extent of the two rows at its ends
-  const int32_t r_first = row_of[base];
-  const bool cut_start = base > e0 && row_of[base - 1] == r_first;
-  const bool cut_end = end < e1 && row_of[end] == r_last;
-  const int64_t first_beg = indptr[r_first], first_end = indptr[r_first + 1];
-  const int64_t last_beg = indptr[r_last], last_end = indptr[r_last + 1];
-  float x[kSmEPL], M[kSmEPL], S[kSmEPL];
-  int32_t r[kSmEPL];
-  // transpose through the wave's patch: the logits, then (same patch) the row ids
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int idx = j * kWave + lane;  // owner lane idx / EPL, slot idx % EPL
-    px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)] = xs[j];
-  }
-  sm_wave_sync();
-#pragma unroll
-  for (int v = 0; v < kSmEPL / 4; ++v) {
-    const float4 a = *reinterpret_cast<const float4*>(px + lane * kSmPad + 4 * v);
-    x[4 * v] = a.x; x[4 * v + 1] = a.y; x[4 * v + 2] = a.z; x[4 * v + 3] = a.w;
-  }
-  sm_wave_sync();
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int idx = j * kWave + lane;
-    pr[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)] = rs[j];
-  }
-  sm_wave_sync();
-#pragma unroll
-  for (int v = 0; v < kSmEPL / 4; ++v) {
-    const int4 b = *reinterpret_cast<const int4*>(pr + lane * kSmPad + 4 * v);
-    r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
-  }
-  // ---- lane-local runs
-  M[0] = x[0];
-#pragma unroll
-  for (int i = 1; i < kSmEPL; ++i) M[i] = r[i] == r[i - 1] ? fmaxf(M[i - 1], x[i]) : x[i];
-#pragma unroll
-  for (int i = kSmEPL - 2; i >= 0; --i) M[i] = r[i] == r[i + 1] ? M[i + 1] : M[i];
-  // x[i] <- exp(x[i] - lane-local run max): the run sums use it, and so does the result
-  // (rescaled by exp(run max - row max) where the row reaches beyond the lane)
-#pragma unroll
-  for (int i = 0; i < kSmEPL; ++i) x[i] = sm_exp(x[i] - M[i]);
-  S[0] = x[0];
-#pragma unroll
-  for (int i = 1; i < kSmEPL; ++i) S[i] = r[i] == r[i - 1] ? S[i - 1] + x[i] : x[i];
-#pragma unroll
-  for (int i = kSmEPL - 2; i >= 0; --i) S[i] = r[i] == r[i + 1] ? S[i + 1] : S[i];
-  // ---- rows spanning lanes
-  const int32_t key_f = r[0], key_l = r[kSmEPL - 1];
-  const bool multi = key_f != key_l;  // the lane's last run starts (and its first run ends) inside the lane
-  const int32_t prev_l = __shfl_up(key_l, 1, kWave), next_f = __shfl_down(key_f, 1, kWave);
-  const bool link = lane > 0 && prev_l == key_f;             // first run continues lane-1's last run
-  const bool link_n = lane < kWave - 1 && key_l == next_f;   // last run continues into lane+1
-  // I = (m, s) of the lane's last row from the row's start (inside the wavefront) to the lane's end
-  float im = M[kSmEPL - 1], is = S[kSmEPL - 1];
-  {
-    int stop = (multi || !link) ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const float m2 = __shfl_up(im, d, kWave), s2 = __shfl_up(is, d, kWave);
-      const int f2 = __shfl_up(stop, d, kWave);
-      const bool act = lane >= d && !stop;  // (selects, not a branch: every lane runs the combine)
-      float cm = m2, cs = s2;
-      sm_combine(cm, cs, im, is);
-      im = act ? cm : im;
-      is = act ? cs : is;
-      stop = act ? f2 : stop;
-    }
-  }
-  // the row that is the lane's FIRST run: finished total if it ends in this lane
-  float fm = M[0], fs = S[0];
-  {
-    const float pm = __shfl_up(im, 1, kWave), ps = __shfl_up(is, 1, kWave);
-    float cm = pm, cs = ps;
-    sm_combine(cm, cs, fm, fs);
-    fm = (multi && link) ? cm : fm;
-    fs = (multi && link) ? cs : fs;
-  }
-  // E = finished total of the row that is the lane's first run (copy scan from the lane where it ends)
-  float em = multi ? fm : im, es = multi ? fs : is;
-  {
-    int stop = (multi || !link_n) ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const float m2 = __shfl_down(em, d, kWave), s2 = __shfl_down(es, d, kWave);
-      const int f2 = __shfl_down(stop, d, kWave);
-      const bool act = lane + d < kWave && !stop;
-      em = act ? m2 : em;
-      es = act ? s2 : es;
-      stop = act ? f2 : stop;
-    }
-  }
-  const float nm = __shfl_down(em, 1, kWave), ns = __shfl_down(es, 1, kWave);
-  const float lm = multi ? (link_n ? nm : im) : em, ls = multi ? (link_n ? ns : is) : es;  // last run's row
-  // ---- the rows cut by the range: their positions inside it follow from indptr
-  const int32_t R0 = r_first, RL = r_last;
-  const int c0 = (int)((first_end < end ? first_end : end) - base);
-  const int cl = (int)(end - (last_beg > base ? last_beg : base));
-  const float t0m = __shfl(em, 0, kWave), t0s = __shfl(es, 0, kWave);                 // first row, within the range
-  const float tlm = __shfl(im, kWave - 1, kWave), tls = __shfl(is, kWave - 1, kWave);  // last row, within the range
-  if (lane == 0) {
-    SmCarry a, b;
-    a.row = b.row = -1;
-    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f;
-    a.head = b.head = a.last = b.last = 0; a.pad0 = a.pad1 = b.pad0 = b.pad1 = 0;
-    const int64_t fb = first_beg > e0 ? first_beg : e0, fe = first_end < e1 ? first_end : e1;
-    const int64_t lb = last_beg > e0 ? last_beg : e0, le = last_end < e1 ? last_end : e1;
-    if (cut_start) {  // a follower entry of the first row's chain (the row may also fill the whole range)
-      a.row = R0; a.count = c0; a.m = R0 == RL ? tlm : t0m; a.s = R0 == RL ? tls : t0s;
-      a.head = (int32_t)((fb - e0) / kSmEPW); a.last = (int32_t)((fe - 1 - e0) / kSmEPW);
-    }
-    if (cut_end && !(cut_start && R0 == RL)) {  // the head entry of the last row's chain
-      b.row = RL; b.count = cl; b.m = tlm; b.s = tls;
-      b.head = (int32_t)((lb - e0) / kSmEPW); b.last = (int32_t)((le - 1 - e0) / kSmEPW);
-    }
-    carry[2 * w] = a;
-    carry[2 * w + 1] = b;
-  }
-  // ---- normalise the finished rows; positions of cut rows are left to softmax_cut_rows_kernel
-  const float scale_f = sm_exp(M[0] - em) / es, scale_l = sm_exp(M[kSmEPL - 1] - lm) / ls;
-#pragma unroll
-  for (int i = 0; i < kSmEPL; ++i) {
-    const bool first = r[i] == key_f, last = r[i] == key_l;
-    // (hardware reciprocal, 1 ulp: two instructions per position where the IEEE division took ten)
-    x[i] = x[i] * ((first || last) ? (first ? scale_f : scale_l) : __builtin_amdgcn_rcpf(S[i]));
-  }
-  sm_wave_sync();
-#pragma unroll
-  for (int v = 0; v < kSmEPL / 4; ++v) {
-    float4 a;
-    a.x = x[4 * v]; a.y = x[4 * v + 1]; a.z = x[4 * v + 2]; a.w = x[4 * v + 3];
-    *reinterpret_cast<float4*>(px + lane * kSmPad + 4 * v) = a;
-  }
-  sm_wave_sync();
-  const int64_t skip_lo = cut_start ? base + c0 : base;     // [base, skip_lo) belongs to the cut first row
-  const int64_t skip_hi = cut_end ? end - cl : end;         // [skip_hi, end) belongs to the cut last row
-  float av[kSmEPL];
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int idx = j * kWave + lane;
-    av[j] = px[(idx / kSmEPL) * kSmPad + (idx % kSmEPL)];
-  }
-  if (out_csr) {  // (the wave-uniform tests outside the per-position loops)
-#pragma unroll
-    for (int j = 0; j < kSmEPL; ++j) {
-      const int64_t p = base + j * kWave + lane;
-      if (p >= skip_lo && p < skip_hi) out_csr[p] = av[j];
-    }
-  }
-  if (out) {
-#pragma unroll
-    for (int j = 0; j < kSmEPL; ++j) {
-      const int64_t p = base + j * kWave + lane;
-      if (p >= skip_lo && p < skip_hi) out[eid ? eid[p] : p] = av[j];
-    }
-  }
+  if (aligned && end - base == kSmEPW)
+    sm_sweep<IN_CSR, kSmEPL, true>(e0, e1, w, base, end, indptr, row_of, eid, logits, out, out_csr, carry);
+  else
+    sm_sweep<IN_CSR, kSmEPL, false>(e0, e1, w, base, end, indptr, row_of, eid, logits, out, out_csr, carry);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Round 3 experiment, NOT the shipped sweep (built only with -DKGAT_SOFTMAX_SLOTS; kept as the record of
-// a negative result and as a third implementation for cross-checks): the sweep without scans.  The scan
-// form above spends ~1,500 instructions per wavefront (two LDS transposes, lane-local run loops,
-// thirteen cross-lane scan steps with an exp each) and is bound by instruction issue, not by memory:
-// 7 waves per SIMD x 1,500 instructions ~ 25 us.  This form has ~1,150 instructions and no scans - and
-// is slower: 48.6 us against 32.4 us stand-alone on the amazon-book graph (51.6 against 35.0 in the
-// step).  Its twenty LDS atomics per wavefront mostly hit a handful of addresses (a row is ~23
-// consecutive positions, striped over neighbouring lanes), and the LDS serialises same-address
-// read-modify-writes lane by lane: with 28 resident wavefronts per CU the LDS pipe, not the issue
-// port, becomes the bound.  What it does:
-// a wavefront keeps one LDS slot per destination row of its range (row - first row; at most one
-// row per position) and lets the LDS do the reductions:
-//   1. striped coalesced loads (no transpose), ds_max_f32 of every logit into its row's slot;
-//   2. e = exp(x - slot max), added into the slot in 2^-40 fixed point with ds_add_u64 - integer
-//      adds are associative, so the sum does not depend on the order the LDS serialises the lanes
-//      in: bitwise reproducible by construction (the 3-pass form does the same in global memory);
-//   3. one reciprocal per slot; 4. a = e * slot scale, coalesced stores.
-// ~350 instructions per wavefront.  Rows cut by the range boundaries: every wavefront also reads a
-// halo of 64 positions on either side into two extra accumulators.  A cut row that lies entirely
-// inside range + halo is finished here (own positions normalised with the merged statistics); its
-// carry entry is still written - a neighbour may need it for a row it cannot finish - with pad0 = 1,
-// which tells softmax_cut_rows_kernel to skip it.  Only rows reaching further out (hubs) are left to
-// the second launch, whose wavefronts otherwise return after reading their two entries.
-constexpr int kSmHalo = 64;
-constexpr float kSmFix = 1099511627776.0f;         // 2^40
-constexpr float kSmFixInv = 1.0f / 1099511627776.0f;
-
-#ifdef KGAT_SOFTMAX_SLOTS
-template <bool IN_CSR, int kSmEPL>
-__global__ __launch_bounds__(256) void softmax_slots_kernel(
-    int64_t e0, int64_t e1, const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
-    const int32_t* __restrict__ eid, const float* __restrict__ logits, float* __restrict__ out,
-    float* __restrict__ out_csr, SmCarry* __restrict__ carry) {
-  constexpr int EPW = kWave * kSmEPL, NS = EPW + 3;  // slots: rows of the range, halo before, halo after, discard
-  __shared__ float s_m[256 / kWave][NS];
-  __shared__ unsigned long long s_s[256 / kWave][NS];
-  const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
-  const int64_t w = sm_wave_index();
-  const int64_t base = e0 + w * EPW;
-  if (base >= e1) return;
-  const int64_t end = base + EPW < e1 ? base + EPW : e1;
-  float* pm = s_m[wv];
-  unsigned long long* ps = s_s[wv];
-  // ---- loads: row ids and input indices of the own positions and of the two halos, then the logits
-  const int32_t R0 = row_of[base], RL = row_of[end - 1];
-  int32_t slot[kSmEPL], gi[kSmEPL];
-  float x[kSmEPL];
-  const int64_t pb = base - 1 - lane, pa = end + lane;
-  const bool hb = pb >= e0, ha = pa < e1;
-  const int64_t pbc = hb ? pb : base, pac = ha ? pa : end - 1;
-  const int32_t rb = row_of[pbc], ra = row_of[pac];
-  const int32_t gb = IN_CSR ? 0 : eid[pbc], ga = IN_CSR ? 0 : eid[pac];
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {  // (clamped positions, unconditional loads: nothing here may sit under a branch)
-    const int64_t p = base + j * kWave + lane;
-    const int64_t pc = p < end ? p : end - 1;
-    slot[j] = row_of[pc];
-    gi[j] = IN_CSR ? 0 : eid[pc];
-  }
-  const int64_t first_beg = indptr[R0], first_end = indptr[R0 + 1];
-  const int64_t last_beg = indptr[RL], last_end = indptr[RL + 1];
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int64_t p = base + j * kWave + lane;
-    x[j] = IN_CSR ? logits[p < end ? p : end - 1] : logits[gi[j]];
-  }
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j)  // positions past the end go to the discard slot: no branches in the reductions
-    slot[j] = base + j * kWave + lane < end ? slot[j] - R0 : EPW + 2;
-  const float xb = IN_CSR ? logits[pbc] : logits[gb], xa = IN_CSR ? logits[pac] : logits[ga];
-  for (int k = lane; k < NS; k += kWave) {
-    pm[k] = kSmNegBig;
-    ps[k] = 0ull;
-  }
-  sm_wave_sync();
-  // ---- 1. row maxima
-  const int sb = (hb && rb == R0) ? EPW : EPW + 2, sa = (ha && ra == RL) ? EPW + 1 : EPW + 2;
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j)
-    __hip_atomic_fetch_max(&pm[slot[j]], x[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  __hip_atomic_fetch_max(&pm[sb], xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  __hip_atomic_fetch_max(&pm[sa], xa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  sm_wave_sync();
-  // ---- 2. exp(x - row max) and the row sums, in 2^-40 fixed point (exact integer adds)
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    x[j] = sm_exp(x[j] - pm[slot[j]]);
-    __hip_atomic_fetch_add(&ps[slot[j]], (unsigned long long)(x[j] * kSmFix), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-  __hip_atomic_fetch_add(&ps[sb], (unsigned long long)(sm_exp(xb - pm[sb]) * kSmFix), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WAVEFRONT);
-  __hip_atomic_fetch_add(&ps[sa], (unsigned long long)(sm_exp(xa - pm[sa]) * kSmFix), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WAVEFRONT);
-  sm_wave_sync();
-  // ---- 3. the rows cut by the range (lane 0; statistics read before the slots turn into scales)
-  const int64_t fb = first_beg > e0 ? first_beg : e0, fe = first_end < e1 ? first_end : e1;
-  const int64_t lb = last_beg > e0 ? last_beg : e0, le = last_end < e1 ? last_end : e1;
-  const bool cut_start = fb < base, cut_end = le > end;
-  const int c0 = (int)((fe < end ? fe : end) - base);
-  const int cl = (int)(end - (lb > base ? lb : base));
-  const int sl = RL - R0;
-  // can this wavefront see the whole row?  (first row: starts inside the halo before; if it is also the
-  // last row and continues, it must end inside the halo after)
-  const bool whole0 = fb >= base - kSmHalo && fe <= end + kSmHalo;
-  const bool wholeL = lb >= base - kSmHalo && le <= end + kSmHalo;
-  float sc0 = 0.f, scL = 0.f;  // scales of the first / last row's own positions when finished here
-  if (lane == 0) {
-    const float m0 = pm[0], s0 = (float)ps[0] * kSmFixInv;
-    const float mL = pm[sl], sL = (float)ps[sl] * kSmFixInv;
-    const float mB = pm[EPW], sB = (float)ps[EPW] * kSmFixInv;
-    const float mA = pm[EPW + 1], sA = (float)ps[EPW + 1] * kSmFixInv;
-    SmCarry a, b;
-    a.row = b.row = -1;
-    a.count = b.count = 0; a.m = b.m = kSmNegBig; a.s = b.s = 0.f;
-    a.head = b.head = a.last = b.last = 0; a.pad0 = a.pad1 = b.pad0 = b.pad1 = 0;
-    if (cut_start) {  // a follower entry of the first row's chain (the row may also fill the whole range)
-      a.row = R0; a.count = c0; a.m = m0; a.s = s0;
-      a.head = (int32_t)((fb - e0) / EPW); a.last = (int32_t)((fe - 1 - e0) / EPW);
-      a.pad0 = whole0 ? 1 : 0;
-    }
-    if (cut_end && !(cut_start && R0 == RL)) {  // the head entry of the last row's chain
-      b.row = RL; b.count = cl; b.m = mL; b.s = sL;
-      b.head = (int32_t)((lb - e0) / EPW); b.last = (int32_t)((le - 1 - e0) / EPW);
-      b.pad0 = wholeL ? 1 : 0;
-    }
-    carry[2 * w] = a;
-    carry[2 * w + 1] = b;
-    if ((cut_start || (cut_end && R0 == RL)) && whole0) {  // first row: own positions + halo before (+ halo after)
-      float M = m0, S = s0;
-      if (fb < base) sm_combine(M, S, mB, sB);
-      if (R0 == RL && fe > end) sm_combine(M, S, mA, sA);
-      sc0 = sm_exp(m0 - M) / S;
-    }
-    if (cut_end && R0 != RL && wholeL) {  // last row: own positions + halo after
-      float M = mL, S = sL;
-      sm_combine(M, S, mA, sA);
-      scL = sm_exp(mL - M) / S;
-    }
-  }
-  sc0 = __shfl(sc0, 0, kWave);
-  scL = __shfl(scL, 0, kWave);
-  sm_wave_sync();
-  // slot -> scale (1 / row sum), in place of the maxima
-  for (int k = lane; k < EPW; k += kWave) {
-    const float S = (float)ps[k] * kSmFixInv;
-    pm[k] = S > 0.f ? 1.0f / S : 0.f;
-  }
-  sm_wave_sync();
-  // ---- 4. normalise and store; positions of cut rows that were not finished here are left to the
-  // second launch
-  const bool cut0 = cut_start || (cut_end && R0 == RL), cutL = cut_end && R0 != RL;
-  const bool skip0 = cut0 && !whole0, skipL = cutL && !wholeL;
-#pragma unroll
-  for (int j = 0; j < kSmEPL; ++j) {
-    const int64_t p = base + j * kWave + lane;
-    if (p >= end) continue;
-    const bool in0 = slot[j] == 0, inL = slot[j] == sl;
-    if ((in0 && skip0) || (inL && skipL)) continue;
-    float scale = pm[slot[j]];
-    if (in0 && cut0) scale = sc0;
-    if (inL && cutL) scale = scL;
-    const float a = x[j] * scale;
-    if (out_csr) out_csr[p] = a;
-    if (out) out[eid ? eid[p] : p] = a;
-  }
-}
-
-#endif  // KGAT_SOFTMAX_SLOTS
 
 // (M, S) of a cut row from the carries of its chain: the head wavefront's `b` entry, then the `a`
 // entries of the followers head+1 .. last in blocks of 64 (ordered tree inside a block).  Every
@@ -628,32 +544,32 @@ __device__ __forceinline__ void sm_chain_total(const SmCarry* __restrict__ carry
   M = m; S = s;
 }
 
-// positions [lo, hi) of one row, 8 x 64 per step so that the loads of a step are in flight together
-template <bool IN_CSR>
-__device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float M, float S,
-                                         const int32_t* __restrict__ eid, const float* __restrict__ logits,
-                                         float* __restrict__ out, float* __restrict__ out_csr) {
+// provisional values of positions [lo, hi) of one row times f, 8 x 64 per step so that the loads of a
+// step are in flight together
+__device__ __forceinline__ void sm_rescale_span(int64_t lo, int64_t hi, int lane, float f,
+                                                const int32_t* __restrict__ eid, float* __restrict__ out,
+                                                float* __restrict__ out_csr) {
   constexpr int U = 8;
   for (int64_t p0 = lo; p0 < hi; p0 += U * kWave) {
     int64_t e[U];
     float x[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // all indices first, then all logits (see softmax_local_kernel)
+    for (int u = 0; u < U; ++u) {
       const int64_t p = p0 + u * kWave + lane;
       const int64_t pc = p < hi ? p : hi - 1;
-      e[u] = eid ? eid[pc] : pc;
+      e[u] = out ? (int64_t)eid[pc] : pc;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = p0 + u * kWave + lane;
       const int64_t pc = p < hi ? p : hi - 1;
-      x[u] = IN_CSR ? logits[pc] : logits[e[u]];
+      x[u] = out_csr ? out_csr[pc] : out[e[u]];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = p0 + u * kWave + lane;
       if (p < hi) {
-        const float a = sm_exp(x[u] - M) / S;
+        const float a = x[u] * f;
         if (out_csr) out_csr[p] = a;
         if (out) out[e[u]] = a;
       }
@@ -661,42 +577,60 @@ __device__ __forceinline__ void fix_span(int64_t lo, int64_t hi, int lane, float
   }
 }
 
-template <bool IN_CSR, int kSmEPL>
-__global__ __launch_bounds__(256) void softmax_cut_rows_kernel(
-    int64_t e0, int64_t e1, const int32_t* __restrict__ eid, const float* __restrict__ logits,
-    float* __restrict__ out, float* __restrict__ out_csr, const SmCarry* __restrict__ carry) {
+// Second launch: the rows the ranges cut.  The sweep left their positions as exp(x - m) with m the
+// range's partial maximum of the row (the carry's); here they are multiplied by exp(m - M) / S of the
+// whole row.  The common chain is two ranges long (a row crossing one boundary): its two entries are
+// this wavefront's own and its neighbour's, requested together with the first / last 64 provisional
+// values of the range - one memory round trip; longer chains (hubs) walk their entries.
+template <int kSmEPL>
+__global__ __launch_bounds__(256) void softmax_cut_rows_kernel(int64_t e0, int64_t e1,
+                                                               const int32_t* __restrict__ eid,
+                                                               float* __restrict__ out, float* __restrict__ out_csr,
+                                                               const SmCarry* __restrict__ carry) {
   constexpr int kSmEPW = SmGeom<kSmEPL>::EPW;
   const int lane = threadIdx.x % kWave;
   const int64_t w = sm_wave_index();
   const int64_t base = e0 + w * kSmEPW;
   if (base >= e1) return;
   const int64_t end = base + kSmEPW < e1 ? base + kSmEPW : e1;
-  // the cut rows sit at the two ends of the range: their first 64 positions are requested together
-  // with the carry entries (one memory round trip for the common short case)
+  const int64_t n_waves = (e1 - e0 + kSmEPW - 1) / kSmEPW;
   const SmCarry ca = carry[2 * w], cb = carry[2 * w + 1];
+  const SmCarry pv = carry[2 * (w > 0 ? w - 1 : 0) + 1], nx = carry[2 * (w + 1 < n_waves ? w + 1 : w)];
   const int64_t pa = base + lane < end ? base + lane : end - 1;
   const int64_t pb = end - 1 - lane >= base ? end - 1 - lane : base;
-  const int64_t ea = eid ? eid[pa] : pa, eb = eid ? eid[pb] : pb;
-  const float xa = IN_CSR ? logits[pa] : logits[ea], xb = IN_CSR ? logits[pb] : logits[eb];
-  if (ca.row >= 0 && !ca.pad0) {  // (pad0: the sweep saw the whole row through its halo and finished its own positions)
+  const int64_t ea = out ? (int64_t)eid[pa] : pa, eb = out ? (int64_t)eid[pb] : pb;
+  const float xa = out_csr ? out_csr[pa] : out[ea], xb = out_csr ? out_csr[pb] : out[eb];
+  if (ca.row >= 0) {
     float M, S;
-    sm_chain_total(carry, ca.head, ca.last, lane, M, S);
+    if (ca.head == w - 1 && ca.last == w) {  // (same operands, same order as the walk)
+      M = pv.m; S = pv.s;
+      sm_combine(M, S, ca.m, ca.s);
+    } else {
+      sm_chain_total(carry, ca.head, ca.last, lane, M, S);
+    }
+    const float f = sm_exp(ca.m - M) / S;
     if (lane < ca.count) {
-      const float a = sm_exp(xa - M) / S;
+      const float a = xa * f;
       if (out_csr) out_csr[pa] = a;
       if (out) out[ea] = a;
     }
-    fix_span<IN_CSR>(base + kWave, base + ca.count, lane, M, S, eid, logits, out, out_csr);
+    sm_rescale_span(base + kWave, base + ca.count, lane, f, eid, out, out_csr);
   }
-  if (cb.row >= 0 && !cb.pad0) {
+  if (cb.row >= 0) {  // (the head entry of its chain: the row starts in this range)
     float M, S;
-    sm_chain_total(carry, cb.head, cb.last, lane, M, S);
+    if (cb.last == w + 1) {
+      M = cb.m; S = cb.s;
+      sm_combine(M, S, nx.m, nx.s);
+    } else {
+      sm_chain_total(carry, cb.head, cb.last, lane, M, S);
+    }
+    const float f = sm_exp(cb.m - M) / S;
     if (lane < cb.count) {
-      const float a = sm_exp(xb - M) / S;
+      const float a = xb * f;
       if (out_csr) out_csr[pb] = a;
       if (out) out[eb] = a;
     }
-    fix_span<IN_CSR>(end - cb.count, end - kWave, lane, M, S, eid, logits, out, out_csr);
+    sm_rescale_span(end - cb.count, end - kWave, lane, f, eid, out, out_csr);
   }
 }
 
@@ -738,15 +672,13 @@ static void launch_softmax_sweep(int64_t e_begin, int64_t e_end, const int32_t* 
                                  hipStream_t st) {
   const int64_t n_waves = (e_end - e_begin + SmGeom<EPL>::EPW - 1) / SmGeom<EPL>::EPW;
   const unsigned blocks = (unsigned)((n_waves + 3) / 4);
-#ifdef KGAT_SOFTMAX_SLOTS  // A/B builds: the LDS-atomic sweep (slower, see softmax_slots_kernel)
-  hipLaunchKernelGGL((softmax_slots_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
-                     eid, logits, out, out_csr, carry);
-#else
-  hipLaunchKernelGGL((softmax_local_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, indptr, row_of,
-                     eid, logits, out, out_csr, carry);
-#endif
-  hipLaunchKernelGGL((softmax_cut_rows_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, logits,
-                     out, out_csr, (const SmCarry*)carry);
+  // the 16-byte loads / stores of the sweep's full ranges need every array it touches that way aligned
+  const uintptr_t bits = (uintptr_t)row_of | (uintptr_t)eid | (uintptr_t)out_csr | (IN_CSR ? (uintptr_t)logits : 0);
+  const int aligned = (bits % 16 == 0 && e_begin % 4 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((softmax_local_kernel<IN_CSR, EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, aligned, indptr,
+                     row_of, eid, logits, out, out_csr, carry);
+  hipLaunchKernelGGL((softmax_cut_rows_kernel<EPL>), dim3(blocks), dim3(256), 0, st, e_begin, e_end, eid, out, out_csr,
+                     (const SmCarry*)carry);
 }
 
 extern "C" {

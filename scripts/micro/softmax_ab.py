@@ -3,7 +3,11 @@
 sweep fed as the propagation path feeds it - grouped-order logits read through the CSR-position ->
 grouped-position map - and with CSR-ordered logits; variants alternate launch by launch.
 
-  python scripts/micro/softmax_ab.py "-DKGAT_SM_SMALL_EDGES=0" "-DKGAT_SOFTMAX_SLOTS"
+  python scripts/micro/softmax_ab.py "-DKGAT_SM_SMALL_EDGES=0" "src=scripts/micro/build/kgat_softmax_old.hip"
+
+A variant is a set of compiler flags for the shipped source, or src=<another source file> (e.g. an earlier
+revision saved with `git show <rev>:dgl-kgat_amd/csrc/kgat_softmax.hip`).  A torch elementwise pass over the
+same bytes (three E-sized reads, one write) is timed beside them as the stream floor of this size.
 """
 import os
 import subprocess
@@ -24,8 +28,12 @@ if not all(os.path.exists(o) for o in objs):
     _lib.build(force=True)
 for vi, flag in enumerate(variants):
     obj = "/tmp/sm_var%d.o" % vi
-    subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + _lib.SOURCES["kgat_softmax.hip"] + flag.split() +
-                          ["-c", os.path.join(_lib.CSRC, "kgat_softmax.hip"), "-o", obj])
+    src_file = os.path.join(_lib.CSRC, "kgat_softmax.hip")
+    extra = flag.split()
+    if flag.startswith("src="):
+        src_file, extra = os.path.join(ROOT, flag[4:]), []
+    subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + _lib.SOURCES["kgat_softmax.hip"] + extra +
+                          ["-c", src_file, "-o", obj])
     so = "/tmp/libkgat_hip_smvar%d.so" % vi
     subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] +
                           [obj if o.endswith("kgat_softmax.o") else o for o in objs])
@@ -61,6 +69,18 @@ for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm
                 if it >= 3:
                     res.setdefault((name, mode), []).append(a.elapsed_time(b))
                 outs[(name, mode)] = o
+    fa, fb, fc = torch.randn(3, len(trip), device=dev).unbind(0)
+    fo = torch.empty_like(fa)
+    fl = []
+    for it in range(23):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        torch.addcmul(fa, fb, fc, out=fo)
+        b.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            fl.append(a.elapsed_time(b))
+    print("%-12s %-36s %-8s median %.4f min %.4f ms" % (wl, "torch.addcmul (3 reads, 1 write)", "stream", np.median(fl), np.min(fl)))
     ref = outs[("shipped", "csr")]
     for (name, mode), v in res.items():
         o = outs[(name, mode)]
