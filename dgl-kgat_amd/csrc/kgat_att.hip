@@ -1,3 +1,4 @@
+#include <stdlib.h>
 // TransR-style attention logits for gfx950.  Rows A1 + A2 of SURVEY.md 8a.
 //
 // Replaces the per-relation loop of reference models.py:146-152

@@ -35,7 +35,7 @@ for vi, flag in enumerate(variants):
     subprocess.check_call([_lib._hipcc()] + _lib.BASE_FLAGS + _lib.SOURCES["kgat_softmax.hip"] + extra +
                           ["-c", src_file, "-o", obj])
     so = "/tmp/libkgat_hip_smvar%d.so" % vi
-    subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] +
+    subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so] +
                           [obj if o.endswith("kgat_softmax.o") else o for o in objs])
     _lib.SO_PATH, _lib._lib = so, None
     libs[flag] = _lib.load()
