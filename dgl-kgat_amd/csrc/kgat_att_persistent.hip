@@ -1026,6 +1026,11 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
 // with their indices requested one chunk ahead; their tail rows are not (the row buffer is 64
 // registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
 constexpr int kFusedThreads = 512;
+// KGAT_ATT_XCD_REMAP=1 (A/B builds): every XCD a contiguous eighth of the workgroups' tile ranges
+// (xcd_contiguous, kgat_common.h).  Within the noise at d = 64 (0.172 vs 0.176 ms), 2 % slower at d = 128.
+#ifndef KGAT_ATT_XCD_REMAP
+#define KGAT_ATT_XCD_REMAP 0
+#endif
 
 
 // X3: the two products as bf16-piece products (above); W_r's pieces sit in LDS already in fragment
@@ -1077,9 +1082,9 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   }
   const int32_t n_tiles = rel_tptr[n_rel];
   // the workgroup's contiguous tile range: cost balanced (kgat_fold_tile_parts) or equal counts
-  const int32_t t_begin = part_tptr ? part_tptr[blockIdx.x] : (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
-  const int32_t t_end = part_tptr ? part_tptr[blockIdx.x + 1]
-                                  : (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  const unsigned part = KGAT_ATT_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
+  const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
 #ifdef KGAT_ATT_STAMPS
   unsigned long long ph[5] = {0, 0, 0, 0, 0};
@@ -1893,9 +1898,9 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
     }
   }
   const int32_t n_tiles = rel_tptr[n_rel];
-  const int32_t t_begin = part_tptr ? part_tptr[blockIdx.x] : (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
-  const int32_t t_end = part_tptr ? part_tptr[blockIdx.x + 1]
-                                  : (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
+  const unsigned part = KGAT_ATT_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
+  const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
 
   struct HBuf { float a[KS]; };

@@ -228,9 +228,19 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
   __shared__ float4 s_part[NSUB][2][LPR];
   __shared__ int32_t s_row[NSUB][2];
 
+  // KGAT_SPMM_XCD_REMAP=1 (A/B builds): every XCD takes a contiguous eighth of the tiles instead of
+  // every eighth tile.  Measured slower on both CKG shapes (round 3, scripts/micro/spmm_runlen_ab.py with
+  // AB_FLAG=-DKGAT_SPMM_XCD_REMAP=1; D = 64: 0.110 vs 0.105 ms, D = 128: 0.200 vs 0.181 ms, D = 32: 0.073 vs
+  // 0.066 ms): with the round-robin placement the eight L2s work on neighbouring destination ranges at
+  // the same time and miss on the same source rows together - one fetch from the Infinity Cache serves
+  // requests that are in flight in several XCDs -, a contiguous eighth per XCD spreads the misses in time.
+#ifndef KGAT_SPMM_XCD_REMAP
+#define KGAT_SPMM_XCD_REMAP 0
+#endif
   const int tid = threadIdx.x;
   const int sub = tid / LPR, sl = tid % LPR;
-  const int64_t tile0 = e0 + (int64_t)blockIdx.x * TE;
+  const unsigned tile = KGAT_SPMM_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t tile0 = e0 + (int64_t)tile * TE;
   const int64_t tile1 = (tile0 + TE < e1) ? tile0 + TE : e1;
   const int n_tile = (int)(tile1 - tile0);
   KGAT_STAMP(0);
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
   {
     const int32_t first_row = s_rec[0].r;
     const int32_t last_row = s_rec[n_tile - 1].r;
-    float4* bp = bpart + (size_t)blockIdx.x * 2 * LPR;
+    float4* bp = bpart + (size_t)tile * 2 * LPR;
     constexpr int NE = 2 * NSUB;
     constexpr int SPW = kWave / LPR >= 1 ? kWave / LPR : 1;  // lane groups per wavefront
     constexpr int kShortSeg = 8;

@@ -24,7 +24,7 @@ for src, extra in _lib.SOURCES.items():
                                    os.path.join(_lib.CSRC, src), "-o", obj]))
 for p in procs:
     assert p.wait() == 0
-subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so] + objs)
 _lib.SO_PATH = so
 _lib._lib = None
 lib = _lib.load()

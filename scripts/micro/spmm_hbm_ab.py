@@ -30,7 +30,7 @@ for vi, flag in enumerate(variants):
     these = [obj if o.endswith("kgat_spmm.o") else o for o in objs]
     if not all(os.path.exists(o) for o in these):   # the shipped objects did not travel: rebuild them once
         _lib.build(force=True)
-    subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + these)
+    subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", so] + these)
     _lib.SO_PATH, _lib._lib = so, None
     libs[flag] = _lib.load()
 
