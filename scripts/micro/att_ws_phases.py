@@ -16,6 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from dgl_kgat_amd import _lib, ops, synth  # noqa: E402
 
+D = 64
+if len(sys.argv) > 1 and sys.argv[1].isdigit():
+    D = int(sys.argv.pop(1))
 extra_flags = sys.argv[1:]
 so = "/tmp/libkgat_hip_att_ws_stamps.so"
 tag = '-DKGAT_BUILD_HASH="kgat-src-hash:%s"' % _lib.source_hash()
@@ -36,7 +39,7 @@ lib.kgat_debug_set_att_phases.argtypes = [C.c_void_p]
 
 dev = torch.device("cuda:0")
 n, trip, R = synth.amazon_book_ckg()
-E, D = len(trip), 64
+E = len(trip)
 src = torch.as_tensor(trip[:, 2].copy(), device=dev)
 dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
 et = torch.as_tensor(trip[:, 1].copy(), device=dev)
@@ -50,12 +53,12 @@ ent = torch.randn(n, D, generator=g).to(dev)
 W = ((torch.rand(R, D, D, generator=g) - 0.5) * (2 * 1.414 * (6 / (D * D + R * D)) ** 0.5)).to(dev)
 rel = torch.randn(R, D, generator=g).to(dev)
 n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
-tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups)
+tiles, tptr, parts = ops.fold_tiles(rp, gid, gptr, n_groups, cost=ops.fold_tile_cost(D))
 fn = lambda: ops.att_score_fused(n, rp, perm, sg, idx, gid, gptr, g_node, tiles, tptr, ent, W, rel, want_eid=False,  # noqa: E731
                                  want_csr=False, want_grouped=True, part_tptr=parts, rec_g=rec)
 for _ in range(3):
     fn()
-NWAVE = 16
+NWAVE = 16 if D == 64 else 8
 ph = torch.zeros(n_wg * NWAVE * 8, dtype=torch.int64, device=dev)
 assert lib.kgat_debug_set_att_phases(ph.data_ptr()) == 0
 a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,7 +71,7 @@ a = ph.cpu().numpy().reshape(n_wg, NWAVE, 8).astype(np.float64)
 tiles_of = a[:, :, 7]
 prod = tiles_of > 0
 # producers are the waves with sections 4..6 populated
-is_p = a[:, :, 4].sum(0) > 0
+is_p = (a[:, :, 4].sum(0) > 0) if D == 64 else (np.arange(NWAVE) < 4)
 print("launch %.1f us (stamped build) flags %s" % (a0.elapsed_time(b0) * 1e3, extra_flags))
 for name, sel, labels in (("producer", is_p, ["issue", "rows+cut", "product 1", "tanh+cut", "product 2", "wait free", "park+publish"]),
                           ("consumer", ~is_p, ["issue", "wait V", "first chunk", "later chunks"])):
