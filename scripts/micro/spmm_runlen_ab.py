@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool: the merge SpMM with and without the half-length runs for mid-size launches
-(-DKGAT_SPMM_MID_LIMIT=0 disables them), alternating the two builds launch by launch on one box."""
+"""Developer tool: the shipped merge SpMM against a build with one more compiler flag (AB_FLAG; default
+-DKGAT_SPMM_MID_LIMIT=0: no half-length runs for mid-size launches; -DKGAT_SPMM_XCD_REMAP=1: every XCD a
+contiguous eighth of the tiles), alternating the two builds launch by launch on one box."""
 import ctypes as C
 import os
 import subprocess
@@ -28,7 +29,8 @@ subprocess.check_call([_lib._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC
 _lib.SO_PATH = so
 _lib._lib = None
 nomid = _lib.load()
-libs = {"half-length runs": base, "full-length runs": nomid}  # second entry: the AB_FLAG build
+AB = os.environ.get("AB_FLAG", "-DKGAT_SPMM_MID_LIMIT=0")
+libs = {"shipped": base, AB: nomid}
 
 dev = torch.device("cuda:0")
 for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm_ckg)):
@@ -53,6 +55,6 @@ for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm
                 if it >= 3:
                     res[name].append(a.elapsed_time(b))
                 outs[name] = o
-        same = torch.equal(outs["half-length runs"], outs["full-length runs"])
+        same = torch.equal(outs["shipped"], outs[AB])
         print("%-12s D=%3d  " % (wl, D) + "  ".join("%s: median %.4f min %.4f ms" % (k, np.median(v), np.min(v))
                                                     for k, v in res.items()) + "  | same bits: %s" % same)
