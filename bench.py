@@ -130,15 +130,15 @@ def hbm_resident_spmm_leg(args, dev):
     # the same bytes: fresh allocations of the same size at the same virtual address fall into a fast
     # (9.2-9.4 ms) or a slow (10.3-10.5 ms) mode, allocation by allocation (scripts/placement_study.py;
     # DESIGN.md 3.1).  A long-lived table is allocated once, so the leg does what a deployment can do
-    # once: it draws up to eight candidate allocations, times two launches on each, keeps the fastest and
-    # frees the others - and reports every candidate's time, so the slow mode is on the line too.
+    # once: it draws up to twelve candidate allocations (about one in five was fast on the boxes seen; round 3
+    # stopped after four alike and then sat in the slow mode on such a box), times two launches on each,
+    # keeps the fastest and frees the others - and reports every candidate's time, so the slow mode is on
+    # the line too.
     torch.cuda.empty_cache()
     X, trials, keep_alive = None, [], []
-    for _ in range(8):
+    for _ in range(12):
         if len(trials) >= 2 and min(trials) < 0.94 * max(trials):
             break  # both modes seen: the fastest candidate so far sits in a fast region
-        if len(trials) >= 4 and max(trials) < 1.02 * min(trials):
-            break  # four alike: this box offers one mode only
         cand = torch.empty((n, D), dtype=torch.float32, device=dev)
         cand.normal_(generator=gen)
         t_c = event_times(lambda: ops.spmm(indptr, col, row_of, cand, w, out=out, workspace=ws), 2)
