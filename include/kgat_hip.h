@@ -234,11 +234,14 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
  * Input: logits in edge-id order (logits_in_csr_order = 0; read through eid) or in CSR
  * position order (1).  Outputs (either may be NULL, not both): out in edge-id order (written
  * through eid) and out_csr in CSR order.  eid = original edge id per CSR position.
- * One sweep over the positions (rows finished inside a wavefront's 1,024-position range are
- * normalised on the spot) plus one short launch in which every wavefront combines, for the rows
- * its range cuts, the carry entries of the row's whole chain in a fixed order and normalises its
- * own positions of them.  No atomics, fixed combination order: bitwise reproducible, no bound on
- * a row's length.  indptr[N+1] is the CSR row pointer (the extent of a cut row - which
+ * One sweep over the positions (rows finished inside a wavefront's 512- or 1,024-position range
+ * are normalised on the spot; the positions of the rows the range cuts are stored as
+ * exp(s - partial max)) plus one short launch in which every wavefront combines, for the rows
+ * its range cuts, the carry entries of the row's whole chain in a fixed order and rescales its
+ * own positions of them (it reads the outputs, not the logits).  No atomics, fixed combination
+ * order: bitwise reproducible, no bound on a row's length.  Full ranges move as 16-byte loads /
+ * stores when row_of, eid, out_csr (and CSR-ordered logits) are 16-byte aligned and e_begin is a
+ * multiple of 4; otherwise position by position, same results.  indptr[N+1] is the CSR row pointer (the extent of a cut row - which
  * wavefronts hold its carries - is read from it); every row that has a position in
  * [e_begin, e_end) must lie inside it completely (true for the whole graph and for a
  * destination-range shard).  Workspace: n_edges = e_end - e_begin. */

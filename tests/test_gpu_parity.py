@@ -279,6 +279,39 @@ def test_edge_softmax_range_boundaries_and_hubs(K, dev, e):
             assert rel_err(part_csr[e0:e1].cpu().numpy(), out_csr[e0:e1].cpu().numpy()) < 1e-6, (layout, lo, hi)
 
 
+@pytest.mark.parametrize("length", [1, 2, 3, 7, 8, 9, 15, 16, 17, 24, 63, 64, 65, 120, 127, 128, 129, 136, 248, 256, 264,
+                                    511, 512, 513, 520, 1000, 1500, 5000])
+def test_edge_softmax_lane_structures(K, dev, length):
+    """Rows of one length at every alignment against the sweep's geometry: 8 positions per lane, DPP rows of
+    16 lanes (segments starting / ending at lanes 15 | 16, 31 | 32, 47 | 48), 512-position ranges (rows cut
+    once, rows spanning several ranges, a range that is one row), shifted by a prefix row of 0 .. 13
+    positions; against an fp64 segment softmax, CSR-ordered and index-mapped input giving the same bits."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(1000 + length)
+    for off in (0, 1, 5, 8, 13):
+        n_rows = max(3, min(4000 // length + 2, 700))
+        dst = np.concatenate([np.zeros(off, np.int32), np.repeat(np.arange(1, n_rows + 1, dtype=np.int32), length),
+                              np.full(3, n_rows + 2, np.int32)])  # (row n_rows + 1 has no in-edges)
+        e, n = len(dst), n_rows + 4
+        src = rng.integers(0, n, e).astype(np.int32)
+        s = (rng.standard_normal(e) * 4).astype(np.float32)
+        indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        out, out_csr = ops.edge_softmax(indptr, row_of, eid, tf(s, dev), want_out=True, want_csr=True)
+        x = s.astype(np.float64)
+        m = np.full(n, -np.inf)
+        np.maximum.at(m, dst, x)
+        ex = np.exp(x - m[dst])
+        z = np.zeros(n)
+        np.add.at(z, dst, ex)
+        ref = ex / z[dst]
+        got = out.cpu().numpy()
+        assert np.all(np.isfinite(got)) and np.max(np.abs(got - ref) / np.maximum(ref, 1e-3)) < 2e-6, (length, off)
+        assert torch.equal(out_csr, out[eid.long()])
+        _, csr_in = ops.edge_softmax(indptr, row_of, eid, ops.gather(eid, tf(s, dev)), in_csr_order=True, want_out=False,
+                                     want_csr=True)
+        assert torch.equal(csr_in, out_csr), (length, off)
+
+
 def test_edge_softmax_known_answers(K, dev):
     from dgl_kgat_amd import ops
     src = np.array([1, 2, 3, 0], np.int32)
