@@ -118,9 +118,16 @@ def one(seed):
     if ops.att_score_fused_supported(n, d, d, R):
         got["fused"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts)[0]
         stage("fused")
-        got["fused, fp32 products"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts,
-                                                          f32_products=True)[0]
-        stage("fused, fp32 products")
+        if d != 128:  # (the one-launch form at d = 128 has the bf16-piece products only)
+            got["fused, fp32 products"] = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts,
+                                                              f32_products=True)[0]
+            stage("fused, fp32 products")
+        # grouped-order output alone (the propagation path's form) gives the bits of the scattered outputs
+        rec = ops.att_pack_records(rel_ptr, gptr, gid, src_g)
+        g_only = ops.att_score_fused(*args, tiles, tptr, tf(ent), tf(W), tf(rel), part_tptr=parts, rec_g=rec, want_eid=False,
+                                     want_csr=False, want_grouped=True)[2]
+        assert torch.equal(g_only, got["fused"][perm.long()]), "grouped-order logits differ from the edge-id ordered ones"
+        stage("fused, grouped order")
     got["folded"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True)[0]
     stage("folded")
     got["folded, fp32 products"] = ops.att_score_split(*args, n_groups, tf(ent), tf(W), tf(rel), folded=True,
