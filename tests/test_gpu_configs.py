@@ -241,6 +241,89 @@ def test_config4_power_law_beyond_infinity_cache(dev):
     assert np.allclose(sums[deg > 0], 1.0, atol=2e-5)
 
 
+def test_config4_full_size_on_device(dev):
+    """configs[4] at its FULL size on one GPU - 10 M nodes / 200 M edges / R = 64, d = 64, X = 2.56 GB -, graph
+    drawn and kept on the device, every check on the device in fp64 (no host oracle finishes at this size):
+    CSR invariants; attention weights of 2,000 random destination rows against an fp64 evaluation of
+    models.py:135-154; every non-empty row's weights summing to one; the first layer's aggregation on the six
+    heaviest hubs (~10^6 in-edges each), rows without in-edges and the random rows against an fp64 gather;
+    the readout finite with unit-norm layer blocks."""
+    from dgl_kgat_amd import ops, synth
+    import dgl_kgat_amd as K
+    n, e, R, d = 10_000_000, 200_000_000, 64, 64
+    src, dst, et = synth.power_law_coo_device(n, e, R, dev, seed=11)
+    torch.manual_seed(1234)
+    model = K.KGATPropagation(n, R, input_node_dim=d, relation_dim=d, num_gnn_layers=3, n_hidden=d, dropout=0.0).to(dev)
+    g = K.DGLGraph()
+    g.add_nodes(n)
+    g.add_edges(src, dst)
+    g.readonly()
+    g.ndata["id"] = torch.arange(n, device=dev)
+    g.edata["type"] = et.long()
+    csr = g._st.csr(dev)
+    indptr, col, eid, row_of = csr.indptr, csr.col, csr.eid, csr.row_of
+    # --- structure
+    deg = (indptr[1:] - indptr[:-1]).long()
+    assert int(indptr[0]) == 0 and int(indptr[-1]) == e and int(deg.min()) >= 0
+    assert int(deg.max()) > 500_000 and int((deg == 0).sum()) > 0
+    assert torch.equal(dst.index_select(0, eid.long()), row_of) and torch.equal(src.index_select(0, eid.long()), col)
+    assert int(eid.long().sum()) == e * (e - 1) // 2 and bool((row_of[1:] >= row_of[:-1]).all())
+    with torch.no_grad():
+        a = torch.as_tensor(model.compute_attention(g)).reshape(-1)
+        g.edata["w"] = a.reshape(-1, 1)
+        out = model.gnn(g)
+    torch.cuda.synchronize()
+    a_csr = a.index_select(0, eid.long())
+    # --- every non-empty row's weights sum to one (fp64 prefix sums over the CSR order)
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(a_csr.double(), 0)])
+    row_sum = cs[indptr[1:].long()] - cs[indptr[:-1].long()]
+    assert float((row_sum[deg > 0] - 1.0).abs().max()) < 1e-4  # (a 2e8-term fp64 prefix sum: ~1e-9 per difference)
+    del cs, row_sum
+    # --- attention weights of random rows against fp64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    rows = torch.unique(torch.randint(0, n, (2000,), generator=gen, device=dev))
+    rows = rows[deg[rows] <= 4096]
+    starts, lens = indptr[rows].long(), deg[rows]
+    seg = torch.repeat_interleave(torch.arange(rows.numel(), device=dev), lens)
+    pos = torch.repeat_interleave(starts - torch.cumsum(lens, 0) + lens, lens) + torch.arange(int(lens.sum()), device=dev)
+    ed = eid[pos].long()
+    ent, W_R, rel = (model.entity_embed.weight.detach().double(), model.W_R.detach().double(),
+                     model.relation_embed.weight.detach().double())
+    et_s, t_s, h_s = et[ed].long(), ent[src[ed].long()], ent[dst[ed].long()]
+    logit = torch.zeros(ed.numel(), dtype=torch.float64, device=dev)
+    for r in range(R):
+        m = torch.nonzero(et_s == r).reshape(-1)
+        if m.numel():
+            logit[m] = ((t_s[m] @ W_R[r]) * torch.tanh(h_s[m] @ W_R[r] + rel[r])).sum(1)
+    mx = torch.full((rows.numel(),), -float("inf"), dtype=torch.float64, device=dev).scatter_reduce(0, seg, logit, "amax")
+    ex = torch.exp(logit - mx[seg])
+    a64 = ex / torch.zeros(rows.numel(), dtype=torch.float64, device=dev).index_add_(0, seg, ex)[seg]
+    err = (a_csr[pos].double() - a64).abs() / torch.clamp(a64, min=1e-3 * float(a64.max()))
+    assert float(err.max()) < 1e-4, float(err.max())                       # SURVEY 8c, elementwise
+    assert float((a_csr[pos].double() - a64).abs().max()) < 1e-5 * float(a64.max())
+    # --- first layer's aggregation: hubs, empty rows, the random rows, against an fp64 gather with the device's weights
+    X = model.entity_embed.weight.detach()
+    hn = ops.spmm(indptr, col, row_of, X, a_csr)
+    pick = torch.unique(torch.cat([torch.topk(deg, 6).indices, torch.nonzero(deg == 0).reshape(-1)[:3], rows]))
+    worst = 0.0
+    for v in pick.tolist():
+        b, en = int(indptr[v]), int(indptr[v + 1])
+        if en == b:
+            assert float(hn[v].abs().max()) == 0.0
+            continue
+        terms = a_csr[b:en].double()[:, None] * X[col[b:en].long()].double()
+        ref, mag = terms.sum(0), terms.abs().sum(0)
+        worst = max(worst, float(((hn[v].double() - ref).abs() / torch.clamp(mag, min=1e-300)).max()))
+    assert worst < 1e-5, worst   # (tests/conftest.py::sum_err: forward error of a sum of products)
+    # --- readout
+    assert out.shape == (n, 64 + 64 + 32 + 16) and bool(torch.isfinite(out).all())
+    assert torch.equal(out[:, :64], X)
+    for lo, hi in ((64, 128), (128, 160), (160, 176)):
+        nrm = out[:, lo:hi].norm(dim=1)
+        assert float(nrm.max()) < 1.0 + 1e-5 and float((nrm[nrm > 0.5] - 1.0).abs().max()) < 1e-5
+
+
 def test_attention_form_is_deterministic_across_processes(dev):
     """Two fresh processes pick the same attention form for the same graph and produce equal bits
     (the form is a function of graph statistics, not of a timing race)."""
