@@ -39,7 +39,10 @@ __device__ __forceinline__ float4 mul4(const float4& a, const float4& b) {
   return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
 
-constexpr int kSpmmThreads = 256;
+#ifndef KGAT_SPMM_THREADS
+#define KGAT_SPMM_THREADS 256  // (A/B builds.  128-thread workgroups with half-size tiles, round 3: D = 64 0.0993 vs 0.0987 ms, D = 128 0.187 vs 0.179, D = 8 0.058 vs 0.066)
+#endif
+constexpr int kSpmmThreads = KGAT_SPMM_THREADS;
 
 template <int LPR>
 struct SpmmGeom {
