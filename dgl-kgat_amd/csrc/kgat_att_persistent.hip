@@ -718,6 +718,60 @@ __device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, c
                                                  0);
 }
 
+// fp16 pieces (experiment of round 3's second half, -DKGAT_ATT_F16_SECOND=1; d <= 64 fused kernel, second product:
+// W_r * 2^shift as three fp16 pieces, the tanh values as two, five piece products).  Measured on the amazon-book
+// graph, d = 64: stand-alone 0.1555 vs 0.1614 ms, inside the step 137.3 vs 140.6 us; against fp64 max error
+// 9.98e-7 / mean 1.09e-7 (three-bf16-piece form: 9.4e-7 / 1.23e-7; fp32 MFMA: 1.48e-6 / 1.43e-7), every GPU test
+// unchanged.  NOT the default: 3 us of a 455 us step do not pay for a second arithmetic statement on the path.
+// A value inside fp16's range is h + m + l with three round-to-nearest fp16 pieces EXACTLY (3 x 11 significand
+// bits), and h + m with a residual <= 2^-22 |x|.  What the format buys is the cut: the remainder x - float(h) is
+// ONE v_fma_mix_f32 per value (f16 operand taken straight from either half of the packed register), so a pair
+// costs 4 instructions for two pieces and 7 for three, against 11 for three bf16 pieces (v_fma_mix_f32_bf16 is
+// not a gfx950 instruction).  What it costs is the exponent range: operands are scaled by a power of two first.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned hh) {  // x - float(low half of hh)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned hh) {  // x - float(high half of hh)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+  return r;
+}
+__device__ __forceinline__ void split_f16x2(const float (&x)[8], uintx4& h, uintx4& m) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned hh = cvt_pk_f16(x[2 * t], x[2 * t + 1]);
+    h[t] = hh;
+    m[t] = cvt_pk_f16(sub_f16_lo(x[2 * t], hh), sub_f16_hi(x[2 * t + 1], hh));
+  }
+}
+__device__ __forceinline__ void split_f16x3(const float (&x)[8], uintx4& h, uintx4& m, uintx4& l) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned hh = cvt_pk_f16(x[2 * t], x[2 * t + 1]);
+    const float r0 = sub_f16_lo(x[2 * t], hh), r1 = sub_f16_hi(x[2 * t + 1], hh);
+    const unsigned mm = cvt_pk_f16(r0, r1);
+    h[t] = hh;
+    m[t] = mm;
+    l[t] = cvt_pk_f16(sub_f16_lo(r0, mm), sub_f16_hi(r1, mm));
+  }
+}
+__device__ __forceinline__ floatx4 mfma_f16(const uintx4& a, const uintx4& b, const floatx4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// power of two that brings a block's largest magnitude into [2^13, 2^14) (0 for a zero / non-finite maximum)
+__device__ __forceinline__ int f16_block_shift(unsigned max_bits) {
+  const int ex = (int)(max_bits >> 23);
+  return (ex == 0 || ex == 255) ? 0 : 13 - (ex - 127);
+}
+
 // Folded head kernel for widths whose W_r does not fit the register file (d = k = 128: 64 KB).
 // One 512-thread workgroup per CU keeps the current relation's W_r in LDS, row-major with a
 // 4-float pad (bank-conflict-free for both fragment shapes: the first product reads
@@ -1066,6 +1120,11 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   __shared__ uintx4 s_a[X3 ? 2 * 3 * NFRAG : 1];
   __shared__ __attribute__((aligned(16))) float s_v[NW][16 * LDV];
   __shared__ int32_t s_next;  // next unclaimed tile of the current relation segment
+#ifndef KGAT_ATT_F16_SECOND
+#define KGAT_ATT_F16_SECOND 0
+#endif
+  constexpr bool F16B = X3 && KGAT_ATT_F16_SECOND != 0;  // second product on fp16 pieces: W_r three, tanh values two
+  __shared__ unsigned s_wmax;                             // F16B: bits of max |W_r| of the current relation
   const int tid = threadIdx.x;
   const int lane = tid % kWave, w = tid / kWave;
   const int i = lane & 15, q = lane >> 4;
@@ -1101,6 +1160,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     const int32_t rend = gptr[r + 1];
     int32_t seg_end = rel_tptr[r + 1];
     seg_end = seg_end < t_end ? seg_end : t_end;
+    if (F16B && tid == 0) s_wmax = 0u;  // (every wave has read the previous segment's value by now)
     __syncthreads();  // every wave is done with the previous relation's W_r
     if (tid == 0) s_next = t;
     if (X3) {
@@ -1125,8 +1185,15 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         const float4 w1 = *reinterpret_cast<const float4*>(W + (16 * fc + fi) * K_ + 32 * fs + 16 + 4 * fq);
         x[0] = w0.x; x[1] = w0.y; x[2] = w0.z; x[3] = w0.w;
         x[4] = w1.x; x[5] = w1.y; x[6] = w1.z; x[7] = w1.w;
-        split_bf16x3(x, h, m, l);
-        s_a[3 * NFRAG + f] = h; s_a[4 * NFRAG + f] = m; s_a[5 * NFRAG + f] = l;
+        if (F16B) {  // the fp16 images need the relation's scale first: second pass below
+          float mx = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) mx = fmaxf(mx, fabsf(x[jj]));
+          atomicMax(&s_wmax, __float_as_uint(mx));
+        } else {
+          split_bf16x3(x, h, m, l);
+          s_a[3 * NFRAG + f] = h; s_a[4 * NFRAG + f] = m; s_a[5 * NFRAG + f] = l;
+        }
       }
     } else {
       const float* W = W_R + (size_t)r * D_ * K_;
@@ -1136,6 +1203,23 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       }
     }
     __syncthreads();
+    int w_shift = 0;  // F16B: the second product runs on W_r * 2^w_shift; the logits are scaled back
+    if (F16B) {
+      w_shift = __builtin_amdgcn_readfirstlane(f16_block_shift(s_wmax));
+      const float* W = W_R + (size_t)r * D_ * K_;
+      for (int f = tid; f < NFRAG; f += kFusedThreads) {
+        const int fl = f % kWave, fs = (f / kWave) % S3, fc = f / (kWave * S3);
+        const int fi = fl & 15, fq = fl >> 4;
+        const float4 w0 = *reinterpret_cast<const float4*>(W + (16 * fc + fi) * K_ + 32 * fs + 4 * fq);
+        const float4 w1 = *reinterpret_cast<const float4*>(W + (16 * fc + fi) * K_ + 32 * fs + 16 + 4 * fq);
+        const float x[8] = {ldexpf(w0.x, w_shift), ldexpf(w0.y, w_shift), ldexpf(w0.z, w_shift), ldexpf(w0.w, w_shift),
+                            ldexpf(w1.x, w_shift), ldexpf(w1.y, w_shift), ldexpf(w1.z, w_shift), ldexpf(w1.w, w_shift)};
+        uintx4 h, m, l;
+        split_f16x3(x, h, m, l);
+        s_a[3 * NFRAG + f] = h; s_a[4 * NFRAG + f] = m; s_a[5 * NFRAG + f] = l;
+      }
+      __syncthreads();
+    }
     float relv[KT][4];
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
@@ -1240,6 +1324,21 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
           uintx4 bh, bm, bl;
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
+          if (F16B) {
+            split_f16x2(x, bh, bm);  // |tanh| < 1: inside fp16's range as it is
+#pragma unroll
+            for (int c2 = 0; c2 < KT; ++c2) {  // five piece products, smallest first
+              const uintx4 ah = fa[0 * NFRAG + (c2 * S3 + s) * kWave];
+              const uintx4 am = fa[1 * NFRAG + (c2 * S3 + s) * kWave];
+              const uintx4 al = fa[2 * NFRAG + (c2 * S3 + s) * kWave];
+              v[c2] = mfma_f16(al, bh, v[c2]);
+              v[c2] = mfma_f16(am, bm, v[c2]);
+              v[c2] = mfma_f16(am, bh, v[c2]);
+              v[c2] = mfma_f16(ah, bm, v[c2]);
+              v[c2] = mfma_f16(ah, bh, v[c2]);
+            }
+            continue;
+          }
           split_bf16x3(x, bh, bm, bl);
 #pragma unroll
           for (int c2 = 0; c2 < KT; ++c2) {
@@ -1298,6 +1397,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
         mine = li == s ? d : mine;
       }
+      if (F16B) mine = ldexpf(mine, -w_shift);  // (V rows are those of W_r * 2^w_shift)
       if (p0 + lane < pe) {
         if (LOGITS_EID) logits[c.oe] = mine;
         if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;
