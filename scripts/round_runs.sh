@@ -31,7 +31,7 @@ python scripts/error_attribution.py --seed 3 --nodes 400,600,500 --kg 15000 --uv
 scripts/micro/build/gather_modes > $O/gather_modes.txt 2>&1
 # experiments kept as records: XCD-contiguous tile mapping, wave roles in the attention kernels, softmax variants
 AB_FLAG=-DKGAT_SPMM_XCD_REMAP=1 python scripts/micro/spmm_runlen_ab.py > $O/xcd_remap_ab.txt 2>&1
-python scripts/micro/att_variants_ab.py --dim 64 --costs 64,38,1051 --rounds 10 -- "-DKGAT_ATT_XCD_REMAP=1" "-DKGAT_ATT_WAVE_ROLES" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_ABLATE=1" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_ABLATE=2" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_PRODUCERS=4" > $O/att_wave_roles.txt 2>&1
+python scripts/micro/att_variants_ab.py --dim 64 --costs 64,38,1051 --rounds 10 -- "-DKGAT_ATT_XCD_REMAP=1" "-DKGAT_ATT_F16_SECOND=1" "-DKGAT_ATT_WAVE_ROLES" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_ABLATE=1" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_ABLATE=2" "-DKGAT_ATT_WAVE_ROLES -DKGAT_WS_PRODUCERS=4" > $O/att_wave_roles.txt 2>&1
 python scripts/micro/att_variants_ab.py --dim 128 --costs 64,12,700 --rounds 8 -- "-DKGAT_ATT_XCD_REMAP=1" "-DKGAT_ATT_WAVE_ROLES" "-DKGAT_F128_PASSES=1" >> $O/att_wave_roles.txt 2>&1
 python scripts/micro/att_ws_phases.py 64 >> $O/att_wave_roles.txt 2>&1
 python scripts/micro/att_ws_phases.py 128 >> $O/att_wave_roles.txt 2>&1
