@@ -44,9 +44,16 @@ __device__ __forceinline__ float4 mul4(const float4& a, const float4& b) {
 #endif
 constexpr int kSpmmThreads = KGAT_SPMM_THREADS;
 
+// Threads per workgroup of the kernels that are laid out in lane groups of LPR lanes.  D <= 8 (two lanes per
+// row and fewer): 128 - a 256-thread workgroup holds 128 runs there, i.e. 256 run partials to combine per
+// tile; halving the workgroup (not the run length, which was tried and lost) took the D = 8 launch on the
+// last-fm graph from 0.066 to 0.058 ms (round 3, AB_FLAG=-DKGAT_SPMM_THREADS=128).  Wider rows: no gain.
+constexpr int spmm_threads(int lpr) { return (lpr <= 2 && kSpmmThreads == 256) ? 128 : kSpmmThreads; }
+
 template <int LPR>
 struct SpmmGeom {
-  static constexpr int NSUB = kSpmmThreads / LPR;  // subgroups per workgroup
+  static constexpr int THREADS = spmm_threads(LPR);
+  static constexpr int NSUB = THREADS / LPR;  // subgroups per workgroup
   static constexpr int U = LPR >= 4 ? 4 : LPR;     // X-row loads in flight per subgroup
 };
 
@@ -72,7 +79,7 @@ __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4
 }
 
 template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
-__global__ __launch_bounds__(kSpmmThreads) void spmm_merge_kernel(
+__global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge_kernel(
     int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
     const int32_t* __restrict__ row_of, const int32_t* __restrict__ eid,
     const float4* __restrict__ X, const float* __restrict__ w, float4* __restrict__ out,
@@ -213,7 +220,7 @@ struct alignas(16) EdgeRec {
 };
 
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false>
-__global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
+__global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
     const int32_t* __restrict__ row_of, const float4* __restrict__ X, const float* __restrict__ w,
     float4* __restrict__ out, float4* __restrict__ bpart, const SelfCopy sc) {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
   const int n_tile = (int)(tile1 - tile0);
   KGAT_STAMP(0);
 
-  for (int k = tid; k < TE; k += kSpmmThreads) {
+  for (int k = tid; k < TE; k += SpmmGeom<LPR>::THREADS) {
     EdgeRec rec;
     if (k < n_tile) {
       const int64_t p = tile0 + k;
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_merge2_kernel(
 // LANE, tried next, serialised up to 64 latency-bound chains in a wave: 9 -> 30 us on the
 // amazon-book graph.)
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false>
-__global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
+__global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_finish_kernel(
     int64_t e0, int64_t e1, int32_t row0, int32_t n_rows, int32_t n_tiles,
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ row_of,
     const float4* __restrict__ X, float4* __restrict__ out, const float4* __restrict__ bpart,
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
   constexpr int NSUB = SpmmGeom<LPR>::NSUB;
   constexpr int TE = NSUB * C;
   constexpr int SPW = kWave / LPR >= 1 ? kWave / LPR : 1;  // subgroups per wave
-  constexpr int WPB = kSpmmThreads / kWave;
+  constexpr int WPB = SpmmGeom<LPR>::THREADS / kWave;
   constexpr int kLongChain = 8;
   const int tid = threadIdx.x;
   if ((int32_t)blockIdx.x < fix_blocks) {
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_finish_kernel(
 // reference formulation on the device and as an A/B arm for the merge kernel; long rows
 // serialise on one subgroup.
 template <int LPR, bool MUL_SELF, bool HAS_EID>
-__global__ __launch_bounds__(kSpmmThreads) void spmm_rows_kernel(
+__global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_rows_kernel(
     int32_t n_rows, int32_t row0, const int32_t* __restrict__ indptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
     const int32_t* __restrict__ order, const float4* __restrict__ X, const float* __restrict__ w,
@@ -710,22 +717,23 @@ static int launch_merge_c(const SpmmArgs& a) {
   if (tiles > 0) {
     if (!HAS_EID && a.algo != KGAT_SPMM_ALGO_MERGE1) {
       hipLaunchKernelGGL((spmm_merge2_kernel<LPR, C, MUL_SELF, COPY_SELF>), dim3((unsigned)tiles),
-                         dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
+                         dim3(SpmmGeom<LPR>::THREADS), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
                          (const float4*)a.X, a.w, (float4*)a.out, bpart, sc);
     } else {
       hipLaunchKernelGGL((spmm_merge_kernel<LPR, C, MUL_SELF, HAS_EID>), dim3((unsigned)tiles),
-                         dim3(kSpmmThreads), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
+                         dim3(SpmmGeom<LPR>::THREADS), 0, a.st, e0, e1, (int32_t)a.row0, a.col, a.row_of,
                          a.eid, (const float4*)a.X, a.w, (float4*)a.out, bpart);
     }
     KGAT_CHECK_LAUNCH("spmm_merge");
   }
-  constexpr int kItemsPerBlock = (kSpmmThreads / kWave) * (kWave / LPR >= 1 ? kWave / LPR : 1);  // one per lane group
+  constexpr int kThreads = SpmmGeom<LPR>::THREADS;
+  constexpr int kItemsPerBlock = (kThreads / kWave) * (kWave / LPR >= 1 ? kWave / LPR : 1);  // one per lane group
   const int32_t fix_blocks = (int32_t)((tiles * 2 + kItemsPerBlock - 1) / kItemsPerBlock);
-  int64_t nz_blocks = (a.n_rows + kSpmmThreads - 1) / kSpmmThreads;  // one lane per row
+  int64_t nz_blocks = (a.n_rows + kThreads - 1) / kThreads;  // one lane per row
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
   hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF, COPY_SELF>),
-                     dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kSpmmThreads), 0, a.st, e0, e1,
+                     dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
                      (const float4*)a.X, (float4*)a.out, (const float4*)bpart, fix_blocks, sc);
   KGAT_CHECK_LAUNCH("spmm_finish");
@@ -745,7 +753,7 @@ template <int LPR, bool MUL_SELF, bool HAS_EID>
 static int launch_rows(const SpmmArgs& a) {
   const int64_t blocks = (a.n_rows + SpmmGeom<LPR>::NSUB - 1) / SpmmGeom<LPR>::NSUB;
   hipLaunchKernelGGL((spmm_rows_kernel<LPR, MUL_SELF, HAS_EID>), dim3((unsigned)blocks),
-                     dim3(kSpmmThreads), 0, a.st, (int32_t)a.n_rows, (int32_t)a.row0, a.indptr,
+                     dim3(SpmmGeom<LPR>::THREADS), 0, a.st, (int32_t)a.n_rows, (int32_t)a.row0, a.indptr,
                      a.col, a.eid, a.order, (const float4*)a.X, a.w, (float4*)a.out);
   KGAT_CHECK_LAUNCH("spmm_rows");
   return KGAT_OK;
@@ -824,7 +832,7 @@ int kgat_debug_set_spmm_stamps(void* dev_ptr) {
 size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   const int lpr = lpr_for(D);
   if (lpr == 0 || n_edges <= 0) return 256;
-  const int nsub = kSpmmThreads / lpr;
+  const int nsub = spmm_threads(lpr) / lpr;
   const int64_t te = (int64_t)nsub * run_len(lpr), te_s = (int64_t)nsub * short_run_len(lpr);
   const int64_t te_m = (int64_t)nsub * mid_run_len(lpr);
   int64_t tiles = (n_edges + te - 1) / te;
