@@ -303,7 +303,9 @@ int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t
  * produced by the aggregation with KGAT_SPMM_MUL_SELF), W2 = res_fc_2.weight (d_out x d_in).
  * h_out (n_rows x d_out, may be NULL) receives Z (the input of the next layer); norm_out (may
  * be NULL) receives Z / max(||Z_row||_2, 1e-12) with row stride norm_stride floats (a column
- * slice of the concatenated output).  Widths: see kgat_bi_interaction_supported. */
+ * slice of the concatenated output).  Widths (kgat_bi_interaction_supported): d_in, d_out in
+ * {16, 32, 64, 128} (MFMA kernel), or one of them in {4, 8} with the other in {4, 8, 16, 32} (one
+ * lane per row). */
 int kgat_bi_interaction_supported(int d_in, int d_out);
 int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P, const float* W2,
                             float negative_slope, float* h_out, float* norm_out,
