@@ -42,11 +42,25 @@ for vi, flag in enumerate(variants):
 _lib._lib = base
 
 dev = torch.device("cuda:0")
-for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm_ckg)):
+
+
+def _power_law():  # SOFTMAX_AB_WORKLOAD=power-law: the 10 M / 200 M graph drawn on the device (16 positions per lane by default)
+    n = 10_000_000
+    s_, d_, t_ = synth.power_law_coo_device(n, 200_000_000, 64, dev)
+    return n, (s_, d_, t_), 64
+
+
+workloads = ((("power-law", _power_law),) if os.environ.get("SOFTMAX_AB_WORKLOAD") == "power-law"
+             else (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm_ckg)))
+for wl, mk in workloads:
     n, trip, R = mk()
-    src = torch.as_tensor(trip[:, 2].copy(), device=dev)
-    dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
-    et = torch.as_tensor(trip[:, 1].copy(), device=dev)
+    if isinstance(trip, tuple):
+        src, dst, et = trip
+        trip = src  # (only its length is used below)
+    else:
+        src = torch.as_tensor(trip[:, 2].copy(), device=dev)
+        dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
+        et = torch.as_tensor(trip[:, 1].copy(), device=dev)
     indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
     rp, idx = ops.group_by_relation(ops.gather(eid, et), R)
     gpos = ops.invert_permutation(idx)           # grouped position of every CSR position
