@@ -76,7 +76,19 @@ class KGATConv(nn.Module):
             if torch.is_grad_enabled() and (nfeat.requires_grad or self.res_fc_2.weight.requires_grad):
                 # differentiable shard layer (partition._ShardConv): local backward + all-reduce of the
                 # gradients of the replicated operands; dropout is its hash mask, drawn on global rows
+                from . import ops
+                from .graph import DGLError
                 from .partition import shard_conv
+                # the shard layer treats the edge weights as constants (kgat.py:142-144 computes them under
+                # no_grad) and runs the fused bi-interaction kernels: refuse what it cannot differentiate
+                # instead of dropping a gradient or failing inside autograd
+                if g.edata["w"].requires_grad:
+                    raise DGLError("KGATConv on a shard does not differentiate through the edge weights "
+                                   "(g.edata['w'].requires_grad is True): detach them, or use the unsharded graph")
+                lin = self.res_fc_2
+                if not ops.bi_interaction_supported(lin.in_features, lin.out_features):
+                    raise DGLError("KGATConv on a shard under autograd supports the bi-interaction kernel's widths "
+                                   "only; got %d -> %d" % (lin.in_features, lin.out_features))
                 p = self.mess_drop.p if self.training else 0.0
                 if seed is None:
                     seed = int(torch.empty((), dtype=torch.int64).random_()) if p > 0 else 0

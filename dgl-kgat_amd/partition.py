@@ -87,16 +87,28 @@ class Partition:
       slices the RCCL backend runs the per-owner broadcasts as ONE group (concurrent, a direct
       link per pair).  Backends that insist on equal slice sizes (gloo) only take it for an even
       split of the rows.
-    All of them leave the same bits in the buffer."""
+    All of them leave the same bits in the buffer.
 
-    def __init__(self, rank, world, bounds, n_nodes, group=None, mode=None):
+    ``force_collectives`` (default from ``KGAT_FORCE_COLLECTIVES``): issue every collective even in a
+    one-rank group, where each is an identity - the way to push all the exchange forms (and the
+    gradient all-reduces of `_ShardConv.backward`) through RCCL on a box with one GPU."""
+
+    def __init__(self, rank, world, bounds, n_nodes, group=None, mode=None, force_collectives=None):
         self.rank, self.world, self.bounds, self.n_nodes, self.group = rank, world, list(bounds), n_nodes, group
+        if force_collectives is None:
+            force_collectives = os.environ.get("KGAT_FORCE_COLLECTIVES", "") not in ("", "0")
+        self.force_collectives = bool(force_collectives)
         self.lo, self.hi = bounds[rank], bounds[rank + 1]
         self.mode = mode or os.environ.get("KGAT_EXCHANGE", "allreduce")
         if self.mode not in EXCHANGE_MODES:
             raise ValueError("exchange mode %r is not one of %s" % (self.mode, EXCHANGE_MODES))
         self.exchange_enabled = True  # False: the collective is skipped (local-time probes on one GPU)
         self._bufs = {}
+
+    @property
+    def collectives_on(self):
+        """Whether `assemble` / the backward's gradient sums issue collectives at all."""
+        return (self.world > 1 or self.force_collectives) and self.exchange_enabled
 
     def _global_rank(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -113,7 +125,7 @@ class Partition:
             full = self._bufs.get(key)
             if full is None:
                 full = self._bufs[key] = torch.empty((self.n_nodes, width), dtype=dtype, device=device)
-        if self.mode == "allreduce" and self.world > 1:
+        if self.mode == "allreduce" and (self.world > 1 or self.force_collectives):
             full[:self.lo].zero_()
             full[self.hi:].zero_()
         return full
@@ -121,7 +133,7 @@ class Partition:
     def assemble(self, full):
         """Complete `full` (N x width, this rank's rows already in place) with the other ranks'
         rows, in place."""
-        if self.world == 1 or not self.exchange_enabled:
+        if not self.collectives_on:
             return full
         b = self.bounds
         if self.mode == "allreduce":
@@ -189,7 +201,7 @@ class Partition:
         return self.assemble(full)
 
 
-def shard_graph(g, rank, world, group=None, bounds=None, row_weight=None, mode=None):
+def shard_graph(g, rank, world, group=None, bounds=None, row_weight=None, mode=None, force_collectives=None):
     """The rank's shard of `g`: all nodes, the edges whose destination lies in the rank's row
     range (global edge-id order kept), edge features sliced accordingly.  Returns the shard
     (with ``.partition`` set) and the global ids of its edges.  A graph whose edge list lives on a
@@ -203,7 +215,7 @@ def shard_graph(g, rank, world, group=None, bounds=None, row_weight=None, mode=N
         src, dst = st.coo(dev)
         if bounds is None:
             bounds = balanced_row_bounds_device(dst, st.n_nodes, world, _row_weight(row_weight))
-        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode)
+        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode, force_collectives=force_collectives)
         keep = torch.nonzero((dst >= part.lo) & (dst < part.hi)).reshape(-1)
         sg = DGLGraph()
         sg.add_nodes(st.n_nodes)
@@ -213,7 +225,7 @@ def shard_graph(g, rank, world, group=None, bounds=None, row_weight=None, mode=N
     else:
         if bounds is None:
             bounds = balanced_row_bounds(np.bincount(st._dst, minlength=st.n_nodes), world, _row_weight(row_weight))
-        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode)
+        part = Partition(rank, world, bounds, st.n_nodes, group, mode=mode, force_collectives=force_collectives)
         keep = np.nonzero((st._dst >= part.lo) & (st._dst < part.hi))[0]
         sg = DGLGraph()
         sg.add_nodes(st.n_nodes)
@@ -291,7 +303,7 @@ class _ShardConv(torch.autograd.Function):
                 t_full[lo:hi] = t
                 gh = ops.spmm(rev.indptr, rev.col, rev.row_of, t_full, st.rev_weights(ctx.ew))
                 gh[lo:hi] += g_b
-        if part.world > 1 and part.exchange_enabled:
+        if part.collectives_on:
             if need_h:
                 dist.all_reduce(gh, op=dist.ReduceOp.SUM, group=part.group)
             if need_w:

@@ -507,6 +507,42 @@ def test_accelerate_reference_shaped_model(dev):
     assert m.entity_embed.weight.grad is not None and float(m.layers[0].res_fc_2.weight.grad.abs().sum()) > 0
 
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _run_ranks(script, world, tmp_path, extra_env=None, timeout=600):
+    """Start `world` copies of `script` (RANK = 0..world-1) on a free rendezvous port, their output
+    going to files (a rank blocked on a full pipe while its peer waits in a collective would hang the
+    test), and require exit code 0 of each."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("KGAT_EXCHANGE", None)
+    env.update(extra_env or {})
+    logs = [tmp_path / ("rank%d.log" % r) for r in range(world)]
+    procs = []
+    for r in range(world):
+        with open(logs[r], "wb") as fh:
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=fh,
+                                          stderr=subprocess.STDOUT))
+    try:
+        for p_ in procs:
+            p_.wait(timeout=timeout)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    for p_, log in zip(procs, logs):
+        assert p_.returncode == 0, log.read_text()[-3000:]
+    return [log.read_text() for log in logs]
+
 _RANK_WORKER = r"""
 import os, sys, hashlib, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
@@ -548,19 +584,10 @@ def test_two_ranks_sharded_forward_over_gloo_on_one_gpu(dev, tmp_path):
     """The N > 1 forward path with real kernels: two processes share cuda:0, exchange layer outputs
     over gloo (all-reduce and per-owner broadcast forms) and must both end with the unsharded
     readout, bit-identical across ranks and across repeated passes."""
-    import os
-    import subprocess
-    import sys
     from conftest import ROOT
     script = tmp_path / "rank_worker.py"
     script.write_text(_RANK_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
-    env.pop("KGAT_EXCHANGE", None)
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+    _run_ranks(script, 2, tmp_path)
 
 
 _GRAD_WORKER = r"""
@@ -614,16 +641,106 @@ def test_two_ranks_sharded_backward_matches_one_gpu_gradients(dev, tmp_path):
     one-GPU fused training stack's to 1e-5 of each tensor's scale - with dropout off and with
     dropout 0.1 (the hash mask is drawn on global rows, so the shards reproduce the one-GPU mask) -
     and both ranks end with the same gradients."""
-    import os
-    import subprocess
-    import sys
     from conftest import ROOT
     script = tmp_path / "grad_worker.py"
     script.write_text(_GRAD_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", WORLD_SIZE="2")
-    env.pop("KGAT_EXCHANGE", None)
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+    _run_ranks(script, 2, tmp_path)
+
+
+_RCCL_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import dgl_kgat_amd as K
+from dgl_kgat_amd import partition, synth
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+n, trip, R = synth.amazon_book_ckg(scale=0.05)
+torch.manual_seed(1234)
+model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+g = synth.build_graph(n, trip, dev)
+with torch.no_grad():
+    g.edata["w"] = model.compute_attention(g)
+    ref = model.gnn(g)
+
+# 1. every exchange form of Partition.assemble as RCCL calls (a one-rank group: each is an identity,
+#    but the call goes through the communicator: all_reduce of the padded buffer, all_gather into a
+#    list of row-slice views, per-owner broadcast, grouped send/recv with no peers)
+src = torch.randn(n, 64, device=dev)
+for mode in partition.EXCHANGE_MODES:
+    q = partition.Partition(0, 1, [0, n], n, None, mode=mode, force_collectives=True)
+    assert q.collectives_on
+    full = q.new_buffer(64, dev)
+    full[q.lo:q.hi] = src
+    got = q.assemble(full)
+    torch.cuda.synchronize()
+    assert torch.equal(got, src), mode
+# ... and with an owned range that is a strict sub-range (the zeroed halves of the all-reduce buffer)
+q = partition.Partition(0, 1, [n // 4, n // 2], n, None, mode="allreduce", force_collectives=True)
+full = q.new_buffer(32, dev)
+full[q.lo:q.hi] = src[q.lo:q.hi, :32]
+q.assemble(full)
+assert torch.equal(full[q.lo:q.hi], src[q.lo:q.hi, :32]) and not full[:q.lo].any() and not full[q.hi:].any()
+
+# 2. the sharded forward through RCCL, every mode
+with torch.no_grad():
+    for mode in partition.EXCHANGE_MODES:
+        sg, keep = partition.shard_graph(g, 0, 1, mode=mode, force_collectives=True)
+        sg.edata["w"] = model.compute_attention(sg)
+        assert torch.equal(sg.edata["w"].reshape(-1), g.edata["w"].reshape(-1))
+        out = model.gnn(sg)
+        # the shard path normalises in the readout launch instead of the bi-interaction's epilogue: the
+        # same bar as the two-rank gloo test against the unsharded pass, the same BITS across the modes
+        assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (mode, float((out - ref).abs().max()))
+        first = out if mode == partition.EXCHANGE_MODES[0] else first
+        assert torch.equal(out, first), mode
+print("forward ok: modes", partition.EXCHANGE_MODES)
+
+# 3. shard_conv backward (all_reduce of grad_h and grad_W2 through RCCL) against the one-GPU training stack
+model.train()
+users = torch.arange(0, 4000, device=dev) %% n
+pos, neg = (users * 7 + 3) %% n, (users * 13 + 5) %% n
+def grads(graph):
+    model.zero_grad()
+    torch.manual_seed(5)
+    loss = model.get_loss(model.gnn(graph), users, pos, neg)
+    loss.backward()
+    return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+loss1, g1 = grads(g)
+sg, keep = partition.shard_graph(g, 0, 1, mode="allreduce", force_collectives=True)
+with torch.no_grad():
+    sg.edata["w"] = model.compute_attention(sg)
+lossP, gP = grads(sg)
+assert abs(loss1 - lossP) <= 1e-6 * abs(loss1), (loss1, lossP)
+assert set(g1) == set(gP) and "entity_embed.weight" in g1
+for k in g1:
+    scale = float(g1[k].abs().max())
+    err = float((g1[k] - gP[k]).abs().max())
+    assert scale > 0 and err <= 1e-5 * scale, (k, err, scale)
+print("backward ok")
+# which RCCL is mapped into this process
+with open("/proc/self/maps") as fh:
+    libs = sorted({ln.split()[-1] for ln in fh if "rccl" in ln or "nccl" in ln})
+print("rccl libraries mapped:", libs)
+assert libs, "no RCCL library mapped into the process"
+dist.barrier()
+dist.destroy_process_group()
+print("rank 0 ok")
+"""
+
+
+def test_one_rank_rccl_group_runs_every_collective_form(dev, tmp_path):
+    """SURVEY 8e on the one GPU a build box has: a world-size-1 `nccl` (= RCCL) process group with
+    `force_collectives`, so that every collective of the multi-GPU path is an actual RCCL call -
+    all four `Partition.assemble` forms (all_reduce of the zero-padded buffer, all_gather into
+    unequal-slice views, per-owner broadcast, batch_isend_irecv with no peers), the sharded forward of
+    every mode (the same bits in every mode, within 2e-6 of the unsharded readout) and `_ShardConv.backward`'s gradient all-reduces
+    (gradients equal to the one-GPU training stack's).  Runs in a child process: a stalled collective
+    fails the test at the timeout instead of hanging the suite."""
+    from conftest import ROOT
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % ROOT)
+    out = _run_ranks(script, 1, tmp_path, timeout=600)[0]
+    print(out[-1500:])
+    assert "forward ok" in out and "backward ok" in out and "rccl" in out.lower()
