@@ -16,6 +16,7 @@ SO_PATH = os.path.join(_HERE, "libkgat_hip.so")
 SOURCES = {
     "kgat_graph.hip": [],
     "kgat_spmm.hip": [],
+    "kgat_spmm_bi.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "kgat_softmax.hip": [],
     "kgat_att.hip": [],
     "kgat_att_persistent.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -66,6 +67,9 @@ SIGNATURES = {
     "kgat_spmm_umule_sum_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
                                        _p, _sz, _u32, _i32, _p, _i64, _p]),
     "kgat_bi_interaction_supported": (_i32, [_i32, _i32]),
+    "kgat_spmm_bi_fused_supported": (_i32, [_i32, _i32]),
+    "kgat_spmm_bi_fused_f32": (_i32, [_i64, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,
+                                      _i64, _p, _p, _sz, _p, _i64, _p]),
     "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _i64, _p,
                                              _p, _i64, _p]),
     "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _i64,

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   // W2's fragments live in registers for the whole launch - except at 128 x 128, where they would
   // need 256 VGPRs: there every MFMA takes its fragment from the LDS copy (one conflict-free
   // ds_read_b32 each)
-  constexpr bool W_IN_LDS = KS * KT > 128;
+#ifndef KGAT_BI_W_LDS_ABOVE
+#define KGAT_BI_W_LDS_ABOVE 128  // (A/B builds: 0 = fragments always from LDS, fewer registers, more wavefronts per SIMD)
+#endif
+  constexpr bool W_IN_LDS = KS * KT > KGAT_BI_W_LDS_ABOVE;
   float wreg[W_IN_LDS ? 1 : KS][W_IN_LDS ? 1 : KT];
   if (!W_IN_LDS) {
 #pragma unroll
@@ -122,9 +125,13 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             W_IN_LDS ? s_w[(s * KT + c) * kWave + lane] : wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c], a[s], acc[c], 0, 0, 0);
     const int32_t row = row0 + i;
+    // row norm: per 16-column tile the sum of squares over the row's four lanes (i, q = 0..3), then the tiles'
+    // partials in tile order - the order of the fused aggregation + dense launch (kgat_spmm_impl.h: tile_ssq),
+    // whose wavefronts each own one column tile, so the two paths give the same bits
     float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < KT; ++c)
+    for (int c = 0; c < KT; ++c) {
+      float part = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float z = acc[c][j];
@@ -133,11 +140,12 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
           z = drop_keep(seed, index0 + (uint32_t)row * (uint32_t)DO + (uint32_t)(16 * c + 4 * q + j), drop_threshold)
                   ? z * keep_scale : 0.f;
         acc[c][j] = z;
-        ss = fmaf(z, z, ss);
+        part = j == 0 ? z * z : fmaf(z, z, part);
       }
-    // the four lanes (i, q = 0..3) of a row hold its 4 x KT column groups
-    ss += __shfl_xor(ss, 16, kWave);
-    ss += __shfl_xor(ss, 32, kWave);
+      part += __shfl_xor(part, 16, kWave);
+      part += __shfl_xor(part, 32, kWave);
+      ss = c == 0 ? part : ss + part;
+    }
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // one division per row; the 4 x KT values are scaled by it
     if (row < n_rows) {
 #pragma unroll
@@ -156,15 +164,27 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     }
   };
 
-  // rows of the next tile are requested before the current tile is computed
-  float a0[KS], a1[KS];
-  load_a(t_begin, a0);
-  for (int32_t t = t_begin; t < t_end; t += 2) {
-    load_a(t + 1 < t_end ? t + 1 : t, a1);
-    tile(t, a0);
-    if (t + 1 >= t_end) break;
-    load_a(t + 2 < t_end ? t + 2 : t + 1, a0);
-    tile(t + 1, a1);
+  // The rows of the next PF - 1 tiles are requested before a tile is computed.  Round 4 tried a deeper ring (PF = 4,
+  // the grid of two workgroups per CU leaves the registers free), W2's fragments from LDS instead of registers
+  // with 4 and 8 workgroups per CU, and a 1,024-block grid: 30.7-35.7 us against 31.0 at 64 -> 64, 18.1-20.1
+  // against 19.0 at 64 -> 32, 13.7-14.0 against 13.9 at 32 -> 16 (profiles/r04_bi_probe.txt) - the launch is not
+  // bound by the latency of its row fetches, nor by resident wavefronts; dropping either output saves 4-5 us.
+#ifndef KGAT_BI_PREFETCH
+#define KGAT_BI_PREFETCH 2
+#endif
+  constexpr int PF = KS * KGAT_BI_PREFETCH <= 64 ? KGAT_BI_PREFETCH : (64 / KS >= 2 ? 64 / KS : 2);  // <= 64 VGPRs of rows in flight
+  float a[PF][KS];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (t_begin + p < t_end) load_a(t_begin + p, a[p]);
+  for (int32_t t = t_begin; t < t_end; t += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      if (t + p < t_end) {
+        tile(t + p, a[p]);
+        if (t + p + PF < t_end) load_a(t + p + PF, a[p]);
+      }
+    }
   }
 }
 
@@ -304,7 +324,10 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
                      const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st) {
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
-  if (blocks > 512) blocks = 512;    // ... two workgroups per CU (each stages W2 once; measured 256: 22.7, 512: 21.2, 1024: 22.1, 2048: 24.1 us avg)
+#ifndef KGAT_BI_MAX_BLOCKS
+#define KGAT_BI_MAX_BLOCKS 512
+#endif
+  if (blocks > KGAT_BI_MAX_BLOCKS) blocks = KGAT_BI_MAX_BLOCKS;    // ... two workgroups per CU (each stages W2 once; measured 256: 22.7, 512: 21.2, 1024: 22.1, 2048: 24.1 us avg)
   // 16-byte stores into the normalised copy need its slice 16-byte aligned with a row stride that keeps it so
   const bool vec = norm_out == nullptr ||
                    ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);

@@ -236,17 +236,35 @@ class KGATPropagation(nn.Module):
         # the attention launch of the next step by 3.5 us because the pass no longer ends on the embedding
         # table).  KGAT_GNN_COPY_SELF=0 restores the separate copy.
         copy_self = os.environ.get("KGAT_GNN_COPY_SELF", "1") not in ("", "0") and widths[0] % 4 == 0
+        # KGAT_FUSE_BI=1: aggregation and dense part of a layer in ONE launch where the widths allow
+        # (kgat_spmm_bi_fused_f32: the rows h * h_N stay with the workgroup that completed them; same bits as the
+        # two launches).  Off by default: measured 3-4 % SLOWER per layer than the two launches on the benchmark
+        # graph (119.7 vs 116.4 us at 64 -> 64, profiles/r04_fused_bi_ab.txt) - the dense tail
+        # keeps a workgroup's gather slots idle, which costs the latency-bound aggregation more than the 82 MB
+        # round trip of h * h_N costs the separate launch.
+        fuse_bi = os.environ.get("KGAT_FUSE_BI", "0") not in ("", "0")
         st = g._st
+        scratch = None
         for li, layer in enumerate(self.layers):
+            last = li + 1 == len(self.layers)
+            norm_out = out[:, off:off + widths[li + 1]]
+            if (fuse_bi and ops.spmm_bi_fused_supported(widths[li], widths[li + 1]) and off % 4 == 0 and
+                    out.shape[1] % 4 == 0 and h.shape[0] > 0):
+                csr = st.csr(h.device)
+                if scratch is None or scratch.shape[1] != widths[li]:
+                    scratch = torch.empty((h.shape[0], widths[li]), dtype=torch.float32, device=h.device)
+                h = ops.spmm_bi_fused(csr.indptr, csr.col, csr.row_of, h.contiguous(), st.csr_weights(w),
+                                      layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out, want_h=not last,
+                                      scratch=scratch, self_out=out[:, :widths[0]] if (li == 0 and copy_self) else None)
+                off += widths[li + 1]
+                continue
             if li == 0 and copy_self:
                 csr = st.csr(h.device)
                 prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.contiguous(), st.csr_weights(w), mul_self=True,
                                 self_out=out[:, :widths[0]])
             else:
                 prod = u_mul_e_sum(g, h, w, mul_self=True)
-            last = li + 1 == len(self.layers)
-            h = ops.bi_interaction(prod, layer.res_fc_2.weight.detach(), 0.01,
-                                   norm_out=out[:, off:off + widths[li + 1]], want_h=not last)
+            h = ops.bi_interaction(prod, layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out, want_h=not last)
             off += widths[li + 1]
         # the ego-embedding block last: the pass ends having just touched the embedding table, which
         # is what the next attention refresh gathers from (a step's working set is about the size

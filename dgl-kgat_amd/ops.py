@@ -489,6 +489,52 @@ def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=Fal
     return out
 
 
+def spmm_bi_fused_supported(d_in, d_out):
+    return bool(_lib.load().kgat_spmm_bi_fused_supported(int(d_in), int(d_out)))
+
+
+def spmm_bi_fused(indptr, col, row_of, X, w, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h=True,
+                  rows=None, e_range=None, workspace=None, scratch=None, self_out=None):
+    """One KGATConv forward in one pass (kgat_spmm_bi_fused_f32; reference models.py:63-66 + :165):
+    Z = leaky_relu(((sum_p w_p X[col[p]]) * X[v]) @ W2^T) over the CSR rows `rows`; returns Z (or None with
+    want_h=False) and writes Z / ||Z_row|| into `norm_out` (a column slice of a wider row-major buffer).  The
+    same bits as spmm(mul_self=True) followed by bi_interaction."""
+    X = _need(X, torch.float32, "X")
+    W2 = _need(W2, torch.float32, "W2")
+    if X.dim() != 2 or W2.dim() != 2 or W2.shape[1] != X.shape[1]:
+        raise ValueError("X must be (N, d_in) and W2 (d_out, d_in)")
+    d_in, d_out = X.shape[1], W2.shape[0]
+    indptr = _need(indptr, torch.int32, "indptr")
+    col = _need(col, torch.int32, "col")
+    w = _need(w, torch.float32, "w", col.shape)
+    row_of = _need(row_of, torch.int32, "row_of", col.shape)
+    row0, n_rows = (0, indptr.numel() - 1) if rows is None else rows
+    e0, e1 = (0, col.numel()) if e_range is None else e_range
+    if want_h and h_out is None:
+        h_out = torch.empty((n_rows, d_out), dtype=torch.float32, device=X.device)
+    if h_out is not None:
+        h_out = _need(h_out, torch.float32, "h_out", (n_rows, d_out))
+    stride = 0
+    if norm_out is not None:
+        stride = _strided_rows(norm_out, n_rows, d_out, "norm_out")
+    self_stride = 0
+    if self_out is not None:
+        self_stride = _strided_rows(self_out, n_rows, d_in, "self_out")
+    if scratch is None:
+        scratch = torch.empty((n_rows, d_in), dtype=torch.float32, device=X.device)
+    else:
+        scratch = _need(scratch, torch.float32, "scratch", (n_rows, d_in))
+    if workspace is None:
+        workspace = spmm_workspace(e1 - e0, d_in, X.device)
+    with _timed("spmm_bi_fused", (e1 - e0, n_rows, d_in, d_out)):
+        check(_lib.load().kgat_spmm_bi_fused_f32(n_rows, row0, e0, e1, d_in, d_out, _ptr(indptr), _ptr(col),
+                                                 _ptr(row_of), _ptr(X), _ptr(w), _ptr(W2), float(negative_slope),
+                                                 _ptr(h_out), _ptr(norm_out), stride, _ptr(scratch), _ptr(workspace),
+                                                 workspace.numel(), _ptr(self_out), self_stride, _stream(X)),
+              "kgat_spmm_bi_fused_f32")
+    return h_out
+
+
 def bi_interaction_supported(d_in, d_out):
     return bool(_lib.load().kgat_bi_interaction_supported(int(d_in), int(d_out)))
 

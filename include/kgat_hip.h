@@ -311,6 +311,24 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
                             float negative_slope, float* h_out, float* norm_out,
                             int64_t norm_stride, kgat_stream_t stream);
 
+/* ---------------------------------------------------------------- one KGATConv forward in one pass (S1 + B1 + B2)
+ * Replaces reference models.py:63-66 (update_all(u_mul_e, sum); th.mul; res_fc_2; LeakyReLU) and the
+ * F.normalize of models.py:165 for the no-grad forward: kgat_spmm_umule_sum_f32 with KGAT_SPMM_MUL_SELF
+ * (same arguments, CSR-ordered weights, MERGE algorithm) whose completed rows P = h * h_N never leave the
+ * workgroup: they are collected in LDS and take Z = LeakyReLU_slope(P W2^T) (fp32 MFMA) there; h_out /
+ * norm_out / norm_stride as kgat_bi_interaction_f32 (norm_out 16-byte aligned, norm_stride a multiple of
+ * 4).  Results are bit-identical to the two-launch sequence.  `scratch` (n_rows x d_in floats, contents
+ * undefined afterwards) takes the P rows of tiles that span more rows than the LDS buffer holds.
+ * Widths (kgat_spmm_bi_fused_supported): d_in, d_out in {16, 32, 64} with d_out <= d_in.
+ * workspace: kgat_spmm_workspace_bytes(e_end - e_begin, d_in). */
+int kgat_spmm_bi_fused_supported(int d_in, int d_out);
+int kgat_spmm_bi_fused_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64_t e_end, int d_in, int d_out,
+                           const int32_t* indptr, const int32_t* col, const int32_t* row_of,
+                           const float* X, const float* w, const float* W2, float negative_slope,
+                           float* h_out, float* norm_out, int64_t norm_stride, float* scratch,
+                           void* workspace, size_t workspace_bytes, float* self_out, int64_t self_stride,
+                           kgat_stream_t stream);
+
 /* F.normalize(x, p=2, dim=1, eps=1e-12) of n_rows contiguous d-wide rows (reference
  * models.py:165) into a destination with row stride out_stride floats (a column slice of the
  * concatenated output, models.py:167).  Used where the rows of a layer come back from the

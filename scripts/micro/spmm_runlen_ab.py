@@ -33,13 +33,17 @@ AB = os.environ.get("AB_FLAG", "-DKGAT_SPMM_MID_LIMIT=0")
 libs = {"shipped": base, AB: nomid}
 
 dev = torch.device("cuda:0")
+WLS = os.environ.get("AB_WORKLOADS", "amazon-book,last-fm").split(",")
+DIMS = [int(x) for x in os.environ.get("AB_DIMS", "8,16,32,64,128").split(",")]
 for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm_ckg)):
+    if wl not in WLS:
+        continue
     n, trip, R = mk()
     src = torch.as_tensor(trip[:, 2].copy(), device=dev)
     dst = torch.as_tensor(trip[:, 0].copy(), device=dev)
     indptr, col, eid, row_of = ops.csr_from_coo(n, src, dst)
     w = torch.rand(len(trip), device=dev)
-    for D in (8, 16, 32, 64, 128):
+    for D in DIMS:
         X = torch.randn(n, D, device=dev)
         res, outs = {}, {}
         for name in libs:

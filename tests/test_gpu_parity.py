@@ -210,6 +210,124 @@ def test_spmm_self_copy_epilogue(K, dev, D):
         ops.spmm(indptr, col, row_of, X, w_csr, self_out=torch.empty((n, D), device=dev))
 
 
+FUSED_WIDTHS = [(64, 64), (64, 32), (64, 16), (32, 32), (32, 16), (16, 16)]
+
+
+def _fused_vs_two_launches(ops, indptr, col, row_of, X, w_csr, W2, dev, lo=None, hi=None, self_copy=False):
+    """kgat_spmm_bi_fused_f32 against kgat_spmm_umule_sum_f32(MUL_SELF) + kgat_bi_interaction_f32 on the same
+    inputs: the same bits in h_out and in the normalised slice, nothing outside the slice touched."""
+    n, d_in = X.shape
+    d_out = W2.shape[0]
+    kw = {}
+    if lo is not None:
+        ip = indptr.cpu().numpy()
+        kw = dict(rows=(lo, hi - lo), e_range=(int(ip[lo]), int(ip[hi])))
+    rows = n if lo is None else hi - lo
+    prod = ops.spmm(indptr, col, row_of, X, w_csr, mul_self=True, **kw)
+    wide_a = torch.full((rows, d_out + 24), 9.0, device=dev)
+    h_a = ops.bi_interaction(prod, W2, 0.01, norm_out=wide_a[:, 8:8 + d_out])
+    wide_b = torch.full((rows, d_out + 24), 9.0, device=dev)
+    ego = torch.full((rows, d_in + 8), 5.0, device=dev) if self_copy else None
+    h_b = ops.spmm_bi_fused(indptr, col, row_of, X, w_csr, W2, 0.01, norm_out=wide_b[:, 8:8 + d_out],
+                            self_out=None if ego is None else ego[:, 4:4 + d_in], **kw)
+    assert torch.equal(h_a, h_b), float((h_a - h_b).abs().max())
+    assert torch.equal(wide_a, wide_b)
+    if ego is not None:
+        assert torch.equal(ego[:, 4:4 + d_in], X if lo is None else X[lo:hi])
+        assert bool((ego[:, :4] == 5.0).all()) and bool((ego[:, 4 + d_in:] == 5.0).all())
+    # norm-only form (the last layer of the readout): h_out not wanted
+    wide_c = torch.full((rows, d_out + 24), 9.0, device=dev)
+    assert ops.spmm_bi_fused(indptr, col, row_of, X, w_csr, W2, 0.01, norm_out=wide_c[:, 8:8 + d_out], want_h=False,
+                             **kw) is None
+    assert torch.equal(wide_a, wide_c)
+    return h_b, wide_b[:, 8:8 + d_out]
+
+
+@pytest.mark.parametrize("d_in,d_out", FUSED_WIDTHS)
+@pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
+def test_spmm_bi_fused_vs_two_launches_and_oracle(K, dev, d_in, d_out, name, n, e, hub, iso):
+    """S1 + B1 + B2 in one launch (reference models.py:63-66 + :165): the same bits as the two-launch
+    sequence, and within the aggregation's / bi-interaction's bars of the fp64 oracle; graphs with empty
+    rows, a hub row spanning many tiles, a single row holding every edge, no edges at all."""
+    from dgl_kgat_amd import ops
+    src, dst = random_graph(7, n, e, hub, iso)
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((n, d_in)).astype(np.float32)
+    w = rng.random(e).astype(np.float32)
+    W2 = (rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w_csr = ops.gather(eid, tf(w, dev)) if e else tf(w, dev)
+    h, nrm = _fused_vs_two_launches(ops, indptr, col, row_of, tf(X, dev), w_csr, tf(W2, dev), dev, self_copy=True)
+    hn = orc.spmm_u_mul_e_sum(n, src, dst, X, w)
+    ref = orc.bi_interaction(X, hn, W2)
+    assert rel_err_inf(h.cpu().numpy(), ref) < 1e-5
+    assert rel_err_inf(nrm.cpu().numpy(), orc.l2_normalize(ref)) < 1e-4
+    deg = np.diff(indptr.cpu().numpy())
+    assert np.all(h.cpu().numpy()[deg == 0] == 0) and np.all(nrm.cpu().numpy()[deg == 0] == 0)
+    assert np.all(np.isfinite(nrm.cpu().numpy()))
+
+
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16)])
+def test_spmm_bi_fused_long_runs_spill_and_shards(K, dev, d_in, d_out):
+    """Large enough (3.3 M edges) for the full run length; a stretch of degree-1 rows so that tiles span far
+    more rows than the LDS row buffer holds (the spill path through the global scratch), a stretch of empty
+    rows inside a tile's range, a 600 k-edge hub (a boundary row finished by the long-chain path of the
+    finish launch); whole graph, row-range shards (short and mid run lengths), repeated launch = same bits."""
+    from dgl_kgat_amd import ops
+    n, e = 30000, 3_300_000
+    rng = np.random.default_rng(90 + d_in)
+    src, dst = random_graph(91, n, e, hub=600_000, isolated_tail=500)
+    # rows 20000..24999: exactly one in-edge each (5,000 rows in ~5 tiles), rows 25000..25999 then empty
+    keep = (dst < 20000) | (dst >= 26000)
+    src, dst = src[keep], dst[keep]
+    src = np.concatenate([src, rng.integers(0, n, 5000).astype(np.int32)])
+    dst = np.concatenate([dst, np.arange(20000, 25000, dtype=np.int32)])
+    e = len(src)
+    X = tf(rng.standard_normal((n, d_in)).astype(np.float32), dev)
+    W2 = tf((rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32), dev)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w_csr = tf(rng.random(e).astype(np.float32), dev)
+    h, _ = _fused_vs_two_launches(ops, indptr, col, row_of, X, w_csr, W2, dev, self_copy=True)
+    h2, _ = _fused_vs_two_launches(ops, indptr, col, row_of, X, w_csr, W2, dev)
+    assert torch.equal(h, h2)
+    for lo, hi in [(0, 5), (5, 9000), (19990, 26010), (24000, n), (n - 3, n)]:
+        _fused_vs_two_launches(ops, indptr, col, row_of, X, w_csr, W2, dev, lo=lo, hi=hi, self_copy=(lo == 5))
+
+
+def test_gnn_one_launch_layers_same_bits(K, dev, monkeypatch):
+    """Model.gnn with KGAT_FUSE_BI=1 (every layer one kgat_spmm_bi_fused_f32 launch, ego block written by the
+    first) against the default two launches per layer: the same bits in the whole readout."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.amazon_book_ckg(scale=0.05)
+    torch.manual_seed(3)
+    model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    with torch.no_grad():
+        g.edata["w"] = model.compute_attention(g)
+        monkeypatch.setenv("KGAT_FUSE_BI", "0")
+        two = model.gnn(g)
+        monkeypatch.setenv("KGAT_FUSE_BI", "1")
+        one = model.gnn(g)
+    assert torch.equal(one, two), float((one - two).abs().max())
+
+
+def test_spmm_bi_fused_refuses_what_it_cannot_do(K, dev):
+    from dgl_kgat_amd import ops
+    assert ops.spmm_bi_fused_supported(64, 64) and ops.spmm_bi_fused_supported(32, 16)
+    assert not ops.spmm_bi_fused_supported(128, 128) and not ops.spmm_bi_fused_supported(16, 32)
+    assert not ops.spmm_bi_fused_supported(8, 8)
+    n, e = 50, 300
+    src, dst = random_graph(3, n, e)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    X, w = torch.randn(n, 128, device=dev), torch.rand(e, device=dev)
+    with pytest.raises(Exception):
+        ops.spmm_bi_fused(indptr, col, row_of, X, w, torch.randn(128, 128, device=dev))
+    X = torch.randn(n, 64, device=dev)
+    wide = torch.empty((n, 70), device=dev)
+    with pytest.raises(Exception):   # a normalised slice that is not 16-byte aligned
+        ops.spmm_bi_fused(indptr, col, row_of, X, w, torch.randn(64, 64, device=dev), norm_out=wide[:, 3:67])
+
+
 @pytest.mark.parametrize("name,n,e,hub,iso", GRAPHS)
 def test_edge_softmax_vs_oracle(K, dev, name, n, e, hub, iso):
     from dgl_kgat_amd import ops
