@@ -83,6 +83,7 @@ SIGNATURES = {
     "kgat_l2_normalize_rows_f32": (_i32, [_i64, _i32, _p, _p, _i64, _p]),
     "kgat_readout_concat_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "kgat_sddmm_dot_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "kgat_gather_probe_f32": (_i32, [_i64, _i32, _p, _p, _p, _p]),
     "kgat_gather_f32": (_i32, [_i64, _p, _p, _p, _p]),
     "kgat_gather_i32": (_i32, [_i64, _p, _p, _p, _p]),
 }

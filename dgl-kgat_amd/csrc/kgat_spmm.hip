@@ -50,6 +50,36 @@ __global__ __launch_bounds__(256) void sddmm_dot_kernel(int64_t n_edges, int D,
   if (sl == 0) out[e] = acc;
 }
 
+// Measurement aid (bench.py's roofline.gather_ceiling): reads the rows X[col[p], :] of CSR positions [0, n_edges) and
+// nothing else - no weights, no row ids, no output (a running sum keeps the loads alive; `sink` is never written for
+// finite data).  LPR lanes x one float4 per row, U rows in flight per lane group: the access pattern of the
+// aggregation's edge loop without the aggregation.  What this launch takes is the floor of any kernel that has to
+// fetch those rows through the cache hierarchy, whatever serves them (L2, Infinity Cache, HBM).
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void gather_probe_kernel(int64_t n_edges, const int32_t* __restrict__ col,
+                                                           const float4* __restrict__ X, float4* __restrict__ sink) {
+  constexpr int EPS = 64 / LPR;  // edges per wavefront step
+  const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int64_t kPerWave = 512;
+  const int64_t base = wave * kPerWave;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t p0 = base; p0 < base + kPerWave && p0 < n_edges; p0 += EPS * U) {
+    int c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = p0 + EPS * u + sub;
+      c[u] = col[p < n_edges ? p : n_edges - 1];
+    }
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = X[(size_t)c[u] * LPR + sl];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = add4(acc, v[u]);
+  }
+  if (acc.x == 12345.678f && acc.y == -8765.4321f) sink[wave] = acc;
+}
+
 }  // namespace kgat
 
 using namespace kgat;
@@ -118,6 +148,26 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
   const bool mul = flags & KGAT_SPMM_MUL_SELF;
   if (mul) return eid ? dispatch_width<true, true>(a) : dispatch_width<true, false>(a);
   return eid ? dispatch_width<false, true>(a) : dispatch_width<false, false>(a);
+}
+
+int kgat_gather_probe_f32(int64_t n_edges, int D, const int32_t* col, const float* X, float* sink, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_edges >= 0, "gather_probe: bad size");
+  if (n_edges == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(col && X && sink, "gather_probe: null pointer");
+  const unsigned blocks = (unsigned)((n_edges + 2047) / 2048);
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  float4* s4 = reinterpret_cast<float4*>(sink);
+  switch (D) {
+    case 16: hipLaunchKernelGGL((gather_probe_kernel<4, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
+    case 32: hipLaunchKernelGGL((gather_probe_kernel<8, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
+    case 64: hipLaunchKernelGGL((gather_probe_kernel<16, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
+    case 128: hipLaunchKernelGGL((gather_probe_kernel<32, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
+    default:
+      set_error("gather_probe: D must be 16, 32, 64 or 128 (got %d)", D);
+      return KGAT_E_UNSUPPORTED;
+  }
+  KGAT_CHECK_LAUNCH("gather_probe");
+  return KGAT_OK;
 }
 
 int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t* dst,

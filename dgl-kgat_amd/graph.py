@@ -614,7 +614,8 @@ class DGLGraph:
         """compute_attention (models.py:146-154): relation-grouped attention logits + destination
         softmax.  Returns the (E,1) weights in edge-id order; the graph keeps their CSR-ordered
         copy, so a following ``edata['w'] = result`` + ``update_all`` streams them without a
-        permutation pass.  By default (``lazy=None``: on unless ``KGAT_EAGER_EDGE_WEIGHTS`` is set)
+        permutation pass.  With ``lazy=True``, or ``lazy=None`` after the process opted in
+        (``dgl_kgat_amd.enable_lazy_edge_weights()`` / ``KGAT_LAZY_EDGE_WEIGHTS=1``; see lazy.py),
         the result is a `lazy.LazyEdgeWeights`: real storage whose edge-id-ordered values are
         written by the first operation that looks at them - nothing on the path does."""
         if etype is None:
@@ -678,8 +679,11 @@ class DGLGraph:
         else:
             _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, logits, in_csr_order=True,
                                         want_out=False, want_csr=True)
+        from . import lazy as lazy_mod
         if lazy is None:
-            lazy = not os.environ.get("KGAT_EAGER_EDGE_WEIGHTS")
+            lazy = lazy_mod.enabled()
+        elif lazy:
+            lazy_mod._guard_legacy_to_dlpack()   # an explicit lazy=True: the export guard must be in place
         a = torch.empty((st.n_edges, 1), dtype=torch.float32, device=dev)
         a_flat = a.view(-1)
 

@@ -17,10 +17,17 @@ nothing lazy-specific can misbehave afterwards (``copy.deepcopy``, pickling, sub
 code).  Value-reading paths that do not go through a torch operator are covered one by one:
 ``Tensor.type(dtype)`` (a cast, unlike the argument-less metadata query), ``copy.deepcopy`` /
 pickling, and the legacy ``torch.utils.dlpack.to_dlpack`` (a C function that skips
-``__torch_function__``: wrapped at import).  What remains out of reach is a C++ extension that
+``__torch_function__``: wrapped by ``enable()``).  What remains out of reach is a C++ extension that
 takes the raw pointer of a tensor it was handed inside a container without calling any torch
-operator or ``data_ptr()`` on the Python side; set ``KGAT_EAGER_EDGE_WEIGHTS=1`` (or
-``lazy=False``) to get the permutation up front.
+operator or ``data_ptr()`` on the Python side.
+
+**Opt-in.**  The deferred form is OFF unless the process asks for it: ``dgl_kgat_amd.enable_lazy_edge_weights()``
+(= ``lazy.enable()``), ``compat.accelerate(model, lazy_edge_weights=True)``, ``KGAT_LAZY_EDGE_WEIGHTS=1`` in the
+environment, or ``lazy=True`` on one ``kgat_attention`` call.  Importing this package changes nothing in torch;
+only ``enable()`` wraps ``torch.utils.dlpack.to_dlpack`` (one process-wide wrapper, undone by ``enable(False)``),
+because a library that rewrites a torch global at import is a liability inside someone else's training process.
+By default ``compute_attention`` therefore returns an ordinary, fully written tensor (6 % of a step on the
+benchmark graph); ``KGAT_EAGER_EDGE_WEIGHTS=1`` forces that even after ``enable()``.
 """
 import copy
 
@@ -66,13 +73,19 @@ class LazyEdgeWeights(torch.Tensor):
     def materialize(self):
         """Run the deferred permutation (once) and turn this object into a plain torch.Tensor."""
         fill = self.__dict__.get("_kgat_fill")
+        if fill is not None:
+            if self.__dict__.get("_kgat_filling"):
+                return self                    # re-entered from inside the fill itself
+            self.__dict__["_kgat_filling"] = True
+            try:
+                fill()                         # may raise (launch error, out of memory): the object then stays
+            finally:                           # pending, with its fill intact, and the next read tries again
+                self.__dict__.pop("_kgat_filling", None)
         self.__dict__.pop("_kgat_fill", None)
         self.__dict__.pop("_kgat_lazy", None)
         if type(self) is LazyEdgeWeights:
             self.__class__ = torch.Tensor
             self.__dict__["pending"] = False   # `w.pending` keeps answering on the plain tensor
-        if fill is not None:
-            fill()
         return self
 
     @classmethod
@@ -97,12 +110,25 @@ class LazyEdgeWeights(torch.Tensor):
         return self.__reduce_ex__(proto)      # torch.Tensor's
 
 
-def _guard_legacy_to_dlpack():
+_enabled = None   # None: not decided yet (the environment is consulted on first use)
+_dlpack_inner = None
+
+
+def _guard_legacy_to_dlpack(install=True):
     """torch.utils.dlpack.to_dlpack is the C function torch._C._to_dlpack: it exports the storage
-    without consulting __torch_function__.  Wrap it (once) so that a pending tensor is filled first."""
-    inner = _dlpack.to_dlpack
-    if getattr(inner, "_kgat_guarded", False):
+    without consulting __torch_function__.  Wrap it (once) so that a pending tensor is filled first;
+    install=False puts the original back."""
+    global _dlpack_inner
+    cur = _dlpack.to_dlpack
+    if not install:
+        if getattr(cur, "_kgat_guarded", False) and _dlpack_inner is not None:
+            if getattr(torch, "to_dlpack", None) is cur:
+                torch.to_dlpack = _dlpack_inner
+            _dlpack.to_dlpack = _dlpack_inner
         return
+    if getattr(cur, "_kgat_guarded", False):
+        return
+    inner = _dlpack_inner = cur
 
     def to_dlpack(tensor):
         if isinstance(tensor, LazyEdgeWeights):
@@ -115,7 +141,23 @@ def _guard_legacy_to_dlpack():
         torch.to_dlpack = to_dlpack
 
 
-_guard_legacy_to_dlpack()
+def enable(flag=True):
+    """Turn the deferred edge-id-ordered attention on (or off) for this process; turning it on wraps the legacy
+    torch.utils.dlpack.to_dlpack so that a pending tensor is filled before it is exported."""
+    global _enabled
+    _enabled = bool(flag)
+    _guard_legacy_to_dlpack(install=_enabled)
+    return _enabled
+
+
+def enabled():
+    """Whether kgat_attention hands back LazyEdgeWeights by default (see the module docstring)."""
+    import os
+    if os.environ.get("KGAT_EAGER_EDGE_WEIGHTS"):
+        return False
+    if _enabled is None and os.environ.get("KGAT_LAZY_EDGE_WEIGHTS", "") not in ("", "0"):
+        enable(True)
+    return bool(_enabled)
 
 
 def pending_csr_weights(w, structure):

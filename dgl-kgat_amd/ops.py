@@ -670,6 +670,19 @@ def readout_concat(blocks, normalize, out=None):
     return out
 
 
+def gather_probe(col, X, sink=None):
+    """Measurement aid (kgat_gather_probe_f32): fetch the rows X[col[p]] with the aggregation's access pattern and
+    do nothing else; returns the scratch so a caller timing many launches can pass it back in."""
+    X = _need(X, torch.float32, "X")
+    col = _need(col, torch.int32, "col")
+    if sink is None:
+        sink = torch.zeros(((col.numel() + 2047) // 2048 * 4 + 4) * 4, dtype=torch.float32, device=X.device)
+    with _timed("gather_probe", (col.numel(), X.shape[1])):
+        check(_lib.load().kgat_gather_probe_f32(col.numel(), X.shape[1], _ptr(col), _ptr(X), _ptr(sink), _stream(X)),
+              "kgat_gather_probe_f32")
+    return sink
+
+
 def sddmm_dot(src, dst, X, G):
     X = _need(X, torch.float32, "X")
     G = _need(G, torch.float32, "grad_out")

@@ -121,6 +121,25 @@ def main():
         ds.n_users, ds.n_items, ds.n_KG_entity, ds.n_KG_relation, len(ds.train_KG_triplet)))
     model = K.KGATPropagation(ds.n_KG_entity, ds.n_KG_relation, args.entity_embed_dim, args.relation_embed_dim,
                               args.gnn_num_layer, args.gnn_hidden_size, args.dropout_rate).to(dev)
+    K.enable_lazy_edge_weights()   # the attention refresh hands back its edge-id-ordered copy unwritten (nothing here reads it)
+
+    def replicas_agree(tag):
+        """Every rank holds a replica of the parameters and runs the same optimiser on the same gradients
+        (only the shard layers' partial gradients are summed across ranks): a nondeterministic kernel or a
+        diverging per-rank RNG would make the replicas drift silently.  Compare a checksum of all
+        parameters across ranks (MAX - MIN of the per-rank sums) and stop when they differ."""
+        if world == 1:
+            return
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        if float(hi - lo) > 1e-9 * max(abs(float(hi)), 1.0):
+            raise RuntimeError("%s: parameter replicas differ across ranks (checksum spread %.3e)" % (tag, float(hi - lo)))
+    if world > 1:
+        for p in model.parameters():   # one source of truth for the initial parameters, whatever the ranks' RNG drew
+            dist.broadcast(p.data, src=0)
+        replicas_agree("after the initial broadcast")
     # one Adam over all parameters (kgat.py:85); torch's single-kernel implementation of the same update
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, fused=dev.type == "cuda")
     train_g, test_g = ds.train_graph(dev), ds.test_graph(dev)
@@ -176,6 +195,7 @@ def main():
             opt.zero_grad()
             total += loss.item()
         say("           | GNN %.1fs loss %.4f" % (time.time() - t0, total / n_it))
+        replicas_agree("epoch %d" % epoch)
         # ---- evaluation (kgat.py:53-62, 171-196)
         t0 = time.time()
         with torch.no_grad():

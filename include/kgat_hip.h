@@ -291,6 +291,14 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
                             unsigned flags, int algo, float* self_out, int64_t self_stride,
                             kgat_stream_t stream);
 
+/* Measurement aid, not an operator of the path (SURVEY 8d asks for the bound that binds; on the cache-resident CKGs
+ * that is the rate at which gathered rows cross the cache fabric, not HBM): reads the rows X[col[p], :] of CSR
+ * positions p in [0, n_edges) with the aggregation's access pattern - D / 4 lanes x 16 bytes per row, 8 rows in
+ * flight per lane group - and does nothing else (no weights, no output).  sink: a scratch of at least
+ * ceil(n_edges / 2048) * 4 x 16 bytes that is never written for finite data.  D in {16, 32, 64, 128}. */
+int kgat_gather_probe_f32(int64_t n_edges, int D, const int32_t* col, const float* X, float* sink,
+                          kgat_stream_t stream);
+
 /* Gradient of the aggregation w.r.t. the edge weight (DGL backward_rhs of the same op):
  *   grad_w[e] = < X[src e, :], grad_out[dst e, :] >,  edge-id order. */
 int kgat_sddmm_dot_f32(int64_t n_edges, int D, const int32_t* src, const int32_t* dst,

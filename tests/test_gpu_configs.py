@@ -393,9 +393,25 @@ def test_lazy_edge_weights_on_device(dev):
     materialising it; the first value-level read runs the permutation and gives exactly what the
     eager path gives; an in-place edit afterwards is seen by the next aggregation."""
     import dgl_kgat_amd as K
-    from dgl_kgat_amd import synth
+    from dgl_kgat_amd import lazy, synth
     from dgl_kgat_amd.lazy import LazyEdgeWeights
     n, trip, R = synth.amazon_book_ckg(scale=0.05)
+    torch.manual_seed(2)
+    m0 = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+    g0 = synth.build_graph(n, trip, dev)
+    with torch.no_grad():   # the deferred form is opt-in: by default an ordinary, fully written tensor comes back
+        assert not lazy.enabled() and type(m0.compute_attention(g0)) is torch.Tensor
+    del m0, g0
+    K.enable_lazy_edge_weights()
+    try:
+        _lazy_edge_weights_body(K, synth, LazyEdgeWeights, n, trip, R, dev)
+    finally:
+        K.enable_lazy_edge_weights(False)
+    import torch.utils.dlpack as dlpack
+    assert not getattr(dlpack.to_dlpack, "_kgat_guarded", False)   # the wrapper is gone again
+
+
+def _lazy_edge_weights_body(K, synth, LazyEdgeWeights, n, trip, R, dev):
     torch.manual_seed(2)
     m = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
     g = synth.build_graph(n, trip, dev)

@@ -507,8 +507,23 @@ def test_lazy_edge_weights_value_paths_outside_torch_function():
     import copy
     import pickle
     import torch.utils.dlpack as dlpack
+    from dgl_kgat_amd import lazy
     from dgl_kgat_amd.lazy import LazyEdgeWeights
+    # importing the package leaves torch alone: the to_dlpack wrapper exists only after lazy.enable()
+    probe = ("import sys; sys.path.insert(0, %r); import torch.utils.dlpack as d; import dgl_kgat_amd as K; "
+             "from dgl_kgat_amd import lazy; assert not getattr(d.to_dlpack, '_kgat_guarded', False); "
+             "assert not lazy.enabled(); K.enable_lazy_edge_weights(); assert d.to_dlpack._kgat_guarded and lazy.enabled(); "
+             "K.enable_lazy_edge_weights(False); assert not getattr(d.to_dlpack, '_kgat_guarded', False)" % ROOT)
+    subprocess.run([sys.executable, "-c", probe], check=True, env={k: v for k, v in os.environ.items()
+                                                                  if k not in ("KGAT_LAZY_EDGE_WEIGHTS",)})
+    lazy.enable()
+    try:
+        _lazy_value_paths(copy, pickle, dlpack, LazyEdgeWeights)
+    finally:
+        lazy.enable(False)
 
+
+def _lazy_value_paths(copy, pickle, dlpack, LazyEdgeWeights):
     def make():
         base = torch.full((5, 1), float("nan"))
         calls = []
@@ -543,6 +558,26 @@ def test_lazy_edge_weights_value_paths_outside_torch_function():
     assert w.data_ptr() != 0 and calls == [1]                                    # the raw pointer is a value-level read
     w, calls = make()
     assert (w * w).reshape(-1).tolist() == [x * x for x in want] and calls == [1]  # the same tensor twice in one call
+
+
+def test_lazy_fill_failure_leaves_the_tensor_pending():
+    """a fill that raises (launch error, out of memory) must not leave a plain tensor over
+    unwritten storage - the object stays pending with its fill intact and the next read tries again."""
+    from dgl_kgat_amd.lazy import LazyEdgeWeights
+    base = torch.full((3, 1), float("nan"))
+    state = {"fail": True, "calls": 0}
+
+    def fill():
+        state["calls"] += 1
+        if state["fail"]:
+            raise RuntimeError("launch failed")
+        base.copy_(torch.arange(3.0).reshape(3, 1))
+    w = LazyEdgeWeights(base, fill, object(), "csr")
+    with pytest.raises(RuntimeError):
+        w.sum()
+    assert isinstance(w, LazyEdgeWeights) and w.pending and state["calls"] == 1
+    state["fail"] = False
+    assert w.reshape(-1).tolist() == [0.0, 1.0, 2.0] and state["calls"] == 2 and type(w) is torch.Tensor
 
 
 def test_partial_edge_writes_do_not_leak_into_handed_out_columns():
