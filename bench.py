@@ -769,7 +769,9 @@ def main():
                       "pipe - every operand cut by round-to-nearest into three bf16 pieces whose sum is the operand "
                       "exactly (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|), the three dropped piece products together <= 2^-23 "
                       "of a product (one fp32 ulp), either sign; fp32 accumulate: measured error against fp64 no larger "
-                      "than the fp32-MFMA form's (KGAT_ATT_F32_PRODUCTS selects that form)",
+                      "than the fp32-MFMA form's (KGAT_ATT_F32_PRODUCTS selects that form).  Since round 4 the second "
+                      "product of the d <= 64 kernel runs on fp16 pieces (W_r * 2^shift three, tanh * 2^14 two, five piece "
+                      "products on v_mfma_f32_16x16x32_f16): same error, fewer instructions",
         "config": {"workload": "%s N=%d E=%d R=%d, %d layers, embed_dim=%d, fp32; step = compute_attention + "
                                "edge_softmax + %dx(u_mul_e_sum + bi-interaction) + normalize/concat"
                                % (name, n, E, n_rel, args.layers, D, args.layers),

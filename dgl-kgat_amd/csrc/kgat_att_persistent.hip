@@ -718,11 +718,12 @@ __device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, c
                                                  0);
 }
 
-// fp16 pieces (experiment of round 3's second half, -DKGAT_ATT_F16_SECOND=1; d <= 64 fused kernel, second product:
-// W_r * 2^shift as three fp16 pieces, the tanh values as two, five piece products).  Measured on the amazon-book
-// graph, d = 64: stand-alone 0.1555 vs 0.1614 ms, inside the step 137.3 vs 140.6 us; against fp64 max error
-// 9.98e-7 / mean 1.09e-7 (three-bf16-piece form: 9.4e-7 / 1.23e-7; fp32 MFMA: 1.48e-6 / 1.43e-7), every GPU test
-// unchanged.  NOT the default: 3 us of a 455 us step do not pay for a second arithmetic statement on the path.
+// fp16 pieces for the second product of the d <= 64 fused kernel (KGAT_ATT_F16_SECOND, default 1 since round 4;
+// built and measured in round 3: W_r * 2^shift as three fp16 pieces, the tanh values * 2^14 as two, five piece
+// products).  Measured on the amazon-book graph, d = 64: stand-alone 0.1555 vs 0.1614 ms, inside the step 137.3 vs
+// 140.6 us; against fp64 max error 9.98e-7 / mean 1.09e-7 (three-bf16-piece form: 9.4e-7 / 1.23e-7; fp32 MFMA:
+// 1.48e-6 / 1.43e-7), every GPU test unchanged (tests/test_gpu_parity.py::test_att_fused_product_forms, incl. the
+// "small T" case that the 2^14 scale exists for).
 // A value inside fp16's range is h + m + l with three round-to-nearest fp16 pieces EXACTLY (3 x 11 significand
 // bits), and h + m with a residual <= 2^-22 |x|.  What the format buys is the cut: the remainder x - float(h) is
 // ONE v_fma_mix_f32 per value (f16 operand taken straight from either half of the packed register), so a pair
@@ -1121,7 +1122,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   __shared__ __attribute__((aligned(16))) float s_v[NW][16 * LDV];
   __shared__ int32_t s_next;  // next unclaimed tile of the current relation segment
 #ifndef KGAT_ATT_F16_SECOND
-#define KGAT_ATT_F16_SECOND 0
+#define KGAT_ATT_F16_SECOND 1  // default since round 4 (-3.3 us in the step at equal error; 0: three bf16 pieces on both products)
 #endif
   constexpr bool F16B = X3 && KGAT_ATT_F16_SECOND != 0;  // second product on fp16 pieces: W_r three, tanh values two
   __shared__ unsigned s_wmax;                             // F16B: bits of max |W_r| of the current relation
@@ -1315,7 +1316,13 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
 #pragma unroll
       for (int c = 0; c < KT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(fmaf(acc[c][j], kTwoLog2e, relv[c][j]));
+        for (int j = 0; j < 4; ++j) {
+          // F16B: the tanh values leave as T * 2^14 (the same rounding, scaled: a power of two), so that the low
+          // piece of a small |T| is still a normal fp16 number (unscaled, |T| ~ 1e-3 keeps 14 bits, not 22)
+          const float y = fmaf(acc[c][j], kTwoLog2e, relv[c][j]);
+          acc[c][j] = F16B ? fmaf(-32768.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 16384.0f)
+                           : att_tanh_scaled(y);
+        }
       if (X3) {
         const uintx4* fa = s_a + 3 * NFRAG + lane;
 #pragma unroll
@@ -1325,7 +1332,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
           if (F16B) {
-            split_f16x2(x, bh, bm);  // |tanh| < 1: inside fp16's range as it is
+            split_f16x2(x, bh, bm);  // |tanh| * 2^14 < 16,384: inside fp16's range
 #pragma unroll
             for (int c2 = 0; c2 < KT; ++c2) {  // five piece products, smallest first
               const uintx4 ah = fa[0 * NFRAG + (c2 * S3 + s) * kWave];
@@ -1397,7 +1404,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
         mine = li == s ? d : mine;
       }
-      if (F16B) mine = ldexpf(mine, -w_shift);  // (V rows are those of W_r * 2^w_shift)
+      if (F16B) mine = ldexpf(mine, -w_shift - 14);  // (V rows are those of (W_r * 2^w_shift) (T * 2^14))
       if (p0 + lane < pe) {
         if (LOGITS_EID) logits[c.oe] = mine;
         if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;

@@ -14,6 +14,9 @@
 // Rows of a tile beyond the buffer's capacity spill their P row to a global scratch and are read back by the
 // same workgroup (L2-local).  The buffer's size is set by occupancy, not by the typical tile (44 rows):
 // profiles/r04_spmm_lds_ballast_ab.txt.
+#ifdef KGAT_SPMM_THREADS
+#undef KGAT_SPMM_THREADS  // (A/B builds of the plain operator's workgroup size: the fused form is laid out for 256 threads)
+#endif
 #include "kgat_spmm_impl.h"
 
 using namespace kgat;

@@ -647,7 +647,7 @@ def test_att_fused_product_forms(K, dev, d):
     W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
     rel = rng.standard_normal((R, d)).astype(np.float32)
     W0, rel0 = W, rel
-    for case in ("normal", "wide range", "tiny", "signed zeros", "all positive", "large W"):
+    for case in ("normal", "wide range", "tiny", "signed zeros", "all positive", "large W", "small T"):
         ent = rng.standard_normal((n, d)).astype(np.float32)
         W, rel = W0, rel0
         if case == "all positive":   # same-sign operands everywhere: a one-sided error per product would add up
@@ -661,6 +661,9 @@ def test_att_fused_product_forms(K, dev, d):
             ent *= np.float32(1e-37)
         elif case == "signed zeros":
             ent[rng.random((n, d)) < 0.5] = -0.0
+        elif case == "small T":    # |tanh| ~ 1e-3 everywhere (small embeddings AND small relation vectors): the second
+            ent *= np.float32(1e-3)  # product's two fp16 pieces of a tanh value must still carry 22 bits of it
+            rel = rel0 * np.float32(1e-3)
         ref = orc.att_score(ent, W, rel, src, dst, et)
         got = {}
         for f32p in (False, True):
