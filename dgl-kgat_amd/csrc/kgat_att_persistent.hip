@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
 
 // Round 3's wave-role experiments (producer / consumer waves; measured, not adopted - notes in the file)
 #ifdef KGAT_ATT_WAVE_ROLES
-#include "kgat_att_wave_roles_experiment.h"
+#include "../../scripts/micro/att_wave_roles_experiment.h"  // measured and rejected (round 3); not product code, not in the build hash
 #endif
 
 template <int OUT>

@@ -46,6 +46,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // three arrays of n/3 entries (the three entity ids of every sample).
 constexpr int kSsWaves = 16;
 
+// PT: the packed (key, position) type - uint32_t for keys below 2^19 (64 KB of LDS for the two buffers), uint64_t for
+// any int32 key (128 KB: entity ids of graphs beyond 524,288 nodes, e.g. BASELINE configs[4]'s 10 M).
+template <typename PT>
 __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bits, const int32_t* __restrict__ keys,
                                                           const int32_t* __restrict__ keys_b,
                                                           const int32_t* __restrict__ keys_c,
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
                                                           int32_t* __restrict__ offsets,
                                                           int32_t* __restrict__ chunk_ptr,
                                                           int2* __restrict__ chunks) {
-  __shared__ uint32_t s_buf[2][kTrSmallSort];
+  __shared__ PT s_buf[2][kTrSmallSort];
   __shared__ int32_t s_cnt[256 * kSsWaves];
   __shared__ int32_t s_wsum[kSsWaves];
   const int tid = threadIdx.x, lane = tid % kWave, w = tid / kWave;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
     } else {
       key = keys[i];
     }
-    s_buf[0][i] = ((uint32_t)key << 13) | (uint32_t)i;
+    s_buf[0][i] = ((PT)(uint32_t)key << 13) | (PT)i;
   }
   const int32_t slice = ((n + kSsWaves * kWave - 1) / (kSsWaves * kWave)) * kWave;  // per wavefront, multiple of 64
   const int32_t lo = w * slice, hi = lo + slice < n ? lo + slice : n;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
     const int shift = 13 + 8 * pass;
     for (int i = tid; i < 256 * kSsWaves; i += 1024) s_cnt[i] = 0;
     __syncthreads();
-    for (int32_t i = lo + lane; i < hi; i += kWave) atomicAdd(&s_cnt[((s_buf[cur][i] >> shift) & 255u) * kSsWaves + w], 1);
+    for (int32_t i = lo + lane; i < hi; i += kWave) atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & 255u) * kSsWaves + w], 1);
     __syncthreads();
     {  // exclusive scan of the 4096 counters, 4 per thread
       int32_t c[4];
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
     for (int32_t i0 = lo; i0 < hi; i0 += kWave) {
       const int32_t i = i0 + lane;
       const bool valid = i < hi;
-      const uint32_t v = valid ? s_buf[cur][i] : 0u;
-      const uint32_t dgt = (v >> shift) & 255u;
+      const PT v = valid ? s_buf[cur][i] : (PT)0;
+      const uint32_t dgt = (uint32_t)((v >> shift) & 255u);
       uint64_t peers = __ballot(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; ++bit) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
     __syncthreads();
     cur ^= 1;
   }
-  const uint32_t* s = s_buf[cur];
+  const PT* s = s_buf[cur];
   for (int32_t p = tid; p <= n; p += 1024) {
     if (p < n) {
       order[p] = (int32_t)(s[p] & 8191u);
@@ -487,7 +490,7 @@ extern "C" {
 
 int kgat_transr_supported(int64_t n_nodes, int d, int k, int n_rel, int64_t batch) {
   return d > 0 && k > 0 && d % 4 == 0 && k % 4 == 0 && d <= kTrMaxDim && k <= kTrMaxDim && n_rel > 0 && n_rel <= kTrMaxRel && batch > 0 &&
-         3 * batch <= kTrSmallSort && n_nodes > 0 && n_nodes <= (1 << 19);
+         3 * batch <= kTrSmallSort && n_nodes > 0 && n_nodes < INT32_MAX;
 }
 
 size_t kgat_transr_workspace_bytes(int64_t batch, int d, int k, int n_rel) {
@@ -512,7 +515,7 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
                               float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
                               kgat_stream_t stream) {
   if (!kgat_transr_supported(n_nodes, d, k, n_rel, batch)) {
-    set_error("transr: needs d, k multiples of 4 and <= %d, batch <= %d, n_nodes <= 2^19 (d=%d k=%d batch=%lld n_nodes=%lld)", kTrMaxDim,
+    set_error("transr: needs d, k multiples of 4 and <= %d, batch <= %d, n_nodes < 2^31 (d=%d k=%d batch=%lld n_nodes=%lld)", kTrMaxDim,
               kTrSmallSort / 3, d, k, (long long)batch, (long long)n_nodes);
     return KGAT_E_UNSUPPORTED;
   }
@@ -543,7 +546,7 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   int rel_bits = 1, id_bits = 1;
   while ((1 << rel_bits) < n_rel) ++rel_bits;
   while ((1ll << id_bits) < n_nodes) ++id_bits;
-  hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(1024), 0, st, B, rel_bits, r, (const int32_t*)nullptr,
+  hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, B, rel_bits, r, (const int32_t*)nullptr,
                      (const int32_t*)nullptr, order, (int32_t*)nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks);
   KGAT_CHECK_LAUNCH("transr_sort_relations");
   const unsigned sb = (unsigned)((B + 3) / 4);
@@ -570,8 +573,12 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
     set_error("transr: memset failed");
     return KGAT_E_HIP;
   }
-  hipLaunchKernelGGL(small_sort_kernel, dim3(1), dim3(1024), 0, st, 3 * B, id_bits, h, pos_t, neg_t, row_order,
-                     sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
+  if (id_bits <= 19)
+    hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, 3 * B, id_bits, h, pos_t, neg_t, row_order,
+                       sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
+  else  // entity ids beyond 2^19: the 64-bit packing (128 KB of LDS, one more radix pass per 8 id bits)
+    hipLaunchKernelGGL(small_sort_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, 3 * B, id_bits, h, pos_t, neg_t, row_order,
+                       sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
   KGAT_CHECK_LAUNCH("transr_sort_ids");
   hipLaunchKernelGGL(transr_scatter_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, st, 3 * B, d,
                      (const int32_t*)sorted_ids, (const int32_t*)row_order, (const float*)DX, grad_ent);

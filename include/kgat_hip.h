@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 4
+#define KGAT_ABI_VERSION 5
 
 enum {
   KGAT_OK = 0,
@@ -392,8 +392,8 @@ int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, flo
  * loss: 1 float.  grad_ent (n_nodes x d, dense: rows not in the batch are zeroed, as the
  * reference's non-sparse nn.Embedding gradient), grad_W (R x d x k), grad_rel (R x k): all three
  * or none (NULL: loss only).  Fixed summation orders (sorted batch, no atomics): bitwise
- * reproducible.  Needs d, k multiples of 4 and <= 128, 3*batch <= 8192, n_nodes <= 2^19
- * (kgat_transr_supported). */
+ * reproducible.  Needs d, k multiples of 4 and <= 128, 3*batch <= 8192 (the batch is sorted by one workgroup in
+ * LDS), n_rel <= 4096, n_nodes < 2^31 (kgat_transr_supported; beyond it the Python layer takes torch operators). */
 int kgat_transr_supported(int64_t n_nodes, int d, int k, int n_rel, int64_t batch);
 size_t kgat_transr_workspace_bytes(int64_t batch, int d, int k, int n_rel);
 int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h,

@@ -125,6 +125,34 @@ def parity_8c_mean(name, gpu, c32, ref64, factor=1.25, floor=1e-7):
     return e_gpu, e_c
 
 
+def robust_quantile(size):
+    """The quantile the robust 8c gate looks at: the 99.9th percentile, or - on samples too small for that to be
+    anything but the maximum - the level of the 50th-largest element (never below the 90th percentile)."""
+    return float(min(99.9, max(90.0, 100.0 * (1.0 - 50.0 / max(size, 1)))))
+
+
+def parity_8c_robust(name, gpu, c32, ref64, q_factor=1.5, mean_factor=1.25, scale_bar=1e-5, max_factor=10.0,
+                     tol=1e-4, floor=1e-7):
+    """SURVEY 8c with statistics that do not ride on one element (task 7).  The maximum of the
+    elementwise metric over a normalised readout block sits on one element of the row with the smallest norm and
+    moves 2-3 x between two fp32 summation orders on ANY pair of machines (scripts/error_attribution.py); so:
+      * the high quantile (robust_quantile) of the device's 8c errors   <= q_factor    x the CPU fp32 run's,
+      * their mean                                                      <= mean_factor x the CPU fp32 run's,
+      * the whole tensor within scale_bar of its own scale (max |x - y| / max |y|),
+      * and the maximum only as a tripwire: <= max(tol, max_factor x the CPU fp32 run's maximum)."""
+    eg, ec = err_8c(gpu, ref64).reshape(-1), err_8c(c32, ref64).reshape(-1)
+    q = robust_quantile(eg.size)
+    qg, qc = float(np.percentile(eg, q)), float(np.percentile(ec, q))
+    e_inf = rel_err_inf(gpu, ref64)
+    print("[8c robust] %-34s q%.2f gpu %.3e c-fp32 %.3e | mean gpu %.3e c-fp32 %.3e | max gpu %.3e c-fp32 %.3e | at tensor "
+          "scale %.2e" % (name, q, qg, qc, eg.mean(), ec.mean(), eg.max(), ec.max(), e_inf))
+    assert qg <= max(floor, q_factor * qc), (name, "quantile", q, qg, qc)
+    assert eg.mean() <= max(floor, mean_factor * ec.mean()), (name, "mean", eg.mean(), ec.mean())
+    assert e_inf <= scale_bar, (name, "tensor scale", e_inf)
+    assert eg.max() <= max(tol, max_factor * ec.max()), (name, "max tripwire", eg.max(), ec.max())
+    return qg, qc
+
+
 def blocks(x, widths):
     """Column blocks of a Model.gnn output [h0 | n(h1) | n(h2) | ...]."""
     out, o = [], 0

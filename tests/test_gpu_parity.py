@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, blocks, blocks_rel_err_inf, load_golden, parity_8c, rel_err, rel_err_inf, sum_err
+from conftest import (GOLDEN_CASES, blocks, blocks_rel_err_inf, load_golden, parity_8c, parity_8c_robust, rel_err,
+                      rel_err_inf, sum_err)
 from oracle import c_oracle as co
 from oracle import kgat_oracle as orc
 
@@ -836,12 +837,10 @@ def test_layer_surface_and_fused_vs_reference_glue(K, dev, case):
             assert blocks_rel_err_inf(out.cpu().numpy(), g["gnn_out"], widths) < TOL, fused
             for bi, (x, c, y) in enumerate(zip(blocks(out.cpu().numpy(), widths), blocks(out_c, widths),
                                                blocks(g["gnn_out"], widths))):
-                # (50-200-node graphs: the maximum of the 8c metric over a few thousand elements is an extreme
-                # value of a small sample and moves 2-3 x between two fp32 summation orders of the dense
-                # product alone, scripts/error_attribution.py; hence 4 x here, 1 x at config size, and the
-                # tensor-scale bound below)
-                parity_8c("%s readout block %d (%s)" % (case, bi, "fused" if fused else "surface"), x, c, y, factor=4.0)
-                assert rel_err_inf(x, y) <= 1e-5
+                # robust statistics instead of a 4 x bar on the maximum (conftest.parity_8c_robust): high quantile
+                # within 1.5 x and mean within 1.25 x of the CPU fp32 run's, tensor scale within 1e-5, the maximum
+                # only as a 10 x tripwire
+                parity_8c_robust("%s readout block %d (%s)" % (case, bi, "fused" if fused else "surface"), x, c, y)
         h = model.entity_embed(graph.ndata["id"])
         for i, layer in enumerate(model.layers):
             h = layer(graph, h, fused=False)
@@ -1185,7 +1184,8 @@ def test_training_harness_end_to_end(K, dev):
 
 
 @pytest.mark.parametrize("d,k,n,R,B", [(64, 64, 3000, 9, 2048), (16, 32, 500, 3, 100), (32, 16, 500, 40, 2730),
-                                        (128, 128, 800, 5, 513), (8, 8, 60, 2, 1)])
+                                        (128, 128, 800, 5, 513), (8, 8, 60, 2, 1),
+                                        (16, 16, 3_000_000, 4, 2000)])   # entity ids beyond 2^19: the 64-bit sort keys
 def test_transr_fused_loss_and_gradients(K, dev, d, k, n, R, B):
     """Fused TransR step (kgat_transr_loss_grad_f32) against the torch restatement of reference
     models.py:114-133 (itself pinned to the reference's own output in the CPU suite): loss and the
@@ -1197,6 +1197,8 @@ def test_transr_fused_loss_and_gradients(K, dev, d, k, n, R, B):
         m.relation_embed.weight.mul_(3.0)
     g = torch.Generator().manual_seed(6)
     h = torch.randint(0, max(n // 20, 1), (B,), generator=g).to(dev)      # few distinct heads: many repeats
+    if n > (1 << 19):
+        h = (h + (n - n // 20 - 1)).clamp_(max=n - 1)                     # ... among the LARGEST ids
     r = torch.randint(0, R, (B,), generator=g)
     if R > 2:
         r[r == 1] = 0                                                     # relation 1 unused
@@ -1226,7 +1228,8 @@ def test_transr_fused_loss_and_gradients(K, dev, d, k, n, R, B):
 
 def test_transr_fused_refuses_what_it_cannot_do(K, dev):
     from dgl_kgat_amd import ops
-    assert not ops.transr_supported(1000, 64, 64, 5, 4096) and not ops.transr_supported(1 << 20, 64, 64, 5, 16)
+    assert not ops.transr_supported(1000, 64, 64, 5, 4096) and ops.transr_supported(1 << 20, 64, 64, 5, 16)
+    assert ops.transr_supported(10_000_000, 64, 64, 64, 2048)   # BASELINE configs[4]'s node count (round 4: 64-bit sort keys)
     m = K.KGATPropagation(100, 3, 16, 16, 1, 16, dropout=0.0).to(dev)
     idx = torch.zeros(4096, dtype=torch.long, device=dev)
     with pytest.raises(Exception):
