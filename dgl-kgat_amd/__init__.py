@@ -13,6 +13,7 @@ from .compat import accelerate, install_as_dgl  # noqa: F401
 from .ckg_io import CKGDataset  # noqa: F401
 from ._lib import KGATLibraryError  # noqa: F401
 from .lazy import enable as enable_lazy_edge_weights  # noqa: F401
+from .partition import GraphedForward  # noqa: F401
 
 __all__ = ["DGLGraph", "DGLError", "ALL", "function", "edge_softmax", "KGATConv", "KGATPropagation",
-           "install_as_dgl", "accelerate", "KGATLibraryError", "CKGDataset", "enable_lazy_edge_weights"]
+           "install_as_dgl", "accelerate", "KGATLibraryError", "CKGDataset", "enable_lazy_edge_weights", "GraphedForward"]

@@ -189,7 +189,10 @@ class KGATPropagation(nn.Module):
         h = self._node_embeddings(g)
         cache = [h]
         for li, layer in enumerate(self.layers):
-            h = shard_conv(g.partition, g, h, layer.res_fc_2.weight, 0.01, p, seed + li)
+            # (the gradient of a layer's input is needed in full only where that input is a replicated parameter -
+            # the embedding table under layer 0; deeper layers reduce it to the rows' owners)
+            h = shard_conv(g.partition, g, h, layer.res_fc_2.weight, 0.01, p, seed + li,
+                           owner_only_grad=li > 0 and os.environ.get("KGAT_SHARD_GRAD_ALLREDUCE", "") in ("", "0"))
             cache.append(F.normalize(h, p=2, dim=1))
         return torch.cat(cache, 1)
 

@@ -34,6 +34,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="2,3,4")
 ap.add_argument("--scale4", type=float, default=1.0, help="scale of configs[4] (1.0 = 10 M nodes / 200 M edges)")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--graphs", type=int, default=1,
+                help="1: also measure every rank's local step replayed as HIP graphs (partition.GraphedShardForward)")
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_scaling_model.json"))
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -59,7 +61,7 @@ for cfg in [int(c) for c in args.configs.split(",")]:
     widths = [layer.res_fc_2.out_features for layer in model.layers]
     steps = args.steps if E < 20_000_000 else max(args.steps // 4, 3)
     for P in (1, 2, 4, 8):
-        local, rows_per_rank, edges_per_rank = [], [], []
+        local, graphed, att, rows_per_rank, edges_per_rank = [], [], [], [], []
         bounds = None
         for r in range(P):
             if P == 1:
@@ -81,19 +83,55 @@ for cfg in [int(c) for c in args.configs.split(",")]:
                 step()
             torch.cuda.synchronize()
             local.append((time.perf_counter() - t0) / steps * 1e3)
+            with torch.no_grad():                           # the attention refresh alone (no exchange inside it)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    sg.edata["w"] = model.compute_attention(sg)
+                torch.cuda.synchronize()
+                att.append((time.perf_counter() - t0) / steps * 1e3)
+            if args.graphs:
+                gs = partition.GraphedShardForward(model, sg)
+                for _ in range(3):
+                    gs()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    gs()
+                torch.cuda.synchronize()
+                graphed.append((time.perf_counter() - t0) / steps * 1e3)
+                del gs
             rows_per_rank.append(n if P == 1 else int(bounds[r + 1] - bounds[r]))
             edges_per_rank.append(int(sg.number_of_edges()))
             if P > 1:
                 del sg
                 torch.cuda.empty_cache()
-        t_local = max(local)                                # the step ends when the slowest rank has its rows
+        t_eager = max(local)
+        t_local = max(graphed) if graphed else t_eager      # the step ends when the slowest rank has its rows
         S = [n * w * 4 for w in widths]
         frac_max = max(rows_per_rank) / n
         ar = [0.0 if P == 1 else (2 * (P - 1) / P * s / (LINK_GBS * 1e9) * 1e3 + LAUNCH_US * 1e-3) for s in S]
         ag = [0.0 if P == 1 else (frac_max * s / (LINK_GBS * 1e9) * 1e3 + LAUNCH_US * 1e-3) for s in S]
+        # exchange overlapped with compute (Partition.propagate_overlapped, K row blocks per layer: block k travels
+        # while block k + 1 is computed): a layer then costs max(c, x) + min(c, x) / K instead of c + x, with c the
+        # slowest rank's per-layer compute ((local - attention) / layers: an even split, not measured per layer)
+        K_CH = 4
+        slow = int(np.argmax(graphed if graphed else local))
+        c_layer = max(t_local - att[slow], 0.0) / len(widths)
+
+        def overlapped(xs):
+            return att[slow] + sum(max(c_layer, x) + min(c_layer, x) / K_CH for x in xs)
         row = {"config": key, "workload": desc, "P": P, "n_nodes": n, "n_edges": E, "layer_output_bytes": S,
-               "measured_local_ms_per_rank": [round(x, 4) for x in local],
+               "measured_attention_ms_per_rank": [round(x, 4) for x in att],
+               "model_overlap_chunks": K_CH,
+               "model_ms_per_step_allreduce_overlapped": round(t_local if P == 1 else overlapped(ar), 4),
+               "model_ms_per_step_allgather_overlapped": round(t_local if P == 1 else overlapped(ag), 4),
+               "model_exposed_exchange_ms_allgather_overlapped": round(0.0 if P == 1 else overlapped(ag) - t_local, 4),
+               "model_edges_per_s_allgather_overlapped": round(len(widths) * E / ((t_local if P == 1 else overlapped(ag)) * 1e-3), 1),
+               "measured_local_ms_per_rank_eager_launches": [round(x, 4) for x in local],
+               "measured_local_ms_per_rank_hip_graphs": [round(x, 4) for x in graphed],
                "measured_local_ms_slowest_rank": round(t_local, 4),
+               "measured_local_ms_slowest_rank_eager_launches": round(t_eager, 4),
                "rows_per_rank": rows_per_rank, "edges_per_rank": edges_per_rank,
                "model_allreduce_ms_per_layer": [round(x, 4) for x in ar],
                "model_allgather_ms_per_layer": [round(x, 4) for x in ag],
@@ -102,10 +140,11 @@ for cfg in [int(c) for c in args.configs.split(",")]:
                "model_edges_per_s_allreduce": round(len(widths) * E / ((t_local + sum(ar)) * 1e-3), 1),
                "model_edges_per_s_allgather": round(len(widths) * E / ((t_local + sum(ag)) * 1e-3), 1)}
         rows.append(row)
-        print("%s P=%d: local (slowest rank) %.3f ms | model all-reduce +%.3f -> %.3f ms (%.2f G edges/s) | model all-gather "
-              "+%.3f -> %.3f ms (%.2f G edges/s)" % (key, P, t_local, sum(ar), t_local + sum(ar),
+        print("%s P=%d: local (slowest rank) %.3f ms (eager launches %.3f) | model all-reduce +%.3f -> %.3f ms (%.2f G edges/s) | model all-gather "
+              "+%.3f -> %.3f ms (%.2f G edges/s), overlapped %.3f ms" % (key, P, t_local, t_eager, sum(ar), t_local + sum(ar),
                                                       row["model_edges_per_s_allreduce"] / 1e9, sum(ag), t_local + sum(ag),
-                                                      row["model_edges_per_s_allgather"] / 1e9), flush=True)
+                                                      row["model_edges_per_s_allgather"] / 1e9,
+                                                      row["model_ms_per_step_allgather_overlapped"]), flush=True)
     del g, model
     torch.cuda.empty_cache()
 
@@ -119,7 +158,8 @@ out = {"what": "MODEL of the 1/2/4/8-GPU curve: measured_* fields are per-rank l
                "arithmetic of SURVEY 5 and are NOT measurements",
        "link_model": {"xgmi_links_per_gpu": 7, "GBs_per_link_per_direction": LINK_GBS, "launch_us_per_collective": LAUNCH_US,
                       "allreduce": "ring: 2 (P-1)/P x S per link", "allgather": "direct: largest row slice per link",
-                      "overlap": "none assumed: exchange fully exposed after each layer"},
+                      "overlap": "model_ms_per_step_*: none (exchange fully exposed after each layer); model_*_overlapped: "
+                                 "Partition.propagate_overlapped with 4 row blocks per layer, max(c, x) + min(c, x) / 4 per layer"},
        "device": torch.cuda.get_device_properties(dev).name, "rows": rows}
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)

@@ -591,6 +591,16 @@ with torch.no_grad():
         assert len(set(gathered)) == 1, "ranks hold different assembled outputs"
         out2 = model.gnn(sg)                      # persistent exchange buffers: a second pass gives the same bits
         assert torch.equal(out, out2)
+        # the same exchange in two row blocks per rank, block k travelling while block k + 1 is computed
+        sg.partition.n_chunks = 2
+        out3 = model.gnn(sg)
+        assert float((out3 - ref).abs().max()) / float(ref.abs().max()) <= 2e-6, (mode, "chunked")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, hashlib.sha256(out3.cpu().numpy().tobytes()).hexdigest())
+        assert len(set(gathered)) == 1, "ranks hold different assembled outputs (chunked exchange)"
+        if mode != partition.EXCHANGE_MODES[0]:
+            assert gathered[0] == first_chunked, "exchange modes disagree (chunked exchange)"
+        first_chunked = gathered[0]
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -713,6 +723,19 @@ with torch.no_grad():
         assert torch.equal(out, first), mode
 print("forward ok: modes", partition.EXCHANGE_MODES)
 
+# 2b. the exchange overlapped with compute (three row blocks per layer, transfers on a side stream), every mode
+with torch.no_grad():
+    for mode in partition.EXCHANGE_MODES:
+        sg, keep = partition.shard_graph(g, 0, 1, mode=mode, force_collectives=True)
+        sg.partition.n_chunks = 3
+        sg.edata["w"] = model.compute_attention(sg)
+        out = model.gnn(sg)
+        assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (mode, "chunked")
+        first_c = out if mode == partition.EXCHANGE_MODES[0] else first_c
+        assert torch.equal(out, first_c), mode
+        assert torch.equal(out, model.gnn(sg))      # persistent buffers, side stream: a second pass gives the same bits
+print("overlapped forward ok")
+
 # 3. shard_conv backward (all_reduce of grad_h and grad_W2 through RCCL) against the one-GPU training stack
 model.train()
 users = torch.arange(0, 4000, device=dev) %% n
@@ -771,3 +794,32 @@ def test_smoke_gates_hold_on_three_parameter_seeds(dev, capsys):
     out = capsys.readouterr().out
     print(out)
     assert out.count("smoke ok") == 3
+
+
+def test_graphed_forward_replays_the_same_bits(dev):
+    """partition.GraphedForward: the step's launches captured once as HIP graphs and replayed - unsharded graph (one
+    graph) and a destination shard (one graph per stretch between two exchanges; world = 1, all exchange modes) -
+    must give the eager step's readout bit for bit, also after the parameters changed in place (an optimiser step)
+    and after a second replay."""
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import partition, synth
+    n, trip, R = synth.amazon_book_ckg(scale=0.05)
+    torch.manual_seed(21)
+    model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+
+    def eager(graph):
+        with torch.no_grad():
+            graph.edata["w"] = model.compute_attention(graph)
+            return model.gnn(graph).clone()
+    for graph in (g, partition.shard_graph(g, 0, 1, mode="allreduce")[0], partition.shard_graph(g, 1, 3, mode="broadcast")[0]):
+        if graph.partition is not None:
+            graph.partition.exchange_enabled = graph.partition.world == 1
+        ref = eager(graph)
+        gs = K.GraphedForward(model, graph)
+        assert torch.equal(gs(), ref) and torch.equal(gs(), ref)
+        with torch.no_grad():
+            model.entity_embed.weight.mul_(1.25)             # in-place parameter update between replays
+            model.layers[0].res_fc_2.weight.add_(0.01)
+        ref2 = eager(graph)
+        assert not torch.equal(ref2, ref) and torch.equal(gs(), ref2)

@@ -303,6 +303,23 @@ for mode in partition.EXCHANGE_MODES:              # the cheaper equivalents lea
     empty = partition.Partition(rank, world, [0] + [n] * world, n, mode=mode)   # rank 0 owns everything
     got = empty.exchange(full_ref[empty.lo:empty.hi].clone(), 16)
     assert torch.equal(got, full_ref), mode + " with empty slices"
+# the chunked exchange (Partition.propagate_overlapped moves one row block per rank at a time): block cuts known to
+# all ranks (plan_chunks: all_gather_object), every mode assembles the same bits piece by piece
+indptr = torch.zeros(n + 1, dtype=torch.int32)
+dst_loc = torch.as_tensor(np.asarray(trip)[np.asarray(keep), 0].astype(np.int64))
+indptr[1:] = torch.cumsum(torch.bincount(dst_loc, minlength=n), 0).to(torch.int32)
+for mode in ("allreduce", "broadcast", "p2p"):
+    q = partition.Partition(rank, world, p.bounds, n, mode=mode)
+    plan = q.plan_chunks(3, indptr)
+    rows = plan["rows"]
+    assert len(rows) == world and all(r[0] == q.bounds[i] and r[-1] == q.bounds[i + 1] and sorted(r) == r
+                                      for i, r in enumerate(rows))
+    assert plan["edges"][0] == int(indptr[q.lo]) and plan["edges"][-1] == int(indptr[q.hi])
+    full = q.new_buffer(16, torch.device("cpu"))
+    for k in range(3):
+        full[rows[rank][k]:rows[rank][k + 1]] = full_ref[rows[rank][k]:rows[rank][k + 1]]
+        q._assemble_pieces(full, [rows[r][k] for r in range(world)], [rows[r][k + 1] for r in range(world)])
+    assert torch.equal(full, full_ref), mode + " (chunked)"
 cnt = torch.tensor([len(keep)]); dist.all_reduce(cnt)
 assert int(cnt) == len(trip)
 dist.destroy_process_group()
