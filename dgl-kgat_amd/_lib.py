@@ -80,6 +80,7 @@ SIGNATURES = {
     "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,
                                          _p, _p, _p, _sz, _p]),
     "kgat_bi_interaction_f32": (_i32, [_i64, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64, _p]),
+    "kgat_bi_interaction_mul_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, _p, _p, _i64, _p, _i64, _p]),
     "kgat_l2_normalize_rows_f32": (_i32, [_i64, _i32, _p, _p, _i64, _p]),
     "kgat_readout_concat_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "kgat_sddmm_dot_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),

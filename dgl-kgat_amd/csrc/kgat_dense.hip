@@ -41,14 +41,23 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t index, uint32_
   return x >= threshold;
 }
 
-// TRAIN: the A operand is H * HN formed while loading (P = H, second factor HN), and the
-// LeakyReLU output goes through dropout (mess_drop of reference models.py:70) before it is
-// written and normalised.
-template <int DI, int DO, bool TRAIN, bool VEC_NORM>
+// MODE 0: the A operand is P as given.  MODE 1 (kgat_bi_interaction_mul_f32): A = H * HN formed while loading
+// (P = H, second factor HN) - the th.mul of reference models.py:66, which the aggregation used to form in its
+// epilogue at the price of a dependent X[v] load inside its edge loop (91 vs 78 us, profiles/
+// r04_spmm_epilogue_probe.txt) and which costs this kernel one more coalesced stream; the rows of H can also be
+// copied into a column slice of the readout on the way (ego block, models.py:159,168).  MODE 2 (training form): as
+// 1, and the LeakyReLU output goes through dropout (mess_drop of reference models.py:70) before it is written
+// and normalised.
+struct EgoCopy {
+  float* out;      // nullptr: off
+  int64_t stride;  // row stride in floats
+};
+template <int DI, int DO, int MODE, bool VEC_NORM>
 __global__ __launch_bounds__(256) void bi_interaction_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
     float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, uint32_t index0,
-    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride) {
+    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride, const EgoCopy ego) {
+  constexpr bool TRAIN = MODE == 2;
   constexpr int KS = DI / 4, KT = DO / 16;
   // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
   // laid out in B-fragment order so that every wave then pulls its fragments with
@@ -101,7 +110,12 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       const float4 v = pa[m * 4];
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
-    if (TRAIN) {
+    if (MODE >= 1) {
+      if (MODE == 1 && ego.out != nullptr && (t << 4) + i < n_rows) {
+        float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)ra * ego.stride) + q;
+#pragma unroll
+        for (int m = 0; m < DI / 16; ++m) pe[m * 4] = make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]);
+      }
       const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
@@ -252,11 +266,12 @@ __global__ __launch_bounds__(256) void readout_concat_kernel(int64_t n_rows, Rea
 // row, W2 (<= 1,024 floats) broadcast from LDS, the row's d_out results in registers.  Same epilogue as the MFMA
 // kernel (LeakyReLU, hash dropout in the training form, un-normalised rows + L2-normalised copy).  Replaces the
 // torch sequence Linear / leaky_relu / norm / cat (seven launches, ~35 us on the last-fm graph) by one of ~5 us.
-template <int DI, int DO, bool TRAIN>
+template <int DI, int DO, int MODE>
 __global__ __launch_bounds__(256) void bi_interaction_small_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
     float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, uint32_t index0,
-    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride) {
+    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride, const EgoCopy ego) {
+  constexpr bool TRAIN = MODE == 2;
   __shared__ float s_w[DO * DI];
   for (int idx = threadIdx.x; idx < DO * DI; idx += 256) s_w[idx] = W2[idx];
   __syncthreads();
@@ -268,7 +283,12 @@ __global__ __launch_bounds__(256) void bi_interaction_small_kernel(
       const float4 v = pa[m];
       a[4 * m] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
-    if (TRAIN) {
+    if (MODE >= 1) {
+      if (MODE == 1 && ego.out != nullptr) {
+        float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)row * ego.stride);
+#pragma unroll
+        for (int m = 0; m < DI / 4; ++m) pe[m] = make_float4(a[4 * m], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]);
+      }
       const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)row * DI);
 #pragma unroll
       for (int m = 0; m < DI / 4; ++m) {
@@ -321,7 +341,8 @@ static DropArgs drop_args(float p, uint64_t seed, int64_t row0, int d_out) {
 
 template <int DI, int DO>
 static int launch_bi(int64_t n_rows, const float* P, const float* HN, const float* W2, float slope,
-                     const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st) {
+                     const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st,
+                     int mode, const EgoCopy ego) {
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
 #ifndef KGAT_BI_MAX_BLOCKS
@@ -331,14 +352,16 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
   // 16-byte stores into the normalised copy need its slice 16-byte aligned with a row stride that keeps it so
   const bool vec = norm_out == nullptr ||
                    ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);
-#define KGAT_BI_LAUNCH(TR, VEC)                                                                                     \
-  hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, TR, VEC>), dim3((unsigned)blocks), dim3(256), 0, st,            \
+#define KGAT_BI_LAUNCH(MD, VEC)                                                                                     \
+  hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, MD, VEC>), dim3((unsigned)blocks), dim3(256), 0, st,            \
                      (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,     \
-                     norm_out, norm_stride)
-  if (HN) {
-    if (vec) KGAT_BI_LAUNCH(true, true); else KGAT_BI_LAUNCH(true, false);
+                     norm_out, norm_stride, ego)
+  if (mode == 2) {
+    if (vec) KGAT_BI_LAUNCH(2, true); else KGAT_BI_LAUNCH(2, false);
+  } else if (mode == 1) {
+    if (vec) KGAT_BI_LAUNCH(1, true); else KGAT_BI_LAUNCH(1, false);
   } else {
-    if (vec) KGAT_BI_LAUNCH(false, true); else KGAT_BI_LAUNCH(false, false);
+    if (vec) KGAT_BI_LAUNCH(0, true); else KGAT_BI_LAUNCH(0, false);
   }
 #undef KGAT_BI_LAUNCH
   KGAT_CHECK_LAUNCH("bi_interaction");
@@ -347,15 +370,17 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
 
 template <int DI, int DO>
 static int launch_bi_small(int64_t n_rows, const float* P, const float* HN, const float* W2, float slope,
-                           const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st) {
+                           const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st,
+                           int mode, const EgoCopy ego) {
   int64_t blocks = (n_rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (HN)
-    hipLaunchKernelGGL((bi_interaction_small_kernel<DI, DO, true>), dim3((unsigned)blocks), dim3(256), 0, st, (int32_t)n_rows,
-                       P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out, norm_out, norm_stride);
-  else
-    hipLaunchKernelGGL((bi_interaction_small_kernel<DI, DO, false>), dim3((unsigned)blocks), dim3(256), 0, st, (int32_t)n_rows,
-                       P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out, norm_out, norm_stride);
+#define KGAT_BI_SMALL_LAUNCH(MD)                                                                                          \
+  hipLaunchKernelGGL((bi_interaction_small_kernel<DI, DO, MD>), dim3((unsigned)blocks), dim3(256), 0, st, (int32_t)n_rows, \
+                     P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out, norm_out, norm_stride, ego)
+  if (mode == 2) KGAT_BI_SMALL_LAUNCH(2);
+  else if (mode == 1) KGAT_BI_SMALL_LAUNCH(1);
+  else KGAT_BI_SMALL_LAUNCH(0);
+#undef KGAT_BI_SMALL_LAUNCH
   KGAT_CHECK_LAUNCH("bi_interaction_small");
   return KGAT_OK;
 }
@@ -464,10 +489,10 @@ int kgat_bi_interaction_supported(int d_in, int d_out) {
 
 static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, const float* HN, const float* W2,
                        float negative_slope, const DropArgs& dr, float* h_out, float* norm_out,
-                       int64_t norm_stride, hipStream_t st) {
+                       int64_t norm_stride, hipStream_t st, int mode, const EgoCopy ego = EgoCopy{nullptr, 0}) {
 #define KGAT_BI_CASE(DI, DO) \
   if (d_in == DI && d_out == DO) \
-    return launch_bi<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st);
+    return launch_bi<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st, mode, ego);
   KGAT_BI_CASE(16, 16) KGAT_BI_CASE(16, 32) KGAT_BI_CASE(16, 64) KGAT_BI_CASE(16, 128)
   KGAT_BI_CASE(32, 16) KGAT_BI_CASE(32, 32) KGAT_BI_CASE(32, 64) KGAT_BI_CASE(32, 128)
   KGAT_BI_CASE(64, 16) KGAT_BI_CASE(64, 32) KGAT_BI_CASE(64, 64) KGAT_BI_CASE(64, 128)
@@ -475,7 +500,7 @@ static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, cons
 #undef KGAT_BI_CASE
 #define KGAT_BI_SMALL(DI, DO) \
   if (d_in == DI && d_out == DO) \
-    return launch_bi_small<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st);
+    return launch_bi_small<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st, mode, ego);
   KGAT_BI_SMALL(4, 4) KGAT_BI_SMALL(4, 8) KGAT_BI_SMALL(4, 16) KGAT_BI_SMALL(4, 32)
   KGAT_BI_SMALL(8, 4) KGAT_BI_SMALL(8, 8) KGAT_BI_SMALL(8, 16) KGAT_BI_SMALL(8, 32)
   KGAT_BI_SMALL(16, 4) KGAT_BI_SMALL(16, 8) KGAT_BI_SMALL(32, 4) KGAT_BI_SMALL(32, 8)
@@ -496,7 +521,25 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
     return KGAT_E_UNSUPPORTED;
   }
   return bi_dispatch(n_rows, d_in, d_out, P, nullptr, W2, negative_slope, DropArgs(), h_out, norm_out, norm_stride,
-                     as_stream(stream));
+                     as_stream(stream), 0);
+}
+
+int kgat_bi_interaction_mul_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN, const float* W2,
+                                float negative_slope, float* h_out, float* norm_out, int64_t norm_stride,
+                                float* self_out, int64_t self_stride, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX, "bi_interaction_mul: bad row count");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(H && HN && W2 && (h_out || norm_out), "bi_interaction_mul: null pointer");
+  KGAT_CHECK_ARG(norm_out == nullptr || norm_stride >= d_out, "bi_interaction_mul: bad norm_stride");
+  KGAT_CHECK_ARG(self_out == nullptr || (self_stride >= d_in && self_stride % 4 == 0 &&
+                                         (reinterpret_cast<uintptr_t>(self_out) & 15u) == 0),
+                 "bi_interaction_mul: self_out must be 16-byte aligned with a row stride that is a multiple of 4 floats >= d_in");
+  if (!kgat_bi_interaction_supported(d_in, d_out)) {
+    set_error("bi_interaction_mul: unsupported widths %d -> %d", d_in, d_out);
+    return KGAT_E_UNSUPPORTED;
+  }
+  return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, DropArgs(), h_out, norm_out, norm_stride,
+                     as_stream(stream), 1, EgoCopy{self_out, self_stride});
 }
 
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
@@ -514,7 +557,7 @@ int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const flo
     return KGAT_E_UNSUPPORTED;
   }
   return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, drop_args(drop_p, seed, row0, d_out), h_out,
-                     norm_out, norm_stride, as_stream(stream));
+                     norm_out, norm_stride, as_stream(stream), 2);
 }
 
 int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,

@@ -124,6 +124,10 @@ template <int LPR, bool MUL_SELF, bool COPY_SELF = false>
 __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4* __restrict__ X,
                                           int32_t row, int32_t row0, int sl, float4 v,
                                           const SelfCopy sc = SelfCopy{nullptr, 0}) {
+#ifdef KGAT_SPMM_STRIP_EPILOGUE  // A/B builds (WRONG results): what the launch takes without its row epilogue
+  if (v.x == 12345.678f) out[(size_t)(row - row0) * LPR + sl] = v;
+  return;
+#endif
   if (MUL_SELF) {
     const float4 x = X[(size_t)row * LPR + sl];
     v = mul4(v, x);
@@ -333,9 +337,15 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     EdgeRec rec;
     if (k < n_tile) {
       const int64_t p = tile0 + k;
+#ifdef KGAT_SPMM_STRIP_STAGE  // A/B builds (WRONG results): records made up instead of loaded
+      rec.c = (int32_t)(((uint32_t)p * 2654435761u) % (uint32_t)(e1 - e0 > 159251 ? 159251 : 1));
+      rec.r = (int32_t)(p >> 5) + row0;
+      rec.w = 1.0f;
+#else
       rec.c = col[p];
       rec.r = row_of[p];
       rec.w = w[p];
+#endif
     } else {
       rec.c = 0;
       rec.r = -1;
@@ -380,6 +390,20 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   int32_t cur_row = n_run > 0 ? run[0].r : -1;
   bool head_done = false;
   float2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+  // KGAT_SPMM_MUL_SELF loads X[row] when a row ENDS: a dependent round trip inside the edge loop - the wavefront's
+  // other lane groups and its gathers in flight wait for it (benchmark graph: 91.4 us with that epilogue against
+  // 77.5 us for the plain operator, profiles/r04_spmm_epilogue_probe.txt).  A/B arm KGAT_SPMM_SELF_PREFETCH=1:
+  // request it when the row OPENS instead.  The layer now forms h * h_N in the bi-interaction kernel
+  // (kgat_bi_interaction_mul_f32) and calls the plain operator.
+#ifndef KGAT_SPMM_SELF_PREFETCH
+#define KGAT_SPMM_SELF_PREFETCH 0  // measured SLOWER (100.7 vs 91.4 us at D = 64): the conditional load makes every later wait of the loop conservative
+#endif
+  constexpr bool SELF_PF = MUL_SELF && !FUSED && KGAT_SPMM_SELF_PREFETCH != 0;
+  float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto open_row = [&](int32_t row) {
+    cur_row = row;
+    if (SELF_PF) xs = X[(size_t)row * LPR + sl];
+  };
 
   auto flush = [&]() {  // the open row ends here
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
@@ -389,6 +413,9 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       head_done = true;
     } else if (FUSED) {
       put_row(cur_row, acc);
+    } else if (SELF_PF) {
+      if (COPY_SELF) sc.out[(size_t)(cur_row - row0) * sc.stride4 + sl] = xs;
+      out[(size_t)(cur_row - row0) * LPR + sl] = mul4(acc, xs);
     } else {
       store_row<LPR, MUL_SELF, COPY_SELF>(out, X, cur_row, row0, sl, acc, sc);
     }
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       for (int i = 0; i < G; ++i) {
         if (rec[i].r != cur_row) {
           flush();
-          cur_row = rec[i].r;
+          open_row(rec[i].r);
         }
         accum(rec[i].w, x[i]);
       }
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     const float4 x = X[(size_t)rec.c * LPR + sl];
     if (rec.r != cur_row) {
       flush();
-      cur_row = rec.r;
+      open_row(rec.r);
     }
     accum(rec.w, x);
   }

@@ -246,6 +246,8 @@ class KGATPropagation(nn.Module):
         # keeps a workgroup's gather slots idle, which costs the latency-bound aggregation more than the 82 MB
         # round trip of h * h_N costs the separate launch.
         fuse_bi = os.environ.get("KGAT_FUSE_BI", "0") not in ("", "0")
+        # KGAT_GNN_MUL_IN_SPMM=1: rounds 1-3's split - h * h_N in the aggregation's epilogue (A/B)
+        mul_in_spmm = os.environ.get("KGAT_GNN_MUL_IN_SPMM", "0") not in ("", "0")
         st = g._st
         scratch = None
         for li, layer in enumerate(self.layers):
@@ -259,6 +261,16 @@ class KGATPropagation(nn.Module):
                 h = ops.spmm_bi_fused(csr.indptr, csr.col, csr.row_of, h.contiguous(), st.csr_weights(w),
                                       layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out, want_h=not last,
                                       scratch=scratch, self_out=out[:, :widths[0]] if (li == 0 and copy_self) else None)
+                off += widths[li + 1]
+                continue
+            if not mul_in_spmm:
+                # the plain aggregation, and h * h_N formed by the dense kernel while it loads its rows (+ the ego
+                # block of the readout from the rows of layer 0's input): round 4 - the aggregation's h * h_N
+                # epilogue is a dependent X[v] load per finished row inside its edge loop, 91 vs 78 us per launch
+                hn = u_mul_e_sum(g, h, w)
+                h = ops.bi_interaction_mul(h.contiguous(), hn, layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out,
+                                           want_h=not last,
+                                           self_out=out[:, :widths[0]] if (li == 0 and copy_self) else None)
                 off += widths[li + 1]
                 continue
             if li == 0 and copy_self:

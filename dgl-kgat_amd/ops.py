@@ -565,6 +565,31 @@ def bi_interaction(P, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h
     return h_out
 
 
+def bi_interaction_mul(H, HN, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h=True, self_out=None):
+    """Z = leaky_relu((H * HN) @ W2^T) (kgat_bi_interaction_mul_f32): the layer input H and the plain aggregation HN,
+    the product formed while the rows are loaded; `self_out`: an (n, d_in) column slice that also receives H (the
+    ego block of the readout).  Otherwise as bi_interaction."""
+    H = _need(H, torch.float32, "H")
+    HN = _need(HN, torch.float32, "HN", H.shape)
+    W2 = _need(W2, torch.float32, "W2")
+    n, d_in = H.shape
+    d_out = W2.shape[0]
+    if W2.shape[1] != d_in:
+        raise ValueError("W2 has shape %s, expected (*, %d)" % (tuple(W2.shape), d_in))
+    if want_h and h_out is None:
+        h_out = torch.empty((n, d_out), dtype=torch.float32, device=H.device)
+    if h_out is not None:
+        h_out = _need(h_out, torch.float32, "h_out", (n, d_out))
+    stride = _strided_rows(norm_out, n, d_out, "norm_out") if norm_out is not None else 0
+    self_stride = _strided_rows(self_out, n, d_in, "self_out") if self_out is not None else 0
+    with _timed("bi_interaction", (n, d_in, d_out)):
+        check(_lib.load().kgat_bi_interaction_mul_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2), float(negative_slope),
+                                                      _ptr(h_out), _ptr(norm_out), stride, _ptr(self_out), self_stride,
+                                                      _stream(H)),
+              "kgat_bi_interaction_mul_f32")
+    return h_out
+
+
 def _strided_rows(t, n, d, name):
     if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (n, d) or t.stride(1) != 1):
         raise ValueError("%s must be an (n, %d) float32 device view with unit column stride" % (name, d))

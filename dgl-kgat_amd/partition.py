@@ -228,9 +228,9 @@ class Partition:
         for k in range(n_chunks):
             r0, r1 = mine[k], mine[k + 1]
             if r1 > r0:
-                prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, w_csr, mul_self=True, rows=(r0, r1 - r0),
-                                e_range=(edges[k], edges[k + 1]))
-                ops.bi_interaction(prod, w_c, 0.01, h_out=full[r0:r1])
+                hn = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, w_csr, rows=(r0, r1 - r0),
+                              e_range=(edges[k], edges[k + 1]))
+                ops.bi_interaction_mul(h_c[r0:r1], hn, w_c, 0.01, h_out=full[r0:r1])
             if not self.collectives_on:
                 continue
             done = torch.cuda.Event()
@@ -281,11 +281,12 @@ class Partition:
         st = g._st
         csr = st.csr(h.device)
         w_csr = st.csr_weights(g.edata["w"])
-        prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
-                        rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
+        h_c = h.detach().contiguous()
+        hn = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, w_csr, rows=(self.lo, self.hi - self.lo),
+                      e_range=(0, st.n_edges))
         full = self.new_buffer(weight.shape[0], h.device, slot=slot)
-        if self.hi > self.lo:
-            ops.bi_interaction(prod, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
+        if self.hi > self.lo:   # h * h_N is formed by the dense kernel while it loads its rows
+            ops.bi_interaction_mul(h_c[self.lo:self.hi], hn, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
         return full
 
     def propagate_fused(self, g, h, weight, slot=None):
@@ -294,15 +295,7 @@ class Partition:
         exchange buffer, then exchanged.  `slot`: see new_buffer."""
         if self.n_chunks > 1 and h.is_cuda:
             return self.propagate_overlapped(g, h, weight, self.n_chunks, slot=slot)
-        st = g._st
-        csr = st.csr(h.device)
-        w_csr = st.csr_weights(g.edata["w"])
-        prod = ops.spmm(csr.indptr, csr.col, csr.row_of, h.detach().contiguous(), w_csr, mul_self=True,
-                        rows=(self.lo, self.hi - self.lo), e_range=(0, st.n_edges))
-        full = self.new_buffer(weight.shape[0], h.device, slot=slot)
-        if self.hi > self.lo:
-            ops.bi_interaction(prod, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
-        return self.assemble(full)
+        return self.assemble(self.local_into_buffer(g, h, weight, slot=slot))
 
 
 class GraphedForward:

@@ -319,6 +319,17 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
                             float negative_slope, float* h_out, float* norm_out,
                             int64_t norm_stride, kgat_stream_t stream);
 
+/* The same with the product formed on the way (round 4): Z = LeakyReLU_slope((H * HN) @ W2^T) - reference
+ * models.py:66's th.mul(g.ndata['h'], g.ndata['h_neighbor']) + res_fc_2 + LeakyReLU, and models.py:165's normalize -
+ * from the layer input H and the plain aggregation HN = update_all(u_mul_e, sum) (both n_rows x d_in), so that the
+ * aggregation needs no epilogue (its KGAT_SPMM_MUL_SELF form pays a dependent load per finished row inside the edge
+ * loop: 91 vs 78 us on the benchmark graph).  self_out (may be NULL): the rows of H are also copied to
+ * self_out[row * self_stride + 0..d_in) - the ego block [h0 | ...] of Model.gnn's readout (models.py:159,168);
+ * 16-byte aligned, self_stride a multiple of 4 floats.  Same bits as KGAT_SPMM_MUL_SELF + kgat_bi_interaction_f32. */
+int kgat_bi_interaction_mul_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN, const float* W2,
+                                float negative_slope, float* h_out, float* norm_out, int64_t norm_stride,
+                                float* self_out, int64_t self_stride, kgat_stream_t stream);
+
 /* ---------------------------------------------------------------- one KGATConv forward in one pass (S1 + B1 + B2)
  * Replaces reference models.py:63-66 (update_all(u_mul_e, sum); th.mul; res_fc_2; LeakyReLU) and the
  * F.normalize of models.py:165 for the no-grad forward: kgat_spmm_umule_sum_f32 with KGAT_SPMM_MUL_SELF

@@ -875,6 +875,38 @@ def test_bi_interaction_vs_oracle(K, dev, d_in, d_out):
     assert not ops.bi_interaction_supported(8, 64) and not ops.bi_interaction_supported(12, 12)
 
 
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (128, 128), (16, 128), (8, 8), (16, 8), (4, 32)])
+def test_bi_interaction_mul_same_bits_as_the_spmm_epilogue(K, dev, d_in, d_out):
+    """kgat_bi_interaction_mul_f32 (h * h_N formed while the dense kernel loads its rows, ego block copied on the way)
+    against the round 1-3 split - the product in the aggregation's epilogue (KGAT_SPMM_MUL_SELF + self_out), then
+    kgat_bi_interaction_f32: the same bits in h_out, in the normalised slice and in the ego slice; nothing outside
+    the slices touched; row counts around the 16-row tile."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(300 + d_in + d_out)
+    for n in (1, 15, 16, 17, 4001):
+        e = 12 * n
+        src, dst = random_graph(n + d_in, n, e, hub=min(e // 3, 3000), isolated_tail=n // 10)
+        X = tf(rng.standard_normal((n, d_in)).astype(np.float32), dev)
+        W2 = tf((rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32), dev)
+        indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        w_csr = tf(rng.random(e).astype(np.float32), dev)
+        can_copy = d_in % 4 == 0 and d_in >= 16
+        ego_a = torch.full((n, d_in + 8), 5.0, device=dev)
+        prod = ops.spmm(indptr, col, row_of, X, w_csr, mul_self=True,
+                        self_out=ego_a[:, 4:4 + d_in] if can_copy else None)
+        wide_a = torch.full((n, d_out + 24), 9.0, device=dev)
+        h_a = ops.bi_interaction(prod, W2, 0.01, norm_out=wide_a[:, 8:8 + d_out])
+        hn = ops.spmm(indptr, col, row_of, X, w_csr)
+        ego_b = torch.full((n, d_in + 8), 5.0, device=dev)
+        wide_b = torch.full((n, d_out + 24), 9.0, device=dev)
+        h_b = ops.bi_interaction_mul(X, hn, W2, 0.01, norm_out=wide_b[:, 8:8 + d_out],
+                                     self_out=ego_b[:, 4:4 + d_in] if can_copy else None)
+        assert torch.equal(h_a, h_b) and torch.equal(wide_a, wide_b), (n, float((h_a - h_b).abs().max()))
+        if can_copy:
+            assert torch.equal(ego_a, ego_b) and torch.equal(ego_b[:, 4:4 + d_in], X)
+        assert ops.bi_interaction_mul(X, hn, W2, 0.01, norm_out=wide_b[:, 8:8 + d_out], want_h=False) is None
+
+
 def test_autograd_matches_oracle(K, dev):
     from dgl_kgat_amd import synth
     from dgl_kgat_amd.autograd import edge_softmax, u_mul_e_sum
