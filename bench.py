@@ -135,7 +135,7 @@ def hbm_resident_spmm_leg(args, dev):
     # Where the 2.56 GB gathered table lands PHYSICALLY moves this launch by 10-14 % on one box with
     # the same bytes: fresh allocations of the same size at the same virtual address fall into a fast
     # (9.2-9.4 ms) or a slow (10.3-10.5 ms) mode, allocation by allocation (scripts/placement_study.py;
-    # DESIGN.md 3.1).  A long-lived table is allocated once, so the leg does what a deployment can do
+    # NOTEBOOK.md 3.1).  A long-lived table is allocated once, so the leg does what a deployment can do
     # once: it draws up to twelve candidate allocations (about one in five was fast on the boxes seen; round 3
     # stopped after four alike and then sat in the slow mode on such a box), times two launches on each,
     # keeps the fastest and frees the others - and reports every candidate's time, so the slow mode is on
@@ -222,7 +222,7 @@ def hbm_resident_spmm_leg(args, dev):
     b = e * (4 * D + 8) + n * (4 * D + 4)
     med = float(np.median(t))
     ach = b / (med * 1e-3) / 1e9
-    traffic, tfile = committed_traffic("pmc_spmm_traffic_powerlaw.json", ("kgat_spmm.hip", "kgat_common.h"))
+    traffic, tfile = committed_traffic("pmc_spmm_traffic_powerlaw.json", ("kgat_spmm.hip", "kgat_spmm_impl.h", "kgat_common.h"))
     if (n, e) != (10_000_000, 200_000_000):
         traffic, tfile = None, None
     return {"bound": "hbm", "kernel": "kgat_spmm_umule_sum_f32 (spmm_merge2_kernel + spmm_finish_kernel), D=%d: "
@@ -246,7 +246,7 @@ def hbm_resident_spmm_leg(args, dev):
                           "note": "one launch-time per candidate allocation of X (same size, fresh hipMalloc each, all "
                                   "held until the choice); headline = the median candidate, frac_best = the fastest, "
                                   "frac_first_allocation = the first as it came: a table's physical placement moves "
-                                  "this launch by 10-14 % on one box, DESIGN.md 3.1"},
+                                  "this launch by 10-14 % on one box, NOTEBOOK.md 3.1"},
             "with_hmul_epilogue": None if t_epi is None else {
                 "median_ms": round(float(np.median(t_epi)), 4),
                 "frac": round(b / (float(np.median(t_epi)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -667,7 +667,7 @@ def main():
     if world == 1 and args.scale == 1.0 and D == 64:
         suffix = {"amazon-book": "pmc_spmm_traffic.json", "power-law": "pmc_spmm_traffic_powerlaw.json"}.get(args.workload)
         if suffix:
-            traffic, traffic_file = committed_traffic(suffix, ("kgat_spmm.hip", "kgat_common.h"))
+            traffic, traffic_file = committed_traffic(suffix, ("kgat_spmm.hip", "kgat_spmm_impl.h", "kgat_common.h"))
     cache_served = n * D * 4 < 256 * 2 ** 20
     # cold-cache variant: a 1 GiB fill ahead of every launch evicts X, indices and
     # weights from L2 and the Infinity Cache, so the launch starts from HBM

@@ -1,6 +1,6 @@
 // Persistent-wavefront attention-logit kernels (d == k <= 64): the one-kernel form
 // (att_score_persistent_kernel) and the split form (att_split_kernel, MODE_HEAD / MODE_TAIL);
-// overview in kgat_att.hip, measurements and the cost model in DESIGN.md 3.2.
+// overview in kgat_att.hip, measurements and the cost model in DESIGN.md 3.2 / NOTEBOOK.md 3.2.
 // Separate translation unit because it is built with -mllvm -amdgpu-mfma-vgpr-form=1 (MFMA
 // results in VGPRs, no v_accvgpr_read copies in the epilogue), which the LDS-staged chunk
 // kernels of kgat_att.hip do not want (it costs them occupancy).

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 src = sys.argv[1]
-prefix = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r03_"
+prefix = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r04_"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 for f in sorted(os.listdir(src)):

@@ -129,7 +129,8 @@ def main():
             if a == "rows_ordered":
                 fns[a] = lambda: ops.spmm(indptr, col, row_of, X, w_csr, out=out, order=order, algo="rows", workspace=ws)
             else:
-                fns[a] = lambda a=a: ops.spmm(indptr, col, row_of, X, w_csr, out=out, algo=a, workspace=ws, mul_self=True)
+                fns[a] = lambda a=a: ops.spmm(indptr, col, row_of, X, w_csr, out=out, algo=a, workspace=ws,
+                                              mul_self=os.environ.get("KBENCH_MUL_SELF", "0") == "1")  # (round 4: the step calls the plain operator)
         if args.same_rows:  # diagnostic: every edge gathers one of 16 rows (cache resident)
             col16 = col % 16
             fns["merge_samerows"] = lambda: ops.spmm(indptr, col16, row_of, X, w_csr, out=out, algo="merge", workspace=ws, mul_self=True)

@@ -1,7 +1,7 @@
 // Wave-role forms of the two fused attention kernels: EXPERIMENTS of round 3, not part of the shipped
 // library.  Included by kgat_att_persistent.hip only under -DKGAT_ATT_WAVE_ROLES (scripts/micro/
 // att_variants_ab.py, att_ws_phases.py); uses that file's helpers (split_bf16x3, mfma_bf16, the stamp macros).
-// Kept as the record of what was measured - DESIGN.md 3.2, profiles/r03_att_wave_roles.txt.
+// Kept as the record of what was measured - NOTEBOOK.md 3.2, profiles/r03_att_wave_roles.txt.
 #pragma once
 // (included inside namespace kgat)
 

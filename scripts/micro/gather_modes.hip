@@ -1,4 +1,4 @@
-// Placement probe without the rest of the stack: an N-row table far beyond the
+// Placement probe without the rest of the stack (NOTEBOOK.md 3.1): an N-row table far beyond the
 // Infinity Cache, E uniformly random 256-byte row reads per pass, freshly hipMalloc'ed tables one
 // after the other, for several ROW STRIDES.  If the fast / slow modes of the HBM-resident SpMM come
 // from how a physical block's 256-byte rows spread over DRAM channels, a stride that is not a

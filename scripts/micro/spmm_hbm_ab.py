@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: build-time variants of the merge SpMM (-D flags of csrc/kgat_spmm.hip) on the
 HBM-resident 10 M / 200 M graph, alternating launch by launch on ONE allocation of the gathered
-table (so the placement mode of DESIGN.md 3.1 is common to all arms), plus the cache-served
+table (so the placement mode of NOTEBOOK.md 3.1 is common to all arms), plus the cache-served
 amazon-book graph.  Only kgat_spmm.hip is recompiled per variant.
 
   python scripts/micro/spmm_hbm_ab.py "-DKGAT_SPMM_GROUP=8" "-DKGAT_SPMM_GROUP=2" ...

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Why does the HBM-resident SpMM run in a fast or a slow mode depending on the ALLOCATION of the
-gathered table?  One tool (it replaces the round-2 probes placement_probe{,2,3}.py,
+gathered table (NOTEBOOK.md 3.1)?  One tool (it replaces the round-2 probes placement_probe{,2,3}.py,
 interleave_probe.py, pl_step_probe.py):
 
   python scripts/placement_study.py modes [--tries 16]

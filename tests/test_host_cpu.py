@@ -330,12 +330,26 @@ print("rank", rank, "ok")
 def test_partition_exchange_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:   # a free rendezvous port, not a fixed one
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    logs = [tmp_path / ("rank%d.log" % r) for r in range(2)]
+    procs = []
+    for r in range(2):   # output to files: a rank blocked on a full pipe while its peer waits in a collective would hang
+        with open(logs[r], "wb") as fh:
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=fh,
+                                          stderr=subprocess.STDOUT))
+    try:
+        for p in procs:
+            p.wait(timeout=300)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log.read_text()[-3000:]
 
 
 @pytest.mark.parametrize("case", ["toy_d8", "toy_d16_k32", "toy_d64"])
