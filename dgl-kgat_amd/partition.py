@@ -358,10 +358,11 @@ class GraphedForward:
                 if li == 0:
                     attention(state)
                     state["blocks"] = [model._node_embeddings(g).detach()] + [None] * len(layers)
-                state["full"] = part.local_into_buffer(g, state["blocks"][li], layer.res_fc_2.weight, slot=li)
+                # (per-layer keys: at replay time the Python side of every stretch is frozen to what the capture left)
+                state["full", li] = part.local_into_buffer(g, state["blocks"][li], layer.res_fc_2.weight, slot=li)
 
             def exchange(state, li=li):
-                state["blocks"][li + 1] = part.assemble(state["full"])   # (the partition's persistent buffer of slot li)
+                state["blocks"][li + 1] = part.assemble(state["full", li])   # (the partition's persistent buffer of slot li)
             stretches.append((local, exchange))
 
         def readout(state):

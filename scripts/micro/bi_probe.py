@@ -50,10 +50,15 @@ for d_in, d_out in ((64, 64), (64, 32), (32, 16)):
     h = torch.empty((n, d_out), device=dev)
     nrm = wide[:, 64:64 + d_out]
     dense = torch.empty((n, d_out), device=dev)
+    HN = torch.randn(n, d_in, device=dev)
+    ego = wide[:, :d_in] if d_in == 64 else None
     for name, lib in variants.items():
-        if name != "shipped":
-            _lib._lib = lib
-            print("   %s: both %.1f us" % (name, ev(lambda: ops.bi_interaction(P, W2, 0.01, h_out=h, norm_out=nrm))))
+        _lib._lib = lib
+        print("   %s: product formed on the way (kgat_bi_interaction_mul_f32%s) %.1f us%s" % (
+            name, ", ego block copied" if ego is not None else "",
+            ev(lambda: ops.bi_interaction_mul(P, HN, W2, 0.01, h_out=h, norm_out=nrm, self_out=ego)),
+            "" if name == "shipped" else " | plain form, both outputs %.1f us" % ev(
+                lambda: ops.bi_interaction(P, W2, 0.01, h_out=h, norm_out=nrm))))
     _lib._lib = base
     print("%d -> %d: both %.1f us | h only %.1f | norm (strided 176) only %.1f | norm (dense) only %.1f | torch copy of P %.1f | "
           "torch mm %.1f" % (

@@ -601,6 +601,15 @@ with torch.no_grad():
         if mode != partition.EXCHANGE_MODES[0]:
             assert gathered[0] == first_chunked, "exchange modes disagree (chunked exchange)"
         first_chunked = gathered[0]
+    # the stretches between the exchanges replayed as HIP graphs, the collectives staying eager calls between the
+    # replays (round 4: the first form kept ONE "current buffer" on the Python side, which a replay finds frozen at
+    # the last layer's - every exchange then assembled the wrong buffer)
+    os.environ["KGAT_EXCHANGE"] = "allreduce"
+    sg, keep = partition.shard_graph(g, rank, world)
+    sg.edata["w"] = model.compute_attention(sg)
+    eager = model.gnn(sg).clone()
+    gs = K.GraphedForward(model, sg)
+    assert torch.equal(gs(), eager) and torch.equal(gs(), eager), "graph replay differs from the eager sharded step"
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
