@@ -98,6 +98,29 @@ def one(seed):
         o = ops.spmm(indptr, col, row_of, tf(X), w_csr, rows=(lo, hi - lo), e_range=(e0, e1), algo=algo).cpu().numpy()
         assert sum_err(o, r_[lo:hi], r_abs[lo:hi]) < tol, "spmm row range " + algo
     stage("spmm D=%d" % D)
+    # round 4: the dense part with the product formed on the way, and the one-launch layer - both must give the bits
+    # of the round 1-3 split (product in the aggregation's epilogue, then kgat_bi_interaction_f32), whole graph and
+    # row range, with and without the ego copy
+    if D in (16, 32, 64) and e > 0:
+        d_out = int(rng.choice([w_ for w_ in (16, 32, 64) if w_ <= D]))
+        W2 = tf((rng.standard_normal((d_out, D)) / np.sqrt(D)).astype(np.float32))
+        Xd = tf(X)
+        for rows_kw, sl in ((dict(), slice(0, n)), (dict(rows=(lo, hi - lo), e_range=(e0, e1)), slice(lo, hi))):
+            nr = sl.stop - sl.start
+            if nr == 0:
+                continue
+            prod = ops.spmm(indptr, col, row_of, Xd, w_csr, mul_self=True, **rows_kw)
+            wide_a = torch.full((nr, d_out + 8), 3.0, device=dev)
+            h_a = ops.bi_interaction(prod, W2, 0.01, norm_out=wide_a[:, 4:4 + d_out])
+            hn = ops.spmm(indptr, col, row_of, Xd, w_csr, **rows_kw)
+            wide_b = torch.full((nr, d_out + 8), 3.0, device=dev)
+            ego = torch.full((nr, D + 4), 2.0, device=dev)
+            h_b = ops.bi_interaction_mul(Xd[sl], hn, W2, 0.01, norm_out=wide_b[:, 4:4 + d_out], self_out=ego[:, 4:4 + D])
+            assert torch.equal(h_a, h_b) and torch.equal(wide_a, wide_b) and torch.equal(ego[:, 4:], Xd[sl]), "bi_interaction_mul"
+            wide_c = torch.full((nr, d_out + 8), 3.0, device=dev)
+            h_c = ops.spmm_bi_fused(indptr, col, row_of, Xd, w_csr, W2, 0.01, norm_out=wide_c[:, 4:4 + d_out], **rows_kw)
+            assert torch.equal(h_a, h_c) and torch.equal(wide_a, wide_c), "spmm_bi_fused"
+        stage("dense D=%d->%d" % (D, d_out))
     # attention: every form that supports the shape
     R = int(rng.choice([1, 2, 5, 41]))
     d = int(rng.choice([16, 32, 64, 64, 128]))
