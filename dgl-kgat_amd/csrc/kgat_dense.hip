@@ -31,6 +31,29 @@ __device__ __forceinline__ float row16_sum_d(float v) {
   return v;
 }
 
+#ifndef KGAT_BI_NT_LOADS
+#define KGAT_BI_NT_LOADS 0   // A/B builds: the row streams as non-temporal loads (measured 25-70 % SLOWER: profiles/r04_bi_probe.txt)
+#endif
+#ifndef KGAT_BI_NT_STORES
+#define KGAT_BI_NT_STORES 0  // A/B builds: the normalised slice and the ego block as non-temporal stores (no change)
+#endif
+__device__ __forceinline__ float4 ld_row4(const float4* p) {
+#if KGAT_BI_NT_LOADS
+  const floatx4_d v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_d*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_final4(float4* p, const float4& v) {
+#if KGAT_BI_NT_STORES
+  const floatx4_d x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<floatx4_d*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // Dropout mask of the training form: a counter-based hash of (seed, element index), so the backward
 // pass recomputes the mask instead of storing it.  keep <=> hash >= p * 2^32.
 __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t index, uint32_t threshold) {
@@ -107,19 +130,19 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     const float4* pa = reinterpret_cast<const float4*>(P + (size_t)ra * DI) + q;
 #pragma unroll
     for (int m = 0; m < DI / 16; ++m) {
-      const float4 v = pa[m * 4];
+      const float4 v = ld_row4(pa + m * 4);
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
     if (MODE >= 1) {
       if (MODE == 1 && ego.out != nullptr && (t << 4) + i < n_rows) {
         float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)ra * ego.stride) + q;
 #pragma unroll
-        for (int m = 0; m < DI / 16; ++m) pe[m * 4] = make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]);
+        for (int m = 0; m < DI / 16; ++m) st_final4(pe + m * 4, make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]));
       }
       const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
-        const float4 v = pb[m * 4];
+        const float4 v = ld_row4(pb + m * 4);
         a[4 * m + 0] *= v.x; a[4 * m + 1] *= v.y; a[4 * m + 2] *= v.z; a[4 * m + 3] *= v.w;
       }
     }
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
         if (norm_out) {
           float* dst = norm_out + (size_t)row * norm_stride + 16 * c + 4 * q;
           if (VEC_NORM) {
-            *reinterpret_cast<float4*>(dst) = make_float4(z0 * inv, z1 * inv, z2 * inv, z3 * inv);
+            st_final4(reinterpret_cast<float4*>(dst), make_float4(z0 * inv, z1 * inv, z2 * inv, z3 * inv));
           } else {
             dst[0] = z0 * inv; dst[1] = z1 * inv; dst[2] = z2 * inv; dst[3] = z3 * inv;
           }

@@ -133,6 +133,8 @@ __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4
     v = mul4(v, x);
     if (COPY_SELF) sc.out[(size_t)(row - row0) * sc.stride4 + sl] = x;
   }
+  // (round 4 tried write-through `sc1` stores here, which do not keep the output rows' lines in the XCD's L2: no change,
+  // 0.0867 vs 0.0868 ms - profiles/r04_spmm_cache_policy_ab.txt)
   out[(size_t)(row - row0) * LPR + sl] = v;
 }
 
@@ -277,6 +279,9 @@ struct alignas(16) EdgeRec {
   int32_t pad;
 };
 
+#ifndef KGAT_SPMM_REC_NT
+#define KGAT_SPMM_REC_NT 0
+#endif
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false, int DO = 0>
 __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
@@ -342,9 +347,17 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       rec.r = (int32_t)(p >> 5) + row0;
       rec.w = 1.0f;
 #else
+#if KGAT_SPMM_REC_NT  // A/B arm: the once-read record streams as non-temporal loads.  Stand-alone launches back to back
+                      // gain 3 % (D = 64) / 7 % (D = 32) - profiles/r04_spmm_cache_policy_ab.txt -, the step does not
+                      // (aggregation 70.1 vs 68.8 us avg): default off
+      rec.c = __builtin_nontemporal_load(col + p);
+      rec.r = __builtin_nontemporal_load(row_of + p);
+      rec.w = __builtin_nontemporal_load(w + p);
+#else
       rec.c = col[p];
       rec.r = row_of[p];
       rec.w = w[p];
+#endif
 #endif
     } else {
       rec.c = 0;

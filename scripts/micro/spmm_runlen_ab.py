@@ -21,7 +21,7 @@ objs, procs = [], []
 for src, extra in _lib.SOURCES.items():
     obj = "/tmp/nomid_%s.o" % src.replace(".hip", "")
     objs.append(obj)
-    procs.append(subprocess.Popen([_lib._hipcc()] + _lib.BASE_FLAGS + extra + [os.environ.get("AB_FLAG", "-DKGAT_SPMM_MID_LIMIT=0"), tag, "-c",
+    procs.append(subprocess.Popen([_lib._hipcc()] + _lib.BASE_FLAGS + extra + os.environ.get("AB_FLAG", "-DKGAT_SPMM_MID_LIMIT=0").split() + [tag, "-c",
                                    os.path.join(_lib.CSRC, src), "-o", obj]))
 for p in procs:
     assert p.wait() == 0
@@ -53,7 +53,7 @@ for wl, mk in (("amazon-book", synth.amazon_book_ckg), ("last-fm", synth.last_fm
                 _lib._lib = lib
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                o = ops.spmm(indptr, col, row_of, X, w, algo="merge", mul_self=True)
+                o = ops.spmm(indptr, col, row_of, X, w, algo="merge", mul_self=os.environ.get("AB_MUL_SELF", "1") == "1")
                 b.record()
                 torch.cuda.synchronize()
                 if it >= 3:
