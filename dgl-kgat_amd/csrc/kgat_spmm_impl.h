@@ -386,13 +386,13 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   }
   // a complete row of the fused form: P = h * h_N into the LDS row buffer (slot = row - first row of the
   // tile), or into the global scratch when the tile spans more rows than the buffer holds
+  // (h_N only: the product with the row's own features - and the ego copy - is formed by the dense tail, which loads
+  // X[v] for whole 16-row blocks; loading it HERE is a dependent round trip inside the edge loop, the very epilogue
+  // that cost the plain operator 14 us per launch - profiles/r04_spmm_epilogue_probe.txt)
   auto put_row = [&](int32_t row, const float4& acc) {
-    const float4 x = X[(size_t)row * LPR + sl];
-    if (COPY_SELF) sc.out[(size_t)(row - row0) * sc.stride4 + sl] = x;
-    const float4 v = mul4(acc, x);
     const int32_t slot = row - first_row;
-    if (slot < CAP) s_P[slot * PS4 + sl] = v;
-    else out[(size_t)(row - row0) * LPR + sl] = v;
+    if (slot < CAP) s_P[slot * PS4 + sl] = acc;
+    else out[(size_t)(row - row0) * LPR + sl] = acc;
   };
 
   const EdgeRec* run = s_rec + sub * C;
@@ -626,10 +626,24 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
         const int32_t lr = 16 * bb + i;
         const bool valid = bb < nblk && lr < nrows;
         float a[KS];
+        // the rows' own features (requested first: they come from L2 / the Infinity Cache while the LDS reads run)
+        const float4* px = X + (size_t)(rbase + (valid ? lr : 0)) * LPR + q;
+        float4 xv[DI / 16];
+#pragma unroll
+        for (int m = 0; m < DI / 16; ++m) xv[m] = px[4 * m];
 #pragma unroll
         for (int m = 0; m < DI / 16; ++m) {
           const float4 v = src[(valid ? lr : 0) * PS4 + 4 * m + q];
           a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
+        }
+        if (COPY_SELF && c_tile == 0 && valid) {   // ego block of the readout: one wavefront of the four writes it
+          float4* pe = sc.out + (size_t)(rbase + lr - row0) * sc.stride4 + q;
+#pragma unroll
+          for (int m = 0; m < DI / 16; ++m) pe[4 * m] = xv[m];
+        }
+#pragma unroll
+        for (int m = 0; m < DI / 16; ++m) {
+          a[4 * m + 0] *= xv[m].x; a[4 * m + 1] *= xv[m].y; a[4 * m + 2] *= xv[m].z; a[4 * m + 3] *= xv[m].w;
         }
         const floatx4_s z = bi_col_tile<KS>(a, wf, bi.slope);
         float tot = tile_ssq(z);

@@ -67,10 +67,12 @@ for d_in, d_out in ((64, 64), (64, 32), (32, 16)):
     ws = ops.spmm_workspace(E, d_in, dev)
     prod = torch.empty((n, d_in), device=dev)
     h = torch.empty((n, d_out), device=dev)
-    two_a = lambda: ops.spmm(indptr, col, row_of, X, w, mul_self=True, out=prod, workspace=ws)
-    two_b = lambda: ops.bi_interaction(prod, W2, 0.01, h_out=h, norm_out=wide[:, 64:64 + d_out])
+    ego = wide[:, :64] if (d_in == 64 and d_out == 64) else None   # layer 0 of the readout also copies its input rows
+    # round 4's split: the plain operator, then the dense kernel forming h * h_N while it loads its rows
+    two_a = lambda: ops.spmm(indptr, col, row_of, X, w, out=prod, workspace=ws)
+    two_b = lambda: ops.bi_interaction_mul(X, prod, W2, 0.01, h_out=h, norm_out=wide[:, 64:64 + d_out], self_out=ego)
     one = lambda: ops.spmm_bi_fused(indptr, col, row_of, X, w, W2, 0.01, h_out=h, norm_out=wide[:, 64:64 + d_out],
-                                    scratch=prod, workspace=ws)
+                                    scratch=prod, workspace=ws, self_out=ego)
     res = {"spmm": [], "bi": [], "two": []}
     for rep in range(3):
         _lib._lib = base
