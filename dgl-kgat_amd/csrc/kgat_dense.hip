@@ -155,12 +155,17 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     // operands swapped (A = W2 fragment, B = the tile's rows): the accumulators hold Z^T, i.e.
     // acc[c][j] = Z[row0 + i][16c + 4q + j] - four consecutive columns per lane, so the results
     // leave as 16-byte stores (a quarter of the store instructions of the row-major result)
+#ifdef KGAT_BI_STRIP_MFMA  // A/B builds (WRONG results): the launch without its matrix work - what the row streams alone take
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){a[(4 * c) % KS], a[(4 * c + 1) % KS], a[(4 * c + 2) % KS], a[(4 * c + 3) % KS]};
+#else
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < KT; ++c)
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             W_IN_LDS ? s_w[(s * KT + c) * kWave + lane] : wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c], a[s], acc[c], 0, 0, 0);
+#endif
     const int32_t row = row0 + i;
     // row norm: per 16-column tile the sum of squares over the row's four lanes (i, q = 0..3), then the tiles'
     // partials in tile order - the order of the fused aggregation + dense launch (kgat_spmm_impl.h: tile_ssq),
