@@ -534,7 +534,10 @@ def main():
     # ordinary calls between the replays): the same kernels on the same buffers, the same bits.  Informational - the
     # step is bound by its kernels, not by the host (round 4: 0.459 eager vs 0.461 replayed, six alternating rounds).
     hip_graphs = None
-    if not args.no_graphs:
+    # (N > 1 over RCCL: skipped unless KGAT_BENCH_GRAPHS_MULTI=1 - a failed capture next to a live communicator is
+    # not something the headline run should risk for an informational number; gloo runs exercise it)
+    multi_ok = world == 1 or dist.get_backend() != "nccl" or os.environ.get("KGAT_BENCH_GRAPHS_MULTI", "") not in ("", "0")
+    if not args.no_graphs and multi_ok:
         try:
             gs = K.GraphedForward(model, g)
             same = bool(torch.equal(gs(), out))

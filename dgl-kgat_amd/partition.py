@@ -332,7 +332,8 @@ class GraphedForward:
         with torch.no_grad():
             for fn, exchange in self._stretches:
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, pool=self._pool):
+                # (thread_local: a process group's watchdog thread may touch the device while this thread captures)
+                with torch.cuda.graph(gr, pool=self._pool, capture_error_mode="thread_local"):
                     fn(self._state)
                 self._graphs.append(gr)
                 if exchange is not None:
