@@ -605,10 +605,20 @@ def main():
             alt["ms_per_step"] = round(dt_alt / args.steps * 1e3, 4)
             alt["value"] = round(args.layers * E / (dt_alt / args.steps), 1)
             alt["same_bits_as_allreduce"] = bool(torch.equal(out_alt, out))
+            # ... and once more with the exchange overlapped with compute (Partition.propagate_overlapped: four row
+            # blocks per layer, block k travelling on a side stream while block k + 1 is computed)
+            g.partition.n_chunks = int(os.environ.get("KGAT_BENCH_OVERLAP_CHUNKS", "4"))
+            step()
+            sync()
+            dt_ov, (out_ov, _) = timed_steps()
+            alt["overlapped"] = {"chunks": g.partition.n_chunks, "ms_per_step": round(dt_ov / args.steps * 1e3, 4),
+                                 "value": round(args.layers * E / (dt_ov / args.steps), 1),
+                                 "max_abs_diff_vs_unchunked": float((out_ov - out_alt).abs().max())}
         except Exception as exc:  # noqa: BLE001 - reported, not fatal: the measurement above stands
             alt["error"] = repr(exc)[:300]
         finally:
             g.partition.mode = "allreduce"
+            g.partition.n_chunks = int(os.environ.get("KGAT_EXCHANGE_CHUNKS", "1"))
             done.set()
             guard.cancel()
 
@@ -870,6 +880,7 @@ def main():
         pass
     if world > 1:
         result["value_allgather"] = alt["value"]
+        result["value_allgather_overlapped"] = (alt.get("overlapped") or {}).get("value")
         # who took part: world size / backend as torch.distributed sees them, every rank's device,
         # rows and edges (all_gather_object over the job's own process group)
         props = torch.cuda.get_device_properties(dev)
