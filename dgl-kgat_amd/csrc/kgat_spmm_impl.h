@@ -306,7 +306,7 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRecBytes + kPartBytes];
   EdgeRec* const s_rec = reinterpret_cast<EdgeRec*>(s_raw);
   float4 (*const s_part)[2][LPR] = reinterpret_cast<float4 (*)[2][LPR]>(s_raw + kRecBytes);
-  __shared__ int32_t s_row[NSUB][2];
+  __shared__ __attribute__((aligned(16))) int32_t s_row[NSUB][2];
   constexpr int CAP = FusedGeom<LPR>::CAP, PS4 = FusedGeom<LPR>::PS4;
   constexpr int KS = DI / 4, KT = FUSED ? DO / 16 : 1, WAVES = SpmmGeom<LPR>::THREADS / kWave;
   constexpr int GROUPS = WAVES / KT >= 1 ? WAVES / KT : 1;  // independent 16-row block streams of the dense part
@@ -408,6 +408,12 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   // 77.5 us for the plain operator, profiles/r04_spmm_epilogue_probe.txt).  A/B arm KGAT_SPMM_SELF_PREFETCH=1:
   // request it when the row OPENS instead.  The layer now forms h * h_N in the bi-interaction kernel
   // (kgat_bi_interaction_mul_f32) and calls the plain operator.
+#ifndef KGAT_SPMM_TIMING_SKIP_FINISH
+#define KGAT_SPMM_TIMING_SKIP_FINISH 0
+#endif
+#ifndef KGAT_SPMM_COMBINE_ENTRYWISE
+#define KGAT_SPMM_COMBINE_ENTRYWISE 0
+#endif
 #ifndef KGAT_SPMM_SELF_PREFETCH
 #define KGAT_SPMM_SELF_PREFETCH 0  // measured SLOWER (100.7 vs 91.4 us at D = 64): the conditional load makes every later wait of the loop conservative
 #endif
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       else if (FUSED) put_row(rr, v);
       else store_row<LPR, MUL_SELF, COPY_SELF>(out, X, rr, row0, sl, v, sc);
     };
+#if KGAT_SPMM_COMBINE_ENTRYWISE  // A/B arm: the first form of the walk, one dependent LDS read per entry
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int k = 2 * sub + t;
@@ -562,6 +569,67 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
         }
         if (!is_long) emit(rr, v);
       }
+#else
+    // Round 4: the rows of the entries around this lane group's two (2 sub - 2 .. 2 sub + 5) and the partials of
+    // entries 2 sub .. 2 sub + 4 are requested TOGETHER, up front - one LDS round trip - and the common segments
+    // (up to four entries) are summed from registers.  (The first form read s_row / s_part entry by entry, each read
+    // depending on the comparison before it: 5-8 LDS round trips per entry, 4.6-5.8 k of a tile's 28-45 k ticks;
+    // profiles/r04_gather_vs_spmm_widths.txt.)  Same entries, same order of additions: same bits.
+    constexpr int WIN = 8;
+    int32_t rw[WIN];   // rw[j] = row of entry 2 sub - 2 + j; -1: unused slot; -2: no such entry
+    {
+      const int32_t* srow = &s_row[0][0];
+#pragma unroll
+      for (int j = 0; j < WIN; j += 2) {
+        const int e = 2 * sub - 2 + j;
+        const bool in = e >= 0 && e < NE;
+        const int2 v2 = *reinterpret_cast<const int2*>(srow + (in ? e : 0));
+        rw[j] = in ? v2.x : -2;
+        rw[j + 1] = in ? v2.y : -2;
+      }
+    }
+    float4 pw[5];      // pw[j] = partial of entry 2 sub + j
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int e = 2 * sub + j;
+      pw[j] = s_part[(e < NE ? e : 0) >> 1][e & 1][sl];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = 2 * sub + t;
+      const int wi = t + 2;
+      const int32_t rr = rw[wi];
+      // previous valid entry: entry k-1, or k-2 when k-1 is an unused tail slot
+      const int32_t prev = rw[wi - 1] == -1 ? rw[wi - 2] : rw[wi - 1];
+      const bool starts = rr >= 0 && prev != rr;
+      bool is_long = false;
+      {
+        float4 v = pw[t];
+        int taken = 1;
+        bool open = starts;   // the segment may still continue
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) {
+          const int32_t r2 = rw[wi + j];
+          if (open && r2 == rr) {
+            v = add4(v, pw[t + j]);
+            ++taken;
+          } else if (r2 != -1) {
+            open = false;     // another row, or the end of the table
+          }
+        }
+        if (open) {           // longer than the window: walk on, entry by entry
+          for (int k2 = k + 4; k2 < NE; ++k2) {
+            const int32_t r2 = s_row[k2 >> 1][k2 & 1];
+            if (r2 < 0) continue;
+            if (r2 != rr) break;
+            if (taken == kShortSeg) { is_long = true; break; }
+            v = add4(v, s_part[k2 >> 1][k2 & 1][sl]);
+            ++taken;
+          }
+        }
+        if (starts && !is_long) emit(rr, v);
+      }
+#endif
       if (LPR < kWave) {  // (one lane group per wavefront: the walk above is all there is)
         unsigned long long todo = __ballot(is_long && sl == 0);
         while (todo) {
@@ -1022,6 +1090,9 @@ static int launch_merge_c(const SpmmArgs& a) {
   int64_t nz_blocks = (a.n_rows + kThreads - 1) / kThreads;  // one lane per row
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
+#if KGAT_SPMM_TIMING_SKIP_FINISH  // timing probe only (scripts/micro/step_ab.py): rows cut by tiles stay unwritten
+  if (DO == 0) return KGAT_OK;
+#endif
   hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF, COPY_SELF, DO>),
                      dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,

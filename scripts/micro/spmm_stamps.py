@@ -29,6 +29,7 @@ lib.kgat_debug_set_spmm_bi_stamps.restype = C.c_int
 lib.kgat_debug_set_spmm_bi_stamps.argtypes = [C.c_void_p]
 
 dev = torch.device("cuda:0")
+MUL_SELF = os.environ.get("STAMPS_MUL_SELF", "0") == "1"   # (round 4: the step calls the plain operator)
 same_rows = "--same-rows" in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 D = int(args[0]) if args else 64
@@ -46,9 +47,9 @@ tiles = (E + te - 1) // te
 stamps = torch.zeros(tiles * 32, dtype=torch.int64, device=dev)
 out = torch.empty(n, D, device=dev)
 for _ in range(3):
-    ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+    ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=MUL_SELF)
 assert lib.kgat_debug_set_spmm_stamps(stamps.data_ptr()) == 0
-ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=MUL_SELF)
 torch.cuda.synchronize()
 st = stamps.cpu().numpy()[:tiles * 16].reshape(tiles, 16).astype(np.float64)
 names = ["stage (loads -> LDS records, barrier)", "edge loop", "partials -> LDS, barrier", "combine walk, barrier", "emit"]
@@ -57,7 +58,7 @@ for i, nm in enumerate(names):
     d = st[:, i + 1] - st[:, i]
     print("  %-40s median %8.0f   p10 %8.0f   p90 %8.0f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 import time
-fn = lambda: ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=True)
+fn = lambda: ops.spmm(indptr, col, row_of, X, w, out=out, mul_self=MUL_SELF)
 assert lib.kgat_debug_set_spmm_stamps(None) == 0
 for _ in range(5): fn()
 ts = []
