@@ -81,6 +81,9 @@ SIGNATURES = {
                                          _p, _p, _p, _sz, _p]),
     "kgat_bi_interaction_f32": (_i32, [_i64, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64, _p]),
     "kgat_bi_interaction_mul_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, _p, _p, _i64, _p, _i64, _p]),
+    "kgat_bi_interaction_mul_deferred_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, _p, _p, _i64, _p, _i64,
+                                                    _p, _i64, _i64, _p, _i32, _p]),
+    "kgat_spmm_tile_edges": (_i32, [_i64, _i32]),
     "kgat_l2_normalize_rows_f32": (_i32, [_i64, _i32, _p, _p, _i64, _p]),
     "kgat_readout_concat_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "kgat_sddmm_dot_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
@@ -105,7 +108,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def source_hash():

@@ -31,6 +31,10 @@ __device__ __forceinline__ float row16_sum_d(float v) {
   return v;
 }
 
+#ifndef KGAT_BI_MUL_AT_LOAD
+#define KGAT_BI_MUL_AT_LOAD 0   // A/B builds: the first form of MODE >= 1 (h * h_N multiplied in the load step)
+#endif
+#define KGAT_BI_MUL_AT_LOAD_V (KGAT_BI_MUL_AT_LOAD != 0)
 #ifndef KGAT_BI_NT_LOADS
 #define KGAT_BI_NT_LOADS 0   // A/B builds: the row streams as non-temporal loads (measured 25-70 % SLOWER: profiles/r04_bi_probe.txt)
 #endif
@@ -75,12 +79,27 @@ struct EgoCopy {
   float* out;      // nullptr: off
   int64_t stride;  // row stride in floats
 };
-template <int DI, int DO, int MODE, bool VEC_NORM>
+// DEFER (MODE 1, kgat_bi_interaction_mul_deferred_f32): HN comes from an aggregation launched with
+// KGAT_SPMM_DEFER_FINISH - its second launch (kgat_spmm_impl.h: spmm_finish_kernel) did not run, so the rows that
+// are the first or the last row of one of its edge tiles, and the rows without in-edges, are not in HN: this
+// kernel forms them on the way, from the row offsets and the tiles' boundary partials in the aggregation's
+// workspace, in the finish launch's order of additions (same bits).  A dependent launch costs its ~2 us boundary
+// plus a pass over 2 x tiles items: 4.4 us per layer on the benchmark graph (scripts/micro/step_ab.py).
+struct DeferredRows {
+  const int32_t* indptr;  // row offsets of THIS call's row 0 .. n_rows (CSR positions)
+  const float4* bpart;    // per tile two partial rows (first row's, last row's), LPR = d_in / 4 float4 each
+  int32_t e0, e1;         // CSR positions of the row range
+  int32_t te_shift;       // log2(edges per tile)
+};
+constexpr int kDeferLongChain = 8;  // = spmm_finish_kernel's kLongChain
+template <int DI, int DO, int MODE, bool VEC_NORM, bool DEFER = false>
 __global__ __launch_bounds__(256) void bi_interaction_kernel(
     int32_t n_rows, const float* __restrict__ P, const float* __restrict__ HN, const float* __restrict__ W2,
     float slope, uint32_t drop_threshold, float keep_scale, uint32_t seed, uint32_t index0,
-    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride, const EgoCopy ego) {
+    float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride, const EgoCopy ego,
+    const DeferredRows df) {
   constexpr bool TRAIN = MODE == 2;
+  static_assert(!DEFER || (MODE == 1 && !KGAT_BI_MUL_AT_LOAD_V), "the deferred rows go with the late product");
   constexpr int KS = DI / 4, KT = DO / 16;
   // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
   // laid out in B-fragment order so that every wave then pulls its fragments with
@@ -103,7 +122,9 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   const int lane = threadIdx.x % kWave;
   const int i = lane & 15, q = lane >> 4;
   const int64_t n_waves = (int64_t)gridDim.x * (256 / kWave);
-  const int64_t wv = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  // (the wavefront's index through readfirstlane: its tile range is then held in SGPRs and the tile loop's branches
+  // are scalar - as a per-lane value the loop was compiled as divergent control flow, exec-masked block by block)
+  const int64_t wv = (int64_t)blockIdx.x * (256 / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
   const int32_t n_tiles = (n_rows + 15) >> 4;
   const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
@@ -124,7 +145,28 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       for (int c = 0; c < KT; ++c) wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c] = s_w[(s * KT + c) * kWave + lane];
   }
 
-  auto load_a = [&](int32_t t, float (&a)[KS]) {
+  // MODE >= 1: the rows of H and of HN are REQUESTED here and multiplied when the tile is computed (round 4, second
+  // form).  The first form multiplied here, which put the waits for both row sets - one after the other, the ego
+  // copy in between - into the load step: two exposed memory round trips per tile with nothing else of the
+  // wavefront in flight, and no overlap with the previous tile's matrix work whatever KGAT_BI_PREFETCH said
+  // (A/B builds: KGAT_BI_MUL_AT_LOAD=1).
+  constexpr bool LATE_MUL = MODE >= 1 && !KGAT_BI_MUL_AT_LOAD;
+#ifndef KGAT_BI_PREFETCH
+#define KGAT_BI_PREFETCH 2
+#endif
+  constexpr int PF = KS * KGAT_BI_PREFETCH <= 64 ? KGAT_BI_PREFETCH : (64 / KS >= 2 ? 64 / KS : 2);  // <= 64 VGPRs of rows in flight (x 2 with HN)
+  // DEFER: per stage, the offsets of the row this lane loads NEXT (requested one load step ahead), and what the load
+  // step found out for the tile step: nf = followers of the row's chain of tile partials (-1: a row without in-edges,
+  // 0: an ordinary row or a one-partial chain), bh = the chain's head tile
+  constexpr int LPR = DI / 4;
+  struct Defer { int32_t rb, re, nf, bh, slot; };
+  auto row_offsets = [&](int32_t t, Defer& d) {
+    int32_t ra = (t << 4) + i;
+    ra = ra < n_rows ? ra : n_rows - 1;
+    d.rb = df.indptr[ra];
+    d.re = df.indptr[ra + 1];
+  };
+  auto load_a = [&](int32_t t, float (&a)[KS], float (&b)[LATE_MUL ? KS : 1], Defer& d) {
     int32_t ra = (t << 4) + i;
     ra = ra < n_rows ? ra : n_rows - 1;
     const float4* pa = reinterpret_cast<const float4*>(P + (size_t)ra * DI) + q;
@@ -133,7 +175,29 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       const float4 v = ld_row4(pa + m * 4);
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
-    if (MODE >= 1) {
+    if constexpr (LATE_MUL) {
+      const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
+      if constexpr (DEFER) {
+        // a row the aggregation's tiles left as partials: the head partial has an HN row's layout - it is requested
+        // in the row's place, the followers when the tile is computed
+        const int32_t rb = d.rb - df.e0, re = d.re - df.e0;
+        const int32_t te_mask = (1 << df.te_shift) - 1;
+        const int32_t bh = rb >> df.te_shift, bl = (re - 1) >> df.te_shift;
+        const bool empty = rb == re;
+        const bool lo_al = (rb & te_mask) == 0;
+        const bool partial = !empty && (bh != bl || lo_al || (re & te_mask) == 0 || d.re == df.e1);
+        if (partial) pb = df.bpart + ((size_t)bh * 2 + (lo_al ? 0 : 1)) * LPR + q;
+        d.nf = empty ? -1 : (partial ? bl - bh : 0);
+        d.bh = bh;
+        d.slot = lo_al ? 0 : 1;
+      }
+#pragma unroll
+      for (int m = 0; m < DI / 16; ++m) {
+        const float4 v = ld_row4(pb + m * 4);
+        b[4 * m + 0] = v.x; b[4 * m + 1] = v.y; b[4 * m + 2] = v.z; b[4 * m + 3] = v.w;
+      }
+      if constexpr (DEFER) row_offsets(t + PF, d);  // (clamped to the last row past the end)
+    } else if (MODE >= 1) {
       if (MODE == 1 && ego.out != nullptr && (t << 4) + i < n_rows) {
         float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)ra * ego.stride) + q;
 #pragma unroll
@@ -147,8 +211,80 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       }
     }
   };
-  auto tile = [&](int32_t t, const float (&a)[KS]) {
+  auto tile = [&](int32_t t, float (&a)[KS], float (&b)[LATE_MUL ? KS : 1], const int32_t nf, const int32_t bh, const int32_t slot) {
     const int32_t row0 = t << 4;
+    if constexpr (DEFER) {
+      if (__builtin_amdgcn_ballot_w64(nf != 0) != 0ull) {  // (uniform: about a third of the 16-row tiles)
+        const bool is_long = nf >= kDeferLongChain;
+        if (nf < 0) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) b[s] = 0.f;
+        } else if (nf > 0 && !is_long) {
+          // acc = head partial; acc += the followers' first-row partials, in tile order (spmm_finish_kernel)
+          const float4* pf = df.bpart + ((size_t)(bh + 1) * 2) * LPR + q;
+          for (int32_t k = 0; k < nf; ++k, pf += 2 * LPR) {
+#pragma unroll
+            for (int m = 0; m < DI / 16; ++m) {
+              const float4 v = pf[m * 4];
+              b[4 * m + 0] += v.x; b[4 * m + 1] += v.y; b[4 * m + 2] += v.z; b[4 * m + 3] += v.w;
+            }
+          }
+        }
+        // hub rows (a chain of more than kDeferLongChain tiles): the whole wavefront sums one row, as the finish
+        // launch does - lane group g = lane / LPR takes the tiles head + g, head + g + SPW, ..., a fixed shuffle
+        // tree adds the groups' sums - and hands the row to its four lanes
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(is_long && q == 0);
+        if (todo) {
+          constexpr int SPW = kWave / LPR;
+          const int g = lane / LPR, sl = lane % LPR;
+          while (todo) {
+            const int src = __ffsll((long long)todo) - 1;  // (q == 0: the lane index is the row's i)
+            todo &= todo - 1;
+            const int32_t bo = __shfl(bh, src, kWave);
+            const int32_t bl = bo + __shfl(nf, src, kWave);
+            const int so = __shfl(slot, src, kWave);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int32_t bb = bo + g;
+            constexpr int U = 8;
+            for (; bb + (U - 1) * SPW <= bl; bb += U * SPW) {
+              float4 v[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int32_t tt = bb + u * SPW;
+                v[u] = df.bpart[((size_t)tt * 2 + ((tt == bo) ? so : 0)) * LPR + sl];
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; bb <= bl; bb += SPW) {
+              const float4 v = df.bpart[((size_t)bb * 2 + ((bb == bo) ? so : 0)) * LPR + sl];
+              acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+#pragma unroll
+            for (int off = LPR; off < kWave; off <<= 1) {
+              acc.x += __shfl_xor(acc.x, off, kWave); acc.y += __shfl_xor(acc.y, off, kWave);
+              acc.z += __shfl_xor(acc.z, off, kWave); acc.w += __shfl_xor(acc.w, off, kWave);
+            }
+            // every lane group now holds the row (lane sl: columns 4 sl .. 4 sl + 3); lane (i, q) takes 4 (4m + q)..
+#pragma unroll
+            for (int m = 0; m < DI / 16; ++m) {
+              const float x = __shfl(acc.x, 4 * m + q, kWave), y = __shfl(acc.y, 4 * m + q, kWave);
+              const float z = __shfl(acc.z, 4 * m + q, kWave), w = __shfl(acc.w, 4 * m + q, kWave);
+              if (i == src) { b[4 * m + 0] = x; b[4 * m + 1] = y; b[4 * m + 2] = z; b[4 * m + 3] = w; }
+            }
+          }
+        }
+      }
+    }
+    if constexpr (LATE_MUL) {
+      if (MODE == 1 && ego.out != nullptr && row0 + i < n_rows) {
+        float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)(row0 + i) * ego.stride) + q;
+#pragma unroll
+        for (int m = 0; m < DI / 16; ++m) st_final4(pe + m * 4, make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]));
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[s] *= b[s];
+    }
     floatx4_d acc[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){0.f, 0.f, 0.f, 0.f};
@@ -206,25 +342,53 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     }
   };
 
-  // The rows of the next PF - 1 tiles are requested before a tile is computed.  Round 4 tried a deeper ring (PF = 4,
-  // the grid of two workgroups per CU leaves the registers free), W2's fragments from LDS instead of registers
-  // with 4 and 8 workgroups per CU, and a 1,024-block grid: 30.7-35.7 us against 31.0 at 64 -> 64, 18.1-20.1
-  // against 19.0 at 64 -> 32, 13.7-14.0 against 13.9 at 32 -> 16 (profiles/r04_bi_probe.txt) - the launch is not
-  // bound by the latency of its row fetches, nor by resident wavefronts; dropping either output saves 4-5 us.
-#ifndef KGAT_BI_PREFETCH
-#define KGAT_BI_PREFETCH 2
+  // Ring of PF stages: the rows of tile t + PF are requested once tile t is computed.  (A/B form KGAT_BI_PIPELINE=1:
+  // an explicit two-buffer loop, load t + 1 / compute t, whose load steps stand unconditionally - under an
+  // `if (t + p < t_end)` the compiler sees two possible numbers of requests in flight at the next wait and waits
+  // for all of them.  Stand-alone it is faster at 64 -> 64 (37.2 vs 38.9 us) and slower at 32 -> 16 (14.8 vs
+  // 14.0); inside the step the ring wins, 0.4374 vs 0.4395 ms: profiles/r04_bi_late_mul_ab.txt.  Round 4 had
+  // also tried PF = 4, W2's fragments from LDS with 4 and 8 workgroups per CU and a 1,024-block grid:
+  // profiles/r04_bi_probe.txt - the launch runs at the rate of a device copy of its bytes.)
+#ifndef KGAT_BI_PIPELINE
+#define KGAT_BI_PIPELINE 0
 #endif
-  constexpr int PF = KS * KGAT_BI_PREFETCH <= 64 ? KGAT_BI_PREFETCH : (64 / KS >= 2 ? 64 / KS : 2);  // <= 64 VGPRs of rows in flight
-  float a[PF][KS];
+  if constexpr (KGAT_BI_PIPELINE != 0 && !DEFER) {
+    float a0[KS], a1[KS], b0[LATE_MUL ? KS : 1], b1[LATE_MUL ? KS : 1];
+    Defer d0{0, 0, 0, 0, 0};
+    load_a(t_begin, a0, b0, d0);
+    for (int32_t t = t_begin;; t += 2) {
+      if (t + 1 >= t_end) {
+        tile(t, a0, b0, 0, 0, 0);
+        break;
+      }
+      load_a(t + 1, a1, b1, d0);
+      tile(t, a0, b0, 0, 0, 0);
+      if (t + 2 >= t_end) {
+        tile(t + 1, a1, b1, 0, 0, 0);
+        break;
+      }
+      load_a(t + 2, a0, b0, d0);
+      tile(t + 1, a1, b1, 0, 0, 0);
+    }
+    return;
+  }
+  float a[PF][KS], b[PF][LATE_MUL ? KS : 1];
+  Defer d[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    d[p] = Defer{0, 0, 0, 0, 0};
+    if (DEFER) row_offsets(t_begin + p, d[p]);
+  }
 #pragma unroll
   for (int p = 0; p < PF; ++p)
-    if (t_begin + p < t_end) load_a(t_begin + p, a[p]);
+    if (t_begin + p < t_end) load_a(t_begin + p, a[p], b[p], d[p]);
   for (int32_t t = t_begin; t < t_end; t += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       if (t + p < t_end) {
-        tile(t + p, a[p]);
-        if (t + p + PF < t_end) load_a(t + p + PF, a[p]);
+        // (nf / bh by value: the load step below overwrites the stage's record)
+        tile(t + p, a[p], b[p], d[p].nf, d[p].bh, d[p].slot);
+        if (t + p + PF < t_end) load_a(t + p + PF, a[p], b[p], d[p]);
       }
     }
   }
@@ -370,7 +534,7 @@ static DropArgs drop_args(float p, uint64_t seed, int64_t row0, int d_out) {
 template <int DI, int DO>
 static int launch_bi(int64_t n_rows, const float* P, const float* HN, const float* W2, float slope,
                      const DropArgs& dr, float* h_out, float* norm_out, int64_t norm_stride, hipStream_t st,
-                     int mode, const EgoCopy ego) {
+                     int mode, const EgoCopy ego, const DeferredRows* defer = nullptr) {
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
 #ifndef KGAT_BI_MAX_BLOCKS
@@ -380,11 +544,26 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
   // 16-byte stores into the normalised copy need its slice 16-byte aligned with a row stride that keeps it so
   const bool vec = norm_out == nullptr ||
                    ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);
+  const DeferredRows no_defer{nullptr, nullptr, 0, 0, 0};
 #define KGAT_BI_LAUNCH(MD, VEC)                                                                                     \
   hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, MD, VEC>), dim3((unsigned)blocks), dim3(256), 0, st,            \
                      (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,     \
-                     norm_out, norm_stride, ego)
-  if (mode == 2) {
+                     norm_out, norm_stride, ego, no_defer)
+  if (mode == 1 && defer != nullptr) {
+#if KGAT_BI_MUL_AT_LOAD_V
+    set_error("bi_interaction_mul_deferred: not in a KGAT_BI_MUL_AT_LOAD build");
+    return KGAT_E_UNSUPPORTED;
+#else
+    if (vec)
+      hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                         (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,
+                         norm_out, norm_stride, ego, *defer);
+    else
+      hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, 1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                         (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,
+                         norm_out, norm_stride, ego, *defer);
+#endif
+  } else if (mode == 2) {
     if (vec) KGAT_BI_LAUNCH(2, true); else KGAT_BI_LAUNCH(2, false);
   } else if (mode == 1) {
     if (vec) KGAT_BI_LAUNCH(1, true); else KGAT_BI_LAUNCH(1, false);
@@ -517,15 +696,20 @@ int kgat_bi_interaction_supported(int d_in, int d_out) {
 
 static int bi_dispatch(int64_t n_rows, int d_in, int d_out, const float* P, const float* HN, const float* W2,
                        float negative_slope, const DropArgs& dr, float* h_out, float* norm_out,
-                       int64_t norm_stride, hipStream_t st, int mode, const EgoCopy ego = EgoCopy{nullptr, 0}) {
+                       int64_t norm_stride, hipStream_t st, int mode, const EgoCopy ego = EgoCopy{nullptr, 0},
+                       const DeferredRows* defer = nullptr) {
 #define KGAT_BI_CASE(DI, DO) \
   if (d_in == DI && d_out == DO) \
-    return launch_bi<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st, mode, ego);
+    return launch_bi<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st, mode, ego, defer);
   KGAT_BI_CASE(16, 16) KGAT_BI_CASE(16, 32) KGAT_BI_CASE(16, 64) KGAT_BI_CASE(16, 128)
   KGAT_BI_CASE(32, 16) KGAT_BI_CASE(32, 32) KGAT_BI_CASE(32, 64) KGAT_BI_CASE(32, 128)
   KGAT_BI_CASE(64, 16) KGAT_BI_CASE(64, 32) KGAT_BI_CASE(64, 64) KGAT_BI_CASE(64, 128)
   KGAT_BI_CASE(128, 16) KGAT_BI_CASE(128, 32) KGAT_BI_CASE(128, 64) KGAT_BI_CASE(128, 128)
 #undef KGAT_BI_CASE
+  if (defer != nullptr) {
+    set_error("bi_interaction_mul_deferred: widths %d -> %d are outside the MFMA kernel's {16, 32, 64, 128}", d_in, d_out);
+    return KGAT_E_UNSUPPORTED;
+  }
 #define KGAT_BI_SMALL(DI, DO) \
   if (d_in == DI && d_out == DO) \
     return launch_bi_small<DI, DO>(n_rows, P, HN, W2, negative_slope, dr, h_out, norm_out, norm_stride, st, mode, ego);
@@ -568,6 +752,29 @@ int kgat_bi_interaction_mul_f32(int64_t n_rows, int d_in, int d_out, const float
   }
   return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, DropArgs(), h_out, norm_out, norm_stride,
                      as_stream(stream), 1, EgoCopy{self_out, self_stride});
+}
+
+int kgat_bi_interaction_mul_deferred_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
+                                         const float* W2, float negative_slope, float* h_out, float* norm_out,
+                                         int64_t norm_stride, float* self_out, int64_t self_stride,
+                                         const int32_t* indptr_rows, int64_t e_begin, int64_t e_end,
+                                         const void* spmm_workspace, int tile_edges, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX, "bi_interaction_mul_deferred: bad row count");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(H && HN && W2 && (h_out || norm_out) && indptr_rows, "bi_interaction_mul_deferred: null pointer");
+  KGAT_CHECK_ARG(e_begin >= 0 && e_end >= e_begin && e_end < INT32_MAX, "bi_interaction_mul_deferred: bad edge range");
+  KGAT_CHECK_ARG(e_end == e_begin || spmm_workspace != nullptr, "bi_interaction_mul_deferred: null workspace");
+  KGAT_CHECK_ARG(tile_edges > 0 && (tile_edges & (tile_edges - 1)) == 0,
+                 "bi_interaction_mul_deferred: tile_edges must be kgat_spmm_tile_edges() of the aggregation (a power of two)");
+  KGAT_CHECK_ARG(norm_out == nullptr || norm_stride >= d_out, "bi_interaction_mul_deferred: bad norm_stride");
+  KGAT_CHECK_ARG(self_out == nullptr || (self_stride >= d_in && self_stride % 4 == 0 &&
+                                         (reinterpret_cast<uintptr_t>(self_out) & 15u) == 0),
+                 "bi_interaction_mul_deferred: self_out must be 16-byte aligned with a row stride that is a multiple of 4 floats >= d_in");
+  int shift = 0;
+  while ((1 << shift) < tile_edges) ++shift;
+  const DeferredRows df{indptr_rows, static_cast<const float4*>(spmm_workspace), (int32_t)e_begin, (int32_t)e_end, shift};
+  return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, DropArgs(), h_out, norm_out, norm_stride,
+                     as_stream(stream), 1, EgoCopy{self_out, self_stride}, &df);
 }
 
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,

@@ -113,6 +113,19 @@ size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   return align_up((size_t)tiles * 2 * lpr * sizeof(float4), 256) + 256;
 }
 
+int kgat_spmm_tile_edges(int64_t n_edges, int D) {
+  if (n_edges < 0) return 0;
+  int te = 0;
+  switch (D) {
+    case 16: te = merge_tile_edges<4>(n_edges); break;
+    case 32: te = merge_tile_edges<8>(n_edges); break;
+    case 64: te = merge_tile_edges<16>(n_edges); break;
+    case 128: te = merge_tile_edges<32>(n_edges); break;
+    default: return 0;
+  }
+  return (te & (te - 1)) == 0 ? te : 0;  // (the consumer shifts; every shipped geometry is a power of two)
+}
+
 int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64_t e_end, int D,
                             const int32_t* indptr, const int32_t* col, const int32_t* row_of,
                             const int32_t* eid, const float* X, const float* w, float* out,
@@ -126,7 +139,7 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
   if (n_rows == 0) return KGAT_OK;
   KGAT_CHECK_ARG(indptr && X && out, "spmm: null pointer");
   KGAT_CHECK_ARG(e_end == e_begin || (col && w), "spmm: null col/w");
-  KGAT_CHECK_ARG((flags & ~(unsigned)KGAT_SPMM_MUL_SELF) == 0, "spmm: unknown flags 0x%x", flags);
+  KGAT_CHECK_ARG((flags & ~(unsigned)(KGAT_SPMM_MUL_SELF | KGAT_SPMM_DEFER_FINISH)) == 0, "spmm: unknown flags 0x%x", flags);
   KGAT_CHECK_ARG(algo >= KGAT_SPMM_ALGO_AUTO && algo <= KGAT_SPMM_ALGO_MERGE1,
                  "spmm: unknown algo %d", algo);
   if (algo == KGAT_SPMM_ALGO_AUTO)
@@ -137,6 +150,12 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
                  "spmm: merge algorithm needs row_of");
   KGAT_CHECK_ARG(order == nullptr || algo == KGAT_SPMM_ALGO_ROWS,
                  "spmm: a row order only applies to the rows algorithm");
+  if (flags & KGAT_SPMM_DEFER_FINISH) {
+    KGAT_CHECK_ARG(!(flags & KGAT_SPMM_MUL_SELF) && eid == nullptr && algo == KGAT_SPMM_ALGO_MERGE &&
+                       kgat_spmm_tile_edges(e_end - e_begin, D) > 0,
+                   "spmm: KGAT_SPMM_DEFER_FINISH goes with the plain operator, CSR-ordered weights, the merge algorithm "
+                   "and D in {16, 32, 64, 128}");
+  }
   if (self_out != nullptr) {
     KGAT_CHECK_ARG((flags & KGAT_SPMM_MUL_SELF) && eid == nullptr && algo == KGAT_SPMM_ALGO_MERGE,
                    "spmm: self_out goes with KGAT_SPMM_MUL_SELF, CSR-ordered weights and the merge algorithm");

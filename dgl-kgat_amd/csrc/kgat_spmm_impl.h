@@ -1093,6 +1093,9 @@ static int launch_merge_c(const SpmmArgs& a) {
 #if KGAT_SPMM_TIMING_SKIP_FINISH  // timing probe only (scripts/micro/step_ab.py): rows cut by tiles stay unwritten
   if (DO == 0) return KGAT_OK;
 #endif
+  // KGAT_SPMM_DEFER_FINISH: the consumer (kgat_bi_interaction_mul_deferred_f32) forms the tiles' first / last rows
+  // from the partials in the workspace, and the rows without in-edges, itself
+  if (DO == 0 && (a.flags & KGAT_SPMM_DEFER_FINISH)) return KGAT_OK;
   hipLaunchKernelGGL((spmm_finish_kernel<LPR, C, MUL_SELF, COPY_SELF, DO>),
                      dim3((unsigned)(fix_blocks + nz_blocks)), dim3(kThreads), 0, a.st, e0, e1,
                      (int32_t)a.row0, (int32_t)a.n_rows, (int32_t)tiles, a.indptr, a.row_of,
@@ -1118,6 +1121,13 @@ static int launch_merge(const SpmmArgs& a) {
   if (use_mid_runs<LPR>((int64_t)a.e1_host - a.e0_host))
     return launch_merge_c<LPR, mid_run_len(LPR), MUL_SELF, HAS_EID, false, DO>(a);
   return launch_merge_c<LPR, (DO > 0 ? fused_run_len(LPR) : run_len(LPR)), MUL_SELF, HAS_EID, false, DO>(a);
+}
+
+// edges per tile launch_merge picks for a launch over n_edges positions (kgat_spmm_tile_edges)
+template <int LPR>
+static int merge_tile_edges(int64_t n_edges) {
+  const int c = use_short_runs<LPR>(n_edges) ? short_run_len(LPR) : (use_mid_runs<LPR>(n_edges) ? mid_run_len(LPR) : run_len(LPR));
+  return SpmmGeom<LPR>::NSUB * c;
 }
 
 template <int LPR, bool MUL_SELF, bool HAS_EID>

@@ -248,6 +248,7 @@ class KGATPropagation(nn.Module):
         fuse_bi = os.environ.get("KGAT_FUSE_BI", "0") not in ("", "0")
         # KGAT_GNN_MUL_IN_SPMM=1: rounds 1-3's split - h * h_N in the aggregation's epilogue (A/B)
         mul_in_spmm = os.environ.get("KGAT_GNN_MUL_IN_SPMM", "0") not in ("", "0")
+        defer = os.environ.get("KGAT_GNN_DEFER_FINISH", "1") not in ("", "0")
         st = g._st
         scratch = None
         for li, layer in enumerate(self.layers):
@@ -267,6 +268,19 @@ class KGATPropagation(nn.Module):
                 # the plain aggregation, and h * h_N formed by the dense kernel while it loads its rows (+ the ego
                 # block of the readout from the rows of layer 0's input): round 4 - the aggregation's h * h_N
                 # epilogue is a dependent X[v] load per finished row inside its edge loop, 91 vs 78 us per launch
+                # ... and the aggregation's second launch (the sums of the rows its edge tiles cut, the zero rows)
+                # left to that kernel too: the rows are formed there from the tiles' partials, in the same order of
+                # additions (KGAT_SPMM_DEFER_FINISH; same bits, one dependent launch less per layer: step 0.4415 ->
+                # 0.43 ms).  KGAT_GNN_DEFER_FINISH=0 restores the two launches.
+                if defer and ops.bi_interaction_deferral_supported(widths[li], widths[li + 1]) and h.shape[0] > 0:
+                    csr = st.csr(h.device)
+                    hc = h.contiguous()
+                    hn, rows_left = ops.spmm(csr.indptr, csr.col, csr.row_of, hc, st.csr_weights(w), defer_finish=True)
+                    h = ops.bi_interaction_mul(hc, hn, layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out,
+                                               want_h=not last, deferred=rows_left,
+                                               self_out=out[:, :widths[0]] if (li == 0 and copy_self) else None)
+                    off += widths[li + 1]
+                    continue
                 hn = u_mul_e_sum(g, h, w)
                 h = ops.bi_interaction_mul(h.contiguous(), hn, layer.res_fc_2.weight.detach(), 0.01, norm_out=norm_out,
                                            want_h=not last,

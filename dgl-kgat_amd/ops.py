@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import KGATLibraryError, check
 
 SPMM_MUL_SELF = 1
+SPMM_DEFER_FINISH = 2
 SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3, "merge1": 4}
 ATT_ALGO = dict({"auto": 0, "mfma": 1, "generic": 2}, **{"mfma_v%d" % v: 16 + v for v in range(16)})
 
@@ -449,12 +450,29 @@ def spmm_workspace(n_edges, D, device):
     return _workspace(_lib.load().kgat_spmm_workspace_bytes(n_edges, D), device)
 
 
+class DeferredRows:
+    """What spmm(defer_finish=True) leaves to bi_interaction_mul(deferred=...): the row offsets of the call's rows, its
+    CSR position range, the workspace holding the tiles' boundary partials and the tile size."""
+    __slots__ = ("indptr_rows", "e_range", "workspace", "tile_edges", "n_rows", "D")
+
+    def __init__(self, indptr_rows, e_range, workspace, tile_edges, n_rows, D):
+        self.indptr_rows, self.e_range, self.workspace = indptr_rows, e_range, workspace
+        self.tile_edges, self.n_rows, self.D = tile_edges, n_rows, D
+
+
+def bi_interaction_deferral_supported(d_in, d_out):
+    """The widths kgat_spmm_umule_sum_f32(KGAT_SPMM_DEFER_FINISH) + kgat_bi_interaction_mul_deferred_f32 cover."""
+    return int(d_in) in (16, 32, 64, 128) and int(d_out) in (16, 32, 64, 128)
+
+
 def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=False, algo="auto",
-         rows=None, e_range=None, workspace=None, self_out=None):
+         rows=None, e_range=None, workspace=None, self_out=None, defer_finish=False):
     """out[v - row0] = sum_p w_p X[col[p]] over the CSR rows `rows` = (row0, n_rows) whose CSR
     positions are `e_range` (defaults: the whole graph).  w is in CSR order, or in edge-id
     order when `eid` is given.  `self_out` (with mul_self): an (n_rows, D) column slice of a wider
-    row-major buffer that also receives X[v] (the ego block of the readout)."""
+    row-major buffer that also receives X[v] (the ego block of the readout).
+    defer_finish=True (KGAT_SPMM_DEFER_FINISH): returns (out, DeferredRows) - the rows the edge tiles cut and the
+    rows without in-edges are NOT in `out`; bi_interaction_mul(deferred=...) forms them on the way."""
     X = _need(X, torch.float32, "X")
     if X.dim() != 2:
         raise ValueError("X must be (N, D)")
@@ -483,9 +501,12 @@ def spmm(indptr, col, row_of, X, w, eid=None, out=None, order=None, mul_self=Fal
         check(_lib.load().kgat_spmm_umule_sum_f32(n_rows, row0, e0, e1, D, _ptr(indptr), _ptr(col), _ptr(row_of),
                                                   _ptr(eid), _ptr(X), _ptr(w), _ptr(out), _ptr(order),
                                                   _ptr(workspace), workspace.numel(),
-                                                  SPMM_MUL_SELF if mul_self else 0, SPMM_ALGO[algo],
-                                                  _ptr(self_out), self_stride, _stream(X)),
+                                                  (SPMM_MUL_SELF if mul_self else 0) | (SPMM_DEFER_FINISH if defer_finish else 0),
+                                                  SPMM_ALGO[algo], _ptr(self_out), self_stride, _stream(X)),
               "kgat_spmm_umule_sum_f32")
+    if defer_finish:
+        te = int(_lib.load().kgat_spmm_tile_edges(e1 - e0, D))
+        return out, DeferredRows(indptr[row0:row0 + n_rows + 1], (e0, e1), workspace, te, n_rows, D)
     return out
 
 
@@ -565,10 +586,12 @@ def bi_interaction(P, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h
     return h_out
 
 
-def bi_interaction_mul(H, HN, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h=True, self_out=None):
+def bi_interaction_mul(H, HN, W2, negative_slope=0.01, h_out=None, norm_out=None, want_h=True, self_out=None,
+                       deferred=None):
     """Z = leaky_relu((H * HN) @ W2^T) (kgat_bi_interaction_mul_f32): the layer input H and the plain aggregation HN,
     the product formed while the rows are loaded; `self_out`: an (n, d_in) column slice that also receives H (the
-    ego block of the readout).  Otherwise as bi_interaction."""
+    ego block of the readout).  Otherwise as bi_interaction.  `deferred`: the DeferredRows of the
+    spmm(defer_finish=True) call that produced HN (kgat_bi_interaction_mul_deferred_f32; same bits)."""
     H = _need(H, torch.float32, "H")
     HN = _need(HN, torch.float32, "HN", H.shape)
     W2 = _need(W2, torch.float32, "W2")
@@ -583,10 +606,18 @@ def bi_interaction_mul(H, HN, W2, negative_slope=0.01, h_out=None, norm_out=None
     stride = _strided_rows(norm_out, n, d_out, "norm_out") if norm_out is not None else 0
     self_stride = _strided_rows(self_out, n, d_in, "self_out") if self_out is not None else 0
     with _timed("bi_interaction", (n, d_in, d_out)):
-        check(_lib.load().kgat_bi_interaction_mul_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2), float(negative_slope),
-                                                      _ptr(h_out), _ptr(norm_out), stride, _ptr(self_out), self_stride,
-                                                      _stream(H)),
-              "kgat_bi_interaction_mul_f32")
+        if deferred is not None:
+            if deferred.n_rows != n or deferred.D != d_in:
+                raise ValueError("deferred rows of a (%d, %d) aggregation with a (%d, %d) input" % (deferred.n_rows, deferred.D, n, d_in))
+            check(_lib.load().kgat_bi_interaction_mul_deferred_f32(
+                n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2), float(negative_slope), _ptr(h_out), _ptr(norm_out), stride,
+                _ptr(self_out), self_stride, _ptr(deferred.indptr_rows), deferred.e_range[0], deferred.e_range[1],
+                _ptr(deferred.workspace), deferred.tile_edges, _stream(H)), "kgat_bi_interaction_mul_deferred_f32")
+        else:
+            check(_lib.load().kgat_bi_interaction_mul_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2), float(negative_slope),
+                                                          _ptr(h_out), _ptr(norm_out), stride, _ptr(self_out), self_stride,
+                                                          _stream(H)),
+                  "kgat_bi_interaction_mul_f32")
     return h_out
 
 

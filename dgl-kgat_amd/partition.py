@@ -282,11 +282,19 @@ class Partition:
         csr = st.csr(h.device)
         w_csr = st.csr_weights(g.edata["w"])
         h_c = h.detach().contiguous()
+        # (the aggregation's second launch left to the dense kernel where the widths allow, as in the unsharded layer:
+        # kgat_layer._gnn_fused; KGAT_GNN_DEFER_FINISH=0 restores it)
+        defer = (os.environ.get("KGAT_GNN_DEFER_FINISH", "1") not in ("", "0") and self.hi > self.lo and
+                 ops.bi_interaction_deferral_supported(h_c.shape[1], weight.shape[0]))
         hn = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, w_csr, rows=(self.lo, self.hi - self.lo),
-                      e_range=(0, st.n_edges))
+                      e_range=(0, st.n_edges), defer_finish=defer)
+        rows_left = None
+        if defer:
+            hn, rows_left = hn
         full = self.new_buffer(weight.shape[0], h.device, slot=slot)
         if self.hi > self.lo:   # h * h_N is formed by the dense kernel while it loads its rows
-            ops.bi_interaction_mul(h_c[self.lo:self.hi], hn, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi])
+            ops.bi_interaction_mul(h_c[self.lo:self.hi], hn, weight.detach().contiguous(), 0.01, h_out=full[self.lo:self.hi],
+                                   deferred=rows_left)
         return full
 
     def propagate_fused(self, g, h, weight, slot=None):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 5
+#define KGAT_ABI_VERSION 6
 
 enum {
   KGAT_OK = 0,
@@ -40,7 +40,8 @@ enum {
 
 /* flags for kgat_spmm_umule_sum_f32 */
 enum {
-  KGAT_SPMM_MUL_SELF = 1 /* out[v,:] *= X[row0+v,:]  (the h * h_neighbor of models.py:66) */
+  KGAT_SPMM_MUL_SELF = 1, /* out[v,:] *= X[row0+v,:]  (the h * h_neighbor of models.py:66) */
+  KGAT_SPMM_DEFER_FINISH = 2 /* the second launch is left to kgat_bi_interaction_mul_deferred_f32 (see there) */
 };
 
 /* algorithm selectors (AUTO picks the tuned kernel; the others exist for A/B and tests) */
@@ -329,6 +330,23 @@ int kgat_bi_interaction_f32(int64_t n_rows, int d_in, int d_out, const float* P,
 int kgat_bi_interaction_mul_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN, const float* W2,
                                 float negative_slope, float* h_out, float* norm_out, int64_t norm_stride,
                                 float* self_out, int64_t self_stride, kgat_stream_t stream);
+
+/* The pair update_all(u_mul_e, sum) -> th.mul / res_fc_2 / LeakyReLU / normalize (reference models.py:63-66, :165) with
+ * one launch less (round 4).  The aggregation's MERGE algorithm cuts the CSR positions into tiles of
+ * kgat_spmm_tile_edges(e_end - e_begin, D) edges; a tile leaves its first and its last row as partial sums in the
+ * workspace and a second, dependent launch adds them up and zero-fills the rows without in-edges.  With
+ * KGAT_SPMM_DEFER_FINISH (plain operator, CSR-ordered weights, MERGE / AUTO, D in {16, 32, 64, 128}) that launch is
+ * skipped: those rows of `out` are NOT written, and kgat_bi_interaction_mul_deferred_f32 - the same operator as
+ * kgat_bi_interaction_mul_f32 - forms them on the way from `indptr_rows` (= indptr + row0: the row offsets of the
+ * call's rows 0 .. n_rows), the edge range and the untouched workspace, in the second launch's order of additions:
+ * bit-identical results.  d_in, d_out in {16, 32, 64, 128}; nothing else may use the workspace between the two calls.
+ * (Benchmark graph: 4.4 us per layer, 13 us of a 0.44 ms step.) */
+int kgat_spmm_tile_edges(int64_t n_edges, int D);  /* 0: D outside {16, 32, 64, 128} */
+int kgat_bi_interaction_mul_deferred_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
+                                         const float* W2, float negative_slope, float* h_out, float* norm_out,
+                                         int64_t norm_stride, float* self_out, int64_t self_stride,
+                                         const int32_t* indptr_rows, int64_t e_begin, int64_t e_end,
+                                         const void* spmm_workspace, int tile_edges, kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- one KGATConv forward in one pass (S1 + B1 + B2)
  * Replaces reference models.py:63-66 (update_all(u_mul_e, sum); th.mul; res_fc_2; LeakyReLU) and the

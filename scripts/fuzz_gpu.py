@@ -117,6 +117,14 @@ def one(seed):
             ego = torch.full((nr, D + 4), 2.0, device=dev)
             h_b = ops.bi_interaction_mul(Xd[sl], hn, W2, 0.01, norm_out=wide_b[:, 4:4 + d_out], self_out=ego[:, 4:4 + D])
             assert torch.equal(h_a, h_b) and torch.equal(wide_a, wide_b) and torch.equal(ego[:, 4:], Xd[sl]), "bi_interaction_mul"
+            # the aggregation without its second launch + the dense kernel forming the rows that launch would have
+            hn_d, left = ops.spmm(indptr, col, row_of, Xd, w_csr, out=torch.full((nr, D), float("nan"), device=dev),
+                                  defer_finish=True, **rows_kw)
+            wide_d = torch.full((nr, d_out + 8), 3.0, device=dev)
+            ego_d = torch.full((nr, D + 4), 2.0, device=dev)
+            h_d = ops.bi_interaction_mul(Xd[sl], hn_d, W2, 0.01, norm_out=wide_d[:, 4:4 + d_out], self_out=ego_d[:, 4:4 + D],
+                                         deferred=left)
+            assert torch.equal(h_a, h_d) and torch.equal(wide_a, wide_d) and torch.equal(ego, ego_d), "bi_interaction_mul deferred"
             wide_c = torch.full((nr, d_out + 8), 3.0, device=dev)
             h_c = ops.spmm_bi_fused(indptr, col, row_of, Xd, w_csr, W2, 0.01, norm_out=wide_c[:, 4:4 + d_out], **rows_kw)
             assert torch.equal(h_a, h_c) and torch.equal(wide_a, wide_c), "spmm_bi_fused"

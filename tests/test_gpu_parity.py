@@ -907,6 +907,112 @@ def test_bi_interaction_mul_same_bits_as_the_spmm_epilogue(K, dev, d_in, d_out):
         assert ops.bi_interaction_mul(X, hn, W2, 0.01, norm_out=wide_b[:, 8:8 + d_out], want_h=False) is None
 
 
+DEFER_GRAPHS = [  # (n, e, hub, isolated tail)
+    (1, 5, 0, 0), (17, 100, 0, 3), (300, 5000, 0, 40), (500, 20000, 9000, 100), (64, 7000, 7000, 0),
+    (5000, 60000, 30000, 500), (40000, 2500000, 150000, 1000),
+]
+
+
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (128, 128), (16, 128), (128, 16)])
+def test_bi_interaction_mul_deferred_same_bits_as_two_launch_aggregation(K, dev, d_in, d_out):
+    """kgat_spmm_umule_sum_f32(KGAT_SPMM_DEFER_FINISH) + kgat_bi_interaction_mul_deferred_f32 - the aggregation without
+    its second launch, the rows its edge tiles cut (short chains of partials, hub rows spanning tens and hundreds
+    of tiles) and the rows without in-edges formed by the dense kernel - against the two-launch aggregation +
+    kgat_bi_interaction_mul_f32: the same bits in h_out, the normalised slice and the ego slice.  The aggregation's
+    output is pre-filled with NaN, so a deferred row taken from it would show; all three run lengths (tile sizes)."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(900 + d_in + d_out)
+    seen_tiles = set()
+    for gi, (n, e, hub, iso) in enumerate(DEFER_GRAPHS):
+        src, dst = random_graph(50 + gi, n, e, hub=hub, isolated_tail=iso)
+        X = tf(rng.standard_normal((n, d_in)).astype(np.float32), dev)
+        W2 = tf((rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32), dev)
+        indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+        w_csr = tf(rng.random(e).astype(np.float32), dev)
+        hn = ops.spmm(indptr, col, row_of, X, w_csr)
+        ego_a = torch.full((n, d_in + 8), 5.0, device=dev)
+        wide_a = torch.full((n, d_out + 24), 9.0, device=dev)
+        h_a = ops.bi_interaction_mul(X, hn, W2, 0.01, norm_out=wide_a[:, 8:8 + d_out], self_out=ego_a[:, 4:4 + d_in])
+        hn_d = torch.full((n, d_in), float("nan"), device=dev)
+        hn_d, left = ops.spmm(indptr, col, row_of, X, w_csr, out=hn_d, defer_finish=True)
+        seen_tiles.add(left.tile_edges)
+        ego_b = torch.full((n, d_in + 8), 5.0, device=dev)
+        wide_b = torch.full((n, d_out + 24), 9.0, device=dev)
+        h_b = ops.bi_interaction_mul(X, hn_d, W2, 0.01, norm_out=wide_b[:, 8:8 + d_out], self_out=ego_b[:, 4:4 + d_in],
+                                     deferred=left)
+        assert torch.equal(h_a, h_b), (n, e, float((h_a - h_b).abs().max()))
+        assert torch.equal(wide_a, wide_b) and torch.equal(ego_a, ego_b)
+        # the rows the aggregation did write are the two-launch rows; the others were left alone
+        written = ~torch.isnan(hn_d).any(dim=1)
+        assert torch.equal(hn_d[written], hn[written])
+        if e > 1000:
+            assert int((~written).sum()) > 0
+    assert len(seen_tiles) >= 2, seen_tiles
+
+
+def test_bi_interaction_mul_deferred_on_a_row_range(K, dev):
+    """The shard form: rows [row0, row0 + n_rows) of a larger CSR (positions [e0, e1) - tiles counted from e0), the
+    deferred pair against the two-launch pair on the same range."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(77)
+    n, e, d_in, d_out = 3000, 90000, 64, 32
+    src, dst = random_graph(5, n, e, hub=9000, isolated_tail=50)
+    X = tf(rng.standard_normal((n, d_in)).astype(np.float32), dev)
+    W2 = tf((rng.standard_normal((d_out, d_in)) / 8).astype(np.float32), dev)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w_csr = tf(rng.random(e).astype(np.float32), dev)
+    ip = indptr.cpu().numpy()
+    for row0, n_rows in ((0, 1000), (1, 7), (1000, 2000), (2900, 100)):
+        e0, e1 = int(ip[row0]), int(ip[row0 + n_rows])
+        Xr = X[row0:row0 + n_rows].contiguous()
+        hn = ops.spmm(indptr, col, row_of, X, w_csr, rows=(row0, n_rows), e_range=(e0, e1))
+        h_a = ops.bi_interaction_mul(Xr, hn, W2, 0.01)
+        hn_d = torch.full((n_rows, d_in), float("nan"), device=dev)
+        hn_d, left = ops.spmm(indptr, col, row_of, X, w_csr, rows=(row0, n_rows), e_range=(e0, e1), out=hn_d,
+                              defer_finish=True)
+        h_b = ops.bi_interaction_mul(Xr, hn_d, W2, 0.01, deferred=left)
+        assert torch.equal(h_a, h_b), (row0, n_rows, float((h_a - h_b).abs().max()))
+
+
+def test_deferred_finish_refuses_what_it_cannot_do(K, dev):
+    from dgl_kgat_amd import ops
+    n, e = 50, 300
+    src, dst = random_graph(3, n, e)
+    indptr, col, eid, row_of = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    w = torch.rand(e, device=dev)
+    with pytest.raises(Exception):   # a width outside the merge kernel's
+        ops.spmm(indptr, col, row_of, torch.randn(n, 8, device=dev), w, defer_finish=True)
+    with pytest.raises(Exception):   # edge-id-ordered weights
+        ops.spmm(indptr, col, row_of, torch.randn(n, 64, device=dev), w, eid=eid, defer_finish=True)
+    with pytest.raises(Exception):   # the h * h_N epilogue
+        ops.spmm(indptr, col, row_of, torch.randn(n, 64, device=dev), w, mul_self=True, defer_finish=True)
+    with pytest.raises(Exception):   # the rows algorithm has no tiles
+        ops.spmm(indptr, col, row_of, torch.randn(n, 64, device=dev), w, algo="rows", defer_finish=True)
+    X = torch.randn(n, 64, device=dev)
+    hn, left = ops.spmm(indptr, col, row_of, X, w, defer_finish=True)
+    with pytest.raises(Exception):   # another aggregation's rows
+        ops.bi_interaction_mul(torch.randn(n, 32, device=dev), torch.randn(n, 32, device=dev),
+                               torch.randn(16, 32, device=dev), deferred=left)
+    assert ops.bi_interaction_deferral_supported(64, 32) and not ops.bi_interaction_deferral_supported(8, 8)
+
+
+def test_gnn_deferred_finish_same_bits(K, dev, monkeypatch):
+    """Model.gnn's default (the aggregation's second launch left to the dense kernel) against
+    KGAT_GNN_DEFER_FINISH=0 (two launches): the same bits in the whole readout."""
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.amazon_book_ckg(scale=0.05)
+    torch.manual_seed(3)
+    model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    with torch.no_grad():
+        g.edata["w"] = model.compute_attention(g)
+        monkeypatch.setenv("KGAT_GNN_DEFER_FINISH", "0")
+        two = model.gnn(g)
+        monkeypatch.setenv("KGAT_GNN_DEFER_FINISH", "1")
+        one = model.gnn(g)
+    assert torch.equal(one, two), float((one - two).abs().max())
+
+
 def test_autograd_matches_oracle(K, dev):
     from dgl_kgat_amd import synth
     from dgl_kgat_amd.autograd import edge_softmax, u_mul_e_sum
