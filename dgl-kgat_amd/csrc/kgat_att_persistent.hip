@@ -1086,6 +1086,12 @@ constexpr int kFusedThreads = 512;
 #ifndef KGAT_ATT_XCD_REMAP
 #define KGAT_ATT_XCD_REMAP 0
 #endif
+// The packed position records (4 bytes per edge, read once per step) as non-temporal loads: they no longer displace
+// the embedding table and the layer rows from the Infinity Cache - step 0.4178 -> 0.4153 ms
+// (profiles/r04_step_ab_cache_policy.txt).  Bit 2 (A/B arm): the head-group node ids too.
+#ifndef KGAT_ATT_REC_NT
+#define KGAT_ATT_REC_NT 1
+#endif
 
 
 // X3: the two products as bf16-piece products (above); W_r's pieces sit in LDS already in fragment
@@ -1239,13 +1245,21 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     auto head_idx = [&](const int4& d) -> int32_t {
       int32_t g = d.y + i;
       g = g < rend ? g : rend - 1;
+#if KGAT_ATT_REC_NT & 2
+      return __builtin_nontemporal_load(g_node + g);
+#else
       return g_node[g];
+#endif
     };
     auto chunk_idx = [&](const int4& d, int32_t p0) -> CIdx {
       int32_t p = p0 + lane;
       p = p < d.w ? p : d.w - 1;
       CIdx c;
+#if KGAT_ATT_REC_NT & 1
+      const uint32_t rec = (uint32_t)__builtin_nontemporal_load(rec_g + p);
+#else
       const uint32_t rec = (uint32_t)rec_g[p];
+#endif
       // byte offset of the source row: N * d * 4 < 4 GiB (checked by the caller), so the node id ends
       // below bit 32 - ROW_SHIFT and the shift drops exactly the slot bits
       c.row_off = (int32_t)(rec << ROW_SHIFT);

@@ -36,18 +36,23 @@ __device__ __forceinline__ float row16_sum_d(float v) {
 #endif
 #define KGAT_BI_MUL_AT_LOAD_V (KGAT_BI_MUL_AT_LOAD != 0)
 #ifndef KGAT_BI_NT_LOADS
-#define KGAT_BI_NT_LOADS 0   // A/B builds: the row streams as non-temporal loads (measured 25-70 % SLOWER: profiles/r04_bi_probe.txt)
+#define KGAT_BI_NT_LOADS 0   // A/B builds, bit mask: 1 = the rows of H (P), 2 = the rows of HN as non-temporal loads
 #endif
 #ifndef KGAT_BI_NT_STORES
-#define KGAT_BI_NT_STORES 0  // A/B builds: the normalised slice and the ego block as non-temporal stores (no change)
+// The normalised slice and the ego block - the readout, which nothing in the step reads again - leave as non-temporal
+// stores.  Stand-alone launches do not change (profiles/r04_bi_probe.txt); the STEP does: 0.4236 -> 0.4078 ms
+// (profiles/r04_step_ab_cache_policy.txt) - the 112 MB readout no longer pushes the embedding table, the layer's rows
+// and the edge records out of the 256 MiB Infinity Cache before the next launches gather from them.
+#define KGAT_BI_NT_STORES 1
 #endif
+template <bool NT>
 __device__ __forceinline__ float4 ld_row4(const float4* p) {
-#if KGAT_BI_NT_LOADS
-  const floatx4_d v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_d*>(p));
-  return make_float4(v[0], v[1], v[2], v[3]);
-#else
-  return *p;
-#endif
+  if constexpr (NT) {
+    const floatx4_d v = __builtin_nontemporal_load(reinterpret_cast<const floatx4_d*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *p;
+  }
 }
 __device__ __forceinline__ void st_final4(float4* p, const float4& v) {
 #if KGAT_BI_NT_STORES
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     const float4* pa = reinterpret_cast<const float4*>(P + (size_t)ra * DI) + q;
 #pragma unroll
     for (int m = 0; m < DI / 16; ++m) {
-      const float4 v = ld_row4(pa + m * 4);
+      const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 1) != 0>(pa + m * 4);
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
     if constexpr (LATE_MUL) {
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       }
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
-        const float4 v = ld_row4(pb + m * 4);
+        const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 2) != 0>(pb + m * 4);
         b[4 * m + 0] = v.x; b[4 * m + 1] = v.y; b[4 * m + 2] = v.z; b[4 * m + 3] = v.w;
       }
       if constexpr (DEFER) row_offsets(t + PF, d);  // (clamped to the last row past the end)
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
-        const float4 v = ld_row4(pb + m * 4);
+        const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 2) != 0>(pb + m * 4);
         a[4 * m + 0] *= v.x; a[4 * m + 1] *= v.y; a[4 * m + 2] *= v.z; a[4 * m + 3] *= v.w;
       }
     }
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(256) void readout_concat_kernel(int64_t n_rows, Rea
         if (4 * c < w) {
           float4 r = v[j];
           if (b.normalize[k]) r = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
-          *reinterpret_cast<float4*>(o + 4 * c) = r;
+          st_final4(reinterpret_cast<float4*>(o + 4 * c), r);  // (the readout: nothing reads it again in the step)
         }
       }
       o += w;

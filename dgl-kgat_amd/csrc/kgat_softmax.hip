@@ -18,6 +18,23 @@
 
 #include "kgat_common.h"
 
+// Cache policy of the sweep's streams (bit mask KGAT_SM_NT): 2 = the position map (read once per step) as
+// non-temporal loads - step 0.4178 -> 0.4132 ms, it no longer displaces reused rows from the Infinity Cache; 1 = the
+// logits too (A/B arm: SLOWER, 0.4251 - they are gathered through the map and their lines are hit several times);
+// 4 = the destination rows (A/B arm).  profiles/r04_step_ab_cache_policy.txt
+#ifndef KGAT_SM_NT
+#define KGAT_SM_NT 2
+#endif
+#if KGAT_SM_NT & 1
+#define SM_LD_LOGIT(p) __builtin_nontemporal_load(p)
+#else
+#define SM_LD_LOGIT(p) (*(p))
+#endif
+#if KGAT_SM_NT & 2
+#define SM_LD_MAP(p) __builtin_nontemporal_load(p)
+#else
+#define SM_LD_MAP(p) (*(p))
+#endif
 namespace kgat {
 
 constexpr float kFixScale = 1099511627776.0f;       // 2^40
@@ -354,14 +371,24 @@ __device__ __forceinline__ void sm_sweep(int64_t e0, int64_t e1, int64_t w, int6
   if (FAST) {
 #pragma unroll
     for (int v = 0; v < kSmEPL / 4; ++v) {
+#if KGAT_SM_NT & 4
+      typedef int i4r __attribute__((ext_vector_type(4)));
+      const i4r b = __builtin_nontemporal_load(reinterpret_cast<const i4r*>(ro + lane * kSmEPL + 4 * v));
+#else
       const int4 b = *reinterpret_cast<const int4*>(ro + lane * kSmEPL + 4 * v);
+#endif
       r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
     }
     if (need_gi) {
       const int32_t* ei = eid + base;
 #pragma unroll
       for (int v = 0; v < kSmEPL / 4; ++v) {
+#if KGAT_SM_NT & 2
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const i4v b = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(ei + lane * kSmEPL + 4 * v));
+#else
         const int4 b = *reinterpret_cast<const int4*>(ei + lane * kSmEPL + 4 * v);
+#endif
         gi[4 * v] = b.x; gi[4 * v + 1] = b.y; gi[4 * v + 2] = b.z; gi[4 * v + 3] = b.w;
       }
     }
@@ -374,7 +401,7 @@ __device__ __forceinline__ void sm_sweep(int64_t e0, int64_t e1, int64_t w, int6
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < kSmEPL; ++i) x[i] = logits[gi[i]];
+      for (int i = 0; i < kSmEPL; ++i) x[i] = SM_LD_LOGIT(logits + gi[i]);
     }
   } else {
 #pragma unroll
@@ -382,13 +409,13 @@ __device__ __forceinline__ void sm_sweep(int64_t e0, int64_t e1, int64_t w, int6
       const int q = lane * kSmEPL + i;
       const int qc = q < n_valid ? q : n_valid - 1;
       r[i] = ro[qc];
-      gi[i] = need_gi ? eid[base + qc] : 0;
+      gi[i] = need_gi ? SM_LD_MAP(eid + base + qc) : 0;
     }
 #pragma unroll
     for (int i = 0; i < kSmEPL; ++i) {
       const int q = lane * kSmEPL + i;
       const int qc = q < n_valid ? q : n_valid - 1;
-      const float v = IN_CSR ? logits[base + qc] : logits[gi[i]];
+      const float v = IN_CSR ? SM_LD_LOGIT(logits + base + qc) : SM_LD_LOGIT(logits + gi[i]);
       x[i] = q < n_valid ? v : kSmNegBig;
     }
   }

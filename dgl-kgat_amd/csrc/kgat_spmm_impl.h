@@ -4,6 +4,12 @@
 #pragma once
 #include "kgat_common.h"
 
+#ifndef KGAT_SPMM_STORE_NT
+#define KGAT_SPMM_STORE_NT 0
+#endif
+#ifndef KGAT_SPMM_TIMING_SKIP_FINISH
+#define KGAT_SPMM_TIMING_SKIP_FINISH 0
+#endif
 namespace kgat {
 
 __device__ __forceinline__ float4 fma4(float a, const float4& x, const float4& c) {
@@ -135,7 +141,13 @@ __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4
   }
   // (round 4 tried write-through `sc1` stores here, which do not keep the output rows' lines in the XCD's L2: no change,
   // 0.0867 vs 0.0868 ms - profiles/r04_spmm_cache_policy_ab.txt)
+#if KGAT_SPMM_STORE_NT  // A/B arm: the output rows as non-temporal stores
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(out + (size_t)(row - row0) * LPR + sl));
+#else
   out[(size_t)(row - row0) * LPR + sl] = v;
+#endif
 }
 
 template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
@@ -280,7 +292,7 @@ struct alignas(16) EdgeRec {
 };
 
 #ifndef KGAT_SPMM_REC_NT
-#define KGAT_SPMM_REC_NT 0
+#define KGAT_SPMM_REC_NT 1
 #endif
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false, int DO = 0>
 __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
@@ -347,9 +359,10 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       rec.r = (int32_t)(p >> 5) + row0;
       rec.w = 1.0f;
 #else
-#if KGAT_SPMM_REC_NT  // A/B arm: the once-read record streams as non-temporal loads.  Stand-alone launches back to back
-                      // gain 3 % (D = 64) / 7 % (D = 32) - profiles/r04_spmm_cache_policy_ab.txt -, the step does not
-                      // (aggregation 70.1 vs 68.8 us avg): default off
+#if KGAT_SPMM_REC_NT  // the record streams (12 bytes per edge, read once per launch) as non-temporal loads: stand-alone
+                      // launches gain 3 % (D = 64) / 7 % (D = 32) - profiles/r04_spmm_cache_policy_ab.txt -, the step
+                      // 6.6 us (0.4244 -> 0.4178 ms, profiles/r04_step_ab_cache_policy.txt; the first step-level
+                      // comparison, on per-kernel averages of separate runs, had not resolved it)
       rec.c = __builtin_nontemporal_load(col + p);
       rec.r = __builtin_nontemporal_load(row_of + p);
       rec.w = __builtin_nontemporal_load(w + p);
@@ -408,9 +421,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   // 77.5 us for the plain operator, profiles/r04_spmm_epilogue_probe.txt).  A/B arm KGAT_SPMM_SELF_PREFETCH=1:
   // request it when the row OPENS instead.  The layer now forms h * h_N in the bi-interaction kernel
   // (kgat_bi_interaction_mul_f32) and calls the plain operator.
-#ifndef KGAT_SPMM_TIMING_SKIP_FINISH
-#define KGAT_SPMM_TIMING_SKIP_FINISH 0
-#endif
 #ifndef KGAT_SPMM_COMBINE_ENTRYWISE
 #define KGAT_SPMM_COMBINE_ENTRYWISE 0
 #endif
