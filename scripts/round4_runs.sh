@@ -42,7 +42,7 @@ python scripts/pmc_traffic.py $O/pmc_spmm_fetch $O/pmc_spmm_write "spmm_merge2_k
 python scripts/pmc_traffic.py $O/pmc_pl_fetch $O/pmc_pl_write "spmm_merge2_kernel|spmm_finish_kernel" $O/pmc_spmm_traffic_powerlaw.json --sources kgat_spmm.hip,kgat_spmm_impl.h,kgat_common.h --workload "power-law CKG drawn on the device N=10000000 E=200000000, D=64, plain update_all(u_mul_e, sum)" --command "PROBE_MUL_SELF=0 rocprofv3 --pmc FETCH_SIZE (and WRITE_SIZE) --output-format csv -- python3 scripts/hbm_probe.py redraw 1e7 2e8 3" --algorithmic 55400000000 > /dev/null 2>&1
 python scripts/pmc_traffic.py $O/pmc_step_fetch $O/pmc_step_write "att_fold_fused_kernel" $O/pmc_att_traffic.json --sources kgat_att_persistent.hip,kgat_att_common.h,kgat_common.h --workload "amazon-book-shaped CKG N=159251 E=3663302 R=41, d=k=64, fused form (bf16 / fp16 piece products), grouped-order logits" --command "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-graphs" > /dev/null 2>&1
 python scripts/pmc_traffic.py $O/pmc_step_fetch $O/pmc_step_write "softmax_local_kernel|softmax_cut_rows_kernel" $O/pmc_softmax_traffic.json --sources kgat_softmax.hip,kgat_common.h --workload "amazon-book-shaped CKG N=159251 E=3663302, grouped-order logits read through the position map" --command "same passes as pmc_att_traffic.json" --algorithmic 59249836 > /dev/null 2>&1
-python scripts/pmc_traffic.py $O/pmc_step_fetch $O/pmc_step_write "bi_interaction_kernel<64, 64, 1" $O/pmc_bi_traffic.json --sources kgat_dense.hip,kgat_common.h --workload "amazon-book-shaped CKG N=159251, 64 -> 64 (kgat_bi_interaction_mul_f32: H, HN read; h_out, normalised slice and ego block written)" --command "same passes as pmc_att_traffic.json" --algorithmic 203841280 > /dev/null 2>&1
+python scripts/pmc_traffic.py $O/pmc_step_fetch $O/pmc_step_write "bi_interaction_kernel<64, 64, 1" $O/pmc_bi_traffic.json --sources kgat_dense.hip,kgat_common.h --workload "amazon-book-shaped CKG N=159251, 64 -> 64 (kgat_bi_interaction_mul_deferred_f32: H, HN read - and the row offsets plus the tile partials of the rows the aggregation left -; h_out, normalised slice and ego block written, the last two non-temporal)" --command "same passes as pmc_att_traffic.json" --algorithmic 203841280 > /dev/null 2>&1
 find $O -name "*kernel_trace.csv" -size +5M -delete
 find $O -name "*counter_collection.csv" -size +3M -delete
 du -sh $O; tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log
