@@ -90,6 +90,8 @@ struct EgoCopy {
 // kernel forms them on the way, from the row offsets and the tiles' boundary partials in the aggregation's
 // workspace, in the finish launch's order of additions (same bits).  A dependent launch costs its ~2 us boundary
 // plus a pass over 2 x tiles items: 4.4 us per layer on the benchmark graph (scripts/micro/step_ab.py).
+// (Requesting a chain's first follower in the load step as well - one stage instead of two at d_in >= 64 for the
+// registers - changes nothing: 0.4093 vs 0.4088 ms per step.)
 struct DeferredRows {
   const int32_t* indptr;  // row offsets of THIS call's row 0 .. n_rows (CSR positions)
   const float4* bpart;    // per tile two partial rows (first row's, last row's), LPR = d_in / 4 float4 each
