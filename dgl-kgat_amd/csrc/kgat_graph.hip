@@ -262,15 +262,36 @@ __global__ void fold_parts_kernel(int n_rel, int64_t t_max, const int32_t* __res
 // thread: one 16-byte index load, four independent gathers in flight, one 16-byte store (the
 // one-item-per-thread form spent its time on issue slots and launch granularity, not on the
 // gathered sectors).  Pointers with 16-byte alignment take the vector path.
+// fp32 gathers are the permutations of per-edge weights between CSR order and edge-id / reversed-CSR order: the result is
+// either never read on the path (the edge-id-ordered attention tensor) or read once by the next launch's record stream,
+// the index is read once - both as non-temporal accesses (KGAT_GATHER_NT=0: A/B arm; eager step 0.4431 -> 0.4386 ms,
+// profiles/r04_step_ab_cache_policy.txt).  Integer gathers (structure build) stay plain.
+#ifndef KGAT_GATHER_NT
+#define KGAT_GATHER_NT 1
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void gather4_kernel(int64_t n, const int32_t* __restrict__ index,
                                                       const T* __restrict__ in, T* __restrict__ out) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
-    const int4 ix = *reinterpret_cast<const int4*>(index + i);
+    typedef int i4g __attribute__((ext_vector_type(4)));
+    constexpr bool NT = KGAT_GATHER_NT != 0 && sizeof(T) == 4 && static_cast<T>(0.5f) != static_cast<T>(0);  // (float, not int)
+    int4 ix;
+    if constexpr (NT) {
+      const i4g ix4 = __builtin_nontemporal_load(reinterpret_cast<const i4g*>(index + i));
+      ix = make_int4(ix4[0], ix4[1], ix4[2], ix4[3]);
+    } else {
+      ix = *reinterpret_cast<const int4*>(index + i);
+    }
     const T a = in[ix.x], b = in[ix.y], c = in[ix.z], d = in[ix.w];
     T v[4] = {a, b, c, d};
-    *reinterpret_cast<int4*>(out + i) = *reinterpret_cast<const int4*>(v);
+    if constexpr (NT) {
+      const int4 o4 = *reinterpret_cast<const int4*>(v);
+      const i4g ov = {o4.x, o4.y, o4.z, o4.w};
+      __builtin_nontemporal_store(ov, reinterpret_cast<i4g*>(out + i));
+    } else {
+      *reinterpret_cast<int4*>(out + i) = *reinterpret_cast<const int4*>(v);
+    }
   } else {
     for (int64_t k = i; k < n; ++k) out[k] = in[index[k]];
   }

@@ -36,7 +36,8 @@ for vi, flags in enumerate(f for f in os.environ.get("AB_FLAGS", "").split(";") 
 _lib._lib = base
 
 dev = torch.device("cuda:0")
-K.enable_lazy_edge_weights()
+if os.environ.get("AB_EAGER", "") in ("", "0"):   # AB_EAGER=1: the library default (edge-id-ordered weights written every step)
+    K.enable_lazy_edge_weights()
 n, trip, n_rel = synth.amazon_book_ckg()
 g = synth.build_graph(n, trip, device=dev)
 E = g.number_of_edges()
