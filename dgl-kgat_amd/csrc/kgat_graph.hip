@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void gather4_kernel(int64_t n, const int32_t* 
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     typedef int i4g __attribute__((ext_vector_type(4)));
-    constexpr bool NT = KGAT_GATHER_NT != 0 && sizeof(T) == 4 && static_cast<T>(0.5f) != static_cast<T>(0);  // (float, not int)
+    constexpr bool NT = KGAT_GATHER_NT != 0 && std::is_same<T, float>::value;
     int4 ix;
     if constexpr (NT) {
       const i4g ix4 = __builtin_nontemporal_load(reinterpret_cast<const i4g*>(index + i));
