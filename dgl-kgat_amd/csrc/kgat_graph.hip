@@ -7,6 +7,8 @@
 // wave-ballot ranking, no MFMA.
 #include <stdarg.h>
 
+#include <type_traits>
+
 #include "kgat_common.h"
 
 namespace kgat {
