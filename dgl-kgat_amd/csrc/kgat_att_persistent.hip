@@ -1081,10 +1081,16 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
 // with their indices requested one chunk ahead; their tail rows are not (the row buffer is 64
 // registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
 constexpr int kFusedThreads = 512;
-// KGAT_ATT_XCD_REMAP=1 (A/B builds): every XCD a contiguous eighth of the workgroups' tile ranges
-// (xcd_contiguous, kgat_common.h).  Within the noise at d = 64 (0.172 vs 0.176 ms), 2 % slower at d = 128.
+// KGAT_ATT_XCD_REMAP=1: every XCD a contiguous eighth of the workgroups' tile ranges (xcd_contiguous, kgat_common.h)
+// - neighbouring ranges, which share head nodes and relation tables, behind one L2.  Stand-alone within the noise at
+// d = 64 (0.172 vs 0.176 ms, round 3); in the step 0.4116 -> 0.4098 and 0.4121 -> 0.4107 ms on two boxes
+// (profiles/r04_step_ab_cache_policy.txt): default since round 4 for d <= 64.  2 % slower at d = 128
+// (KGAT_ATT128_XCD_REMAP, off).
 #ifndef KGAT_ATT_XCD_REMAP
-#define KGAT_ATT_XCD_REMAP 0
+#define KGAT_ATT_XCD_REMAP 1
+#endif
+#ifndef KGAT_ATT128_XCD_REMAP
+#define KGAT_ATT128_XCD_REMAP 0
 #endif
 // The packed position records (4 bytes per edge, read once per step) as non-temporal loads: they no longer displace
 // the embedding table and the layer rows from the Infinity Cache - step 0.4178 -> 0.4153 ms
@@ -1602,7 +1608,7 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
     }
   }
   const int32_t n_tiles = rel_tptr[n_rel];
-  const unsigned part = KGAT_ATT_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const unsigned part = KGAT_ATT128_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
   const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];

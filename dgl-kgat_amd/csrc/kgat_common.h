@@ -43,9 +43,9 @@ inline int device_cu_count() {
 
 // Workgroups are dealt round-robin over the 8 XCDs (observed placement, a speed matter only: blocks b and
 // b + 8 share an L2; MI355X_MICROARCH.md, Workgroup dispatch).  The work item of block b out of n such
-// that the blocks of one XCD take a CONTIGUOUS eighth of the items (bijective for any n).  Tried on the
-// aggregation's tiles and on the attention's tile ranges in round 3 and NOT adopted (slower / no gain:
-// notes at KGAT_SPMM_XCD_REMAP and KGAT_ATT_XCD_REMAP); kept for A/B builds.
+// that the blocks of one XCD take a CONTIGUOUS eighth of the items (bijective for any n).  Used by the fused
+// attention kernel at d <= 64 (KGAT_ATT_XCD_REMAP); slower on the aggregation's tiles and on the d = 128 attention
+// (notes at KGAT_SPMM_XCD_REMAP, KGAT_ATT128_XCD_REMAP: A/B builds).
 __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n) {
   const unsigned q = n / 8, r = n % 8, x = b % 8;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
