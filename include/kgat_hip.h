@@ -340,7 +340,7 @@ int kgat_bi_interaction_mul_f32(int64_t n_rows, int d_in, int d_out, const float
  * kgat_bi_interaction_mul_f32 - forms them on the way from `indptr_rows` (= indptr + row0: the row offsets of the
  * call's rows 0 .. n_rows), the edge range and the untouched workspace, in the second launch's order of additions:
  * bit-identical results.  d_in, d_out in {16, 32, 64, 128}; nothing else may use the workspace between the two calls.
- * (Benchmark graph: 4.4 us per layer, 13 us of a 0.44 ms step.) */
+ * (Benchmark graph: the three second launches cost 13 us of a 0.44 ms step; forming their rows costs the dense kernels 6.) */
 int kgat_spmm_tile_edges(int64_t n_edges, int D);  /* 0: D outside {16, 32, 64, 128} */
 int kgat_bi_interaction_mul_deferred_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
                                          const float* W2, float negative_slope, float* h_out, float* norm_out,
