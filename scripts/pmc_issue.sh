@@ -7,6 +7,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS -d $O/p3 --output-format csv -- $B > $O/p3.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM -d $O/p4 --output-format csv -- $B > $O/p4.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 scripts/pmc_summary.py "att_fold_fused_kernel|spmm_merge2_kernel<16, 64, true, false>|softmax_local|bi_interaction_kernel<64, 64" $O/p1 $O/p2 $O/p3 $O/p4 > $O/summary.txt 2>&1
+python3 scripts/pmc_summary.py "att_fold_fused_kernel|spmm_merge2_kernel<16, 64, false, false, 0>|spmm_merge2_kernel<8, 32, false|softmax_local|bi_interaction_kernel<64, 64, 1" $O/p1 $O/p2 $O/p3 $O/p4 > $O/summary.txt 2>&1
 find $O -name "*counter_collection.csv" -size +3M -delete
 cat $O/summary.txt
