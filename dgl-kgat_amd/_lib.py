@@ -75,6 +75,8 @@ SIGNATURES = {
     "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _i64,
                                                _p, _p]),
     "kgat_mul2_f32": (_i32, [_i64, _p, _p, _p, _p, _p, _p]),
+    "kgat_bi_interaction_bwd_input_supported": (_i32, [_i32, _i32]),
+    "kgat_bi_interaction_bwd_input_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "kgat_transr_supported": (_i32, [_i64, _i32, _i32, _i32, _i64]),
     "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,
@@ -108,7 +110,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def source_hash():

@@ -174,8 +174,12 @@ class _GNNTrain(torch.autograd.Function):
                                             ctx.drop_p, ctx.seed + li)
             if ctx.needs_input_grad[5 + li]:
                 grad_w[li] = tall_weight_grad(gz, hs[li] * hns[li])
-            gp = gz @ weights[li].detach()
-            t, g_b = ops.mul2(gp, hs[li], hns[li])          # grad_P * h (to be aggregated), grad_P * h_N
+            w_l = weights[li].detach().contiguous()
+            if ops.bi_interaction_bwd_input_supported(w_l.shape[1], w_l.shape[0]):
+                # grad_P = grad_z W2 formed per tile and multiplied on the way: grad_P * h (to be aggregated), grad_P * h_N
+                t, g_b = ops.bi_interaction_bwd_input(gz, w_l, hs[li], hns[li])
+            else:
+                t, g_b = ops.mul2(gz @ w_l, hs[li], hns[li])
             g_a = ops.spmm(rev.indptr, rev.col, rev.row_of, t, w_rev)
         grad_h0 = None
         if ctx.needs_input_grad[4]:

@@ -640,6 +640,99 @@ __global__ __launch_bounds__(256) void bi_bwd_pre_kernel(int64_t n_rows, int d, 
   }
 }
 
+// Backward of the dense part towards the layer input (round 4, second half): grad_P = grad_z W2, then the two products
+// the rest of the backward wants - T = grad_P * H (aggregated over the reversed CSR: the gradient through h_N) and
+// GB = grad_P * HN (the gradient through the row's own features) - in one pass.  Replaces a library GEMM + kgat_mul2_f32:
+// grad_P (N x d_in) is never written.  The forward kernel's structure with the weight read transposed:
+// B fragments s_w[(s*KT + c)*64 + q*16 + i] = W2[k][16c + i], k = 16 (s >> 2) + 4q + (s & 3) the contraction index (a
+// column of grad_z), 16c + i the output column; a lane ends with four consecutive columns of one row, where it also
+// holds H and HN (requested with the grad_z rows).
+template <int DK, int DN>
+__global__ __launch_bounds__(256) void bi_bwd_input_kernel(int32_t n_rows, const float* __restrict__ GZ,
+                                                          const float* __restrict__ W2, const float* __restrict__ H,
+                                                          const float* __restrict__ HN, float* __restrict__ T,
+                                                          float* __restrict__ GB) {
+  constexpr int KS = DK / 4, KT = DN / 16;
+  __shared__ float s_w[KS * KT * kWave];
+  for (int idx = threadIdx.x * 4; idx < DK * DN; idx += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(W2 + idx);  // W2[k][j0 .. j0 + 3]
+    const int k = idx / DN, j0 = idx % DN;
+    const int s = (k >> 4) * 4 + (k & 3), q = (k >> 2) & 3;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + t;
+      s_w[(s * KT + (j >> 4)) * kWave + q * 16 + (j & 15)] = vv[t];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x % kWave;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n_waves = (int64_t)gridDim.x * (256 / kWave);
+  const int64_t wv = (int64_t)blockIdx.x * (256 / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  const int32_t n_tiles = (n_rows + 15) >> 4;
+  const int32_t t_begin = (int32_t)((int64_t)n_tiles * wv / n_waves);
+  const int32_t t_end = (int32_t)((int64_t)n_tiles * (wv + 1) / n_waves);
+  if (t_begin >= t_end) return;
+  constexpr bool W_IN_LDS = KS * KT > 128;
+  float wreg[W_IN_LDS ? 1 : KS][W_IN_LDS ? 1 : KT];
+  if (!W_IN_LDS) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < KT; ++c) wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c] = s_w[(s * KT + c) * kWave + lane];
+  }
+  struct Rows { float g[KS]; float4 h[KT], hn[KT]; };
+  auto load_rows = [&](int32_t t, Rows& r) {
+    int32_t ra = (t << 4) + i;
+    ra = ra < n_rows ? ra : n_rows - 1;
+    const float4* pg = reinterpret_cast<const float4*>(GZ + (size_t)ra * DK) + q;
+#pragma unroll
+    for (int m = 0; m < DK / 16; ++m) {
+      const float4 v = pg[m * 4];
+      r.g[4 * m + 0] = v.x; r.g[4 * m + 1] = v.y; r.g[4 * m + 2] = v.z; r.g[4 * m + 3] = v.w;
+    }
+    const float4* ph = reinterpret_cast<const float4*>(H + (size_t)ra * DN) + q;
+    const float4* pn = reinterpret_cast<const float4*>(HN + (size_t)ra * DN) + q;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      r.h[c] = ph[c * 4];
+      r.hn[c] = pn[c * 4];
+    }
+  };
+  auto tile = [&](int32_t t, const Rows& r) {
+    floatx4_d acc[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+            W_IN_LDS ? s_w[(s * KT + c) * kWave + lane] : wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c], r.g[s], acc[c], 0, 0, 0);
+    const int32_t row = (t << 4) + i;
+    if (row < n_rows) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const size_t off = (size_t)row * DN + 16 * c + 4 * q;
+        *reinterpret_cast<float4*>(T + off) =
+            make_float4(acc[c][0] * r.h[c].x, acc[c][1] * r.h[c].y, acc[c][2] * r.h[c].z, acc[c][3] * r.h[c].w);
+        *reinterpret_cast<float4*>(GB + off) =
+            make_float4(acc[c][0] * r.hn[c].x, acc[c][1] * r.hn[c].y, acc[c][2] * r.hn[c].z, acc[c][3] * r.hn[c].w);
+      }
+    }
+  };
+  Rows r0, r1;
+  load_rows(t_begin, r0);
+  for (int32_t t = t_begin; t < t_end; t += 2) {
+    if (t + 1 < t_end) load_rows(t + 1, r1);
+    tile(t, r0);
+    if (t + 1 >= t_end) break;
+    if (t + 2 < t_end) load_rows(t + 2, r0);
+    tile(t + 1, r1);
+  }
+}
+
 __global__ __launch_bounds__(256) void mul2_kernel(int64_t n4, const float4* __restrict__ A, const float4* __restrict__ B,
                                                    const float4* __restrict__ C, float4* __restrict__ AB,
                                                    float4* __restrict__ AC) {
@@ -821,6 +914,40 @@ int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_ou
                      dr.index0, grad_z);
   KGAT_CHECK_LAUNCH("bi_bwd_pre");
   return KGAT_OK;
+}
+
+int kgat_bi_interaction_bwd_input_supported(int d_in, int d_out) {
+  auto ok = [](int d) { return d == 16 || d == 32 || d == 64 || d == 128; };
+  return ok(d_in) && ok(d_out);
+}
+
+int kgat_bi_interaction_bwd_input_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* W2,
+                                      const float* H, const float* HN, float* grad_hn_times_h, float* grad_h_direct,
+                                      kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX, "bi_interaction_bwd_input: bad row count");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(grad_z && W2 && H && HN && grad_hn_times_h && grad_h_direct, "bi_interaction_bwd_input: null pointer");
+  if (!kgat_bi_interaction_bwd_input_supported(d_in, d_out)) {
+    set_error("bi_interaction_bwd_input: unsupported widths %d -> %d", d_in, d_out);
+    return KGAT_E_UNSUPPORTED;
+  }
+  const int64_t tiles = (n_rows + 15) / 16;
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 512) blocks = 512;
+#define KGAT_BWD_CASE(DK, DN)                                                                                         \
+  if (d_out == DK && d_in == DN) {                                                                                    \
+    hipLaunchKernelGGL((bi_bwd_input_kernel<DK, DN>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),        \
+                       (int32_t)n_rows, grad_z, W2, H, HN, grad_hn_times_h, grad_h_direct);                           \
+    KGAT_CHECK_LAUNCH("bi_bwd_input");                                                                                \
+    return KGAT_OK;                                                                                                   \
+  }
+  KGAT_BWD_CASE(16, 16) KGAT_BWD_CASE(16, 32) KGAT_BWD_CASE(16, 64) KGAT_BWD_CASE(16, 128)
+  KGAT_BWD_CASE(32, 16) KGAT_BWD_CASE(32, 32) KGAT_BWD_CASE(32, 64) KGAT_BWD_CASE(32, 128)
+  KGAT_BWD_CASE(64, 16) KGAT_BWD_CASE(64, 32) KGAT_BWD_CASE(64, 64) KGAT_BWD_CASE(64, 128)
+  KGAT_BWD_CASE(128, 16) KGAT_BWD_CASE(128, 32) KGAT_BWD_CASE(128, 64) KGAT_BWD_CASE(128, 128)
+#undef KGAT_BWD_CASE
+  set_error("bi_interaction_bwd_input: unsupported widths %d -> %d", d_in, d_out);
+  return KGAT_E_UNSUPPORTED;
 }
 
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,

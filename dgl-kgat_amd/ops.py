@@ -666,6 +666,27 @@ def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, dro
     return gz
 
 
+def bi_interaction_bwd_input_supported(d_in, d_out):
+    return bool(_lib.load().kgat_bi_interaction_bwd_input_supported(int(d_in), int(d_out)))
+
+
+def bi_interaction_bwd_input(grad_z, W2, H, HN):
+    """((grad_z @ W2) * H, (grad_z @ W2) * HN) in one pass (kgat_bi_interaction_bwd_input_f32): the gradient of the
+    layer's dense part towards h_N (times h: what the reversed-CSR aggregation then sums) and towards h itself."""
+    grad_z = _need(grad_z, torch.float32, "grad_z")
+    W2 = _need(W2, torch.float32, "W2")
+    n, d_out = grad_z.shape
+    d_in = W2.shape[1]
+    if W2.shape[0] != d_out:
+        raise ValueError("W2 has shape %s, expected (%d, *)" % (tuple(W2.shape), d_out))
+    H = _need(H, torch.float32, "H", (n, d_in))
+    HN = _need(HN, torch.float32, "HN", (n, d_in))
+    t, gb = torch.empty_like(H), torch.empty_like(H)
+    check(_lib.load().kgat_bi_interaction_bwd_input_f32(n, d_in, d_out, _ptr(grad_z), _ptr(W2), _ptr(H), _ptr(HN), _ptr(t),
+                                                        _ptr(gb), _stream(H)), "kgat_bi_interaction_bwd_input_f32")
+    return t, gb
+
+
 def mul2(a, b, c):
     """(a * b, a * c) in one pass."""
     a = _need(a, torch.float32, "a")
@@ -753,6 +774,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]

@@ -492,8 +492,11 @@ class _ShardConv(torch.autograd.Function):
             if need_w:
                 gw = tall_weight_grad(gz, h_loc * hn)
             if need_h:
-                gp = gz @ w
-                t, g_b = ops.mul2(gp, h_loc, hn)     # grad_P * h (aggregated back to the sources), grad_P * h_N
+                # grad_P * h (aggregated back to the sources), grad_P * h_N
+                if ops.bi_interaction_bwd_input_supported(w.shape[1], w.shape[0]):
+                    t, g_b = ops.bi_interaction_bwd_input(gz, w.contiguous(), h_loc, hn)
+                else:
+                    t, g_b = ops.mul2(gz @ w, h_loc, hn)
                 rev = st.csr_rev(dev)
                 # the local edges' destinations all lie in [lo, hi): only those rows of the operand are read
                 t_full = torch.empty((h.shape[0], d_in), dtype=torch.float32, device=dev)

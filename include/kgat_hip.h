@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 6
+#define KGAT_ABI_VERSION 7
 
 enum {
   KGAT_OK = 0,
@@ -408,6 +408,14 @@ int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_ou
                                     const float* grad_b, const float* grad_norm, int64_t grad_norm_stride,
                                     float negative_slope, float drop_p, uint64_t seed, int64_t row0, float* grad_z,
                                     kgat_stream_t stream);
+/* The same two steps in one pass (round 4): grad_P = grad_z W2 formed per 16-row tile on the fp32 MFMA and never
+ * written; grad_hn_times_h = grad_P * H (what the reversed-CSR SpMM then aggregates: the gradient through h_N, reference
+ * models.py:63,66 under autograd) and grad_h_direct = grad_P * HN (the gradient through the row's own features), both
+ * n_rows x d_in.  grad_z n_rows x d_out, W2 = res_fc_2.weight (d_out x d_in).  d_in, d_out in {16, 32, 64, 128}. */
+int kgat_bi_interaction_bwd_input_supported(int d_in, int d_out);
+int kgat_bi_interaction_bwd_input_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* W2,
+                                      const float* H, const float* HN, float* grad_hn_times_h, float* grad_h_direct,
+                                      kgat_stream_t stream);
 /* ab = a * b and ac = a * c elementwise in one pass (n a multiple of 4). */
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
                   kgat_stream_t stream);

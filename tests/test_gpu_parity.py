@@ -1013,6 +1013,30 @@ def test_gnn_deferred_finish_same_bits(K, dev, monkeypatch):
     assert torch.equal(one, two), float((one - two).abs().max())
 
 
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (128, 128), (16, 128), (128, 16)])
+def test_bi_interaction_bwd_input_vs_fp64(K, dev, d_in, d_out):
+    """kgat_bi_interaction_bwd_input_f32 - grad_P = grad_z W2 on the fp32 MFMA, multiplied by H and by HN on the way -
+    against the fp64 product: relative to sum |grad_z| |W2| per element (the products' own rounding), row counts around
+    the 16-row tile and the wavefronts' tile ranges; every element of both outputs written, nothing else."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(40 + d_in + d_out)
+    assert ops.bi_interaction_bwd_input_supported(d_in, d_out) and not ops.bi_interaction_bwd_input_supported(8, 64)
+    for n in (1, 15, 16, 17, 4001, 70000):
+        gz = rng.standard_normal((n, d_out)).astype(np.float32)
+        W2 = (rng.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+        H = rng.standard_normal((n, d_in)).astype(np.float32)
+        HN = rng.standard_normal((n, d_in)).astype(np.float32)
+        t, gb = ops.bi_interaction_bwd_input(tf(gz, dev), tf(W2, dev), tf(H, dev), tf(HN, dev))
+        gp = gz.astype(np.float64) @ W2.astype(np.float64)
+        bound = np.abs(gz).astype(np.float64) @ np.abs(W2).astype(np.float64)
+        for got, factor in ((t, H), (gb, HN)):
+            err = np.abs(got.cpu().numpy().astype(np.float64) - gp * factor)
+            assert np.all(err <= 4e-7 * bound * np.abs(factor) + 1e-30), (n, float((err / (bound * np.abs(factor) + 1e-30)).max()))
+    with pytest.raises(Exception):
+        ops.bi_interaction_bwd_input(torch.randn(5, 8, device=dev), torch.randn(8, 64, device=dev),
+                                     torch.randn(5, 64, device=dev), torch.randn(5, 64, device=dev))
+
+
 def test_autograd_matches_oracle(K, dev):
     from dgl_kgat_amd import synth
     from dgl_kgat_amd.autograd import edge_softmax, u_mul_e_sum
