@@ -77,6 +77,8 @@ SIGNATURES = {
     "kgat_mul2_f32": (_i32, [_i64, _p, _p, _p, _p, _p, _p]),
     "kgat_bi_interaction_bwd_input_supported": (_i32, [_i32, _i32]),
     "kgat_bi_interaction_bwd_input_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "kgat_bi_interaction_bwd_weight_partials": (_i64, [_i64]),
+    "kgat_bi_interaction_bwd_weight_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "kgat_transr_supported": (_i32, [_i64, _i32, _i32, _i32, _i64]),
     "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,

@@ -173,7 +173,10 @@ class _GNNTrain(torch.autograd.Function):
             gz = ops.bi_interaction_bwd_pre(hs[li + 1], g_a, g_b, grad_out[:, offs[li + 1]:offs[li + 2]], ctx.slope,
                                             ctx.drop_p, ctx.seed + li)
             if ctx.needs_input_grad[5 + li]:
-                grad_w[li] = tall_weight_grad(gz, hs[li] * hns[li])
+                if ops.bi_interaction_bwd_input_supported(hs[li].shape[1], gz.shape[1]):
+                    grad_w[li] = ops.bi_interaction_bwd_weight(gz, hs[li], hns[li])   # grad_z^T (h * h_N)
+                else:
+                    grad_w[li] = tall_weight_grad(gz, hs[li] * hns[li])
             w_l = weights[li].detach().contiguous()
             if ops.bi_interaction_bwd_input_supported(w_l.shape[1], w_l.shape[0]):
                 # grad_P = grad_z W2 formed per tile and multiplied on the way: grad_P * h (to be aggregated), grad_P * h_N

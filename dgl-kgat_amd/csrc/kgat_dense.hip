@@ -733,6 +733,97 @@ __global__ __launch_bounds__(256) void bi_bwd_input_kernel(int32_t n_rows, const
   }
 }
 
+// Weight gradient of the dense part (round 4, second half): grad_W2 = grad_z^T (H * HN), a (d_out x d_in) result reduced
+// over all N rows.  Replaces torch's H * HN (an N x d_in round trip) + a batched library GEMM over row slabs.  A
+// workgroup walks 64-row slabs: the rows of grad_z and the product H * HN (formed on the way) are staged in LDS, row
+// stride D + 16 floats so that the four rows of a k-step sit 16 banks apart; wavefront w owns the output tiles
+// w, w + 4, ... (at 64 x 64: one column tile, all four row tiles - one B read per four MFMAs); the contraction index
+// of v_mfma_f32_16x16x4_f32 is the ROW: A[m][k] = grad_z[r0 + k][16 cm + m], B[k][n] = P[r0 + k][16 cn + n].  Every
+// workgroup writes its partial (d_out x d_in); the caller sums the partials (fixed order: reproducible).
+template <int DO, int DI>
+__global__ __launch_bounds__(256) void bi_bwd_weight_kernel(int32_t n_rows, const float* __restrict__ GZ,
+                                                           const float* __restrict__ H, const float* __restrict__ HN,
+                                                           float* __restrict__ partial) {
+  constexpr int SLAB = 64;
+  constexpr int LG = DO == 16 ? 16 : DO + 16, LP = DI == 16 ? 16 : DI + 16;
+  constexpr int TM = DO / 16, TN = DI / 16, TT = TM * TN;
+  constexpr int TPW = (TT + 3) / 4;                 // output tiles per wavefront
+  constexpr int G4 = SLAB * DO / 4 / 256 > 0 ? SLAB * DO / 4 / 256 : 1;  // float4 of grad_z per thread per slab
+  constexpr int P4 = SLAB * DI / 4 / 256 > 0 ? SLAB * DI / 4 / 256 : 1;
+  __shared__ float s_g[SLAB * LG];
+  __shared__ float s_p[SLAB * LP];
+  const int tid = threadIdx.x, lane = tid % kWave, w = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int i = lane & 15, q = lane >> 4;
+  const int32_t n_slabs = (n_rows + SLAB - 1) / SLAB;
+  floatx4_d acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (floatx4_d){0.f, 0.f, 0.f, 0.f};
+  float4 g[G4], hh[P4], hn[P4];
+  auto request = [&](int32_t slab) {  // the slab's rows into registers (rows past the end: zeros)
+    const int32_t r0 = slab * SLAB;
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int e = (u * 256 + tid) * 4;            // element index inside the SLAB x DO block
+      const int32_t r = r0 + e / DO;
+      g[u] = (e < SLAB * DO && r < n_rows) ? *reinterpret_cast<const float4*>(GZ + (size_t)r * DO + e % DO)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < P4; ++u) {
+      const int e = (u * 256 + tid) * 4;
+      const int32_t r = r0 + e / DI;
+      const bool in = e < SLAB * DI && r < n_rows;
+      hh[u] = in ? *reinterpret_cast<const float4*>(H + (size_t)r * DI + e % DI) : make_float4(0.f, 0.f, 0.f, 0.f);
+      hn[u] = in ? *reinterpret_cast<const float4*>(HN + (size_t)r * DI + e % DI) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int32_t slab = blockIdx.x;
+  if (slab < n_slabs) request(slab);
+  for (; slab < n_slabs; slab += gridDim.x) {
+    __syncthreads();  // the previous slab's fragments have been read
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      const int e = (u * 256 + tid) * 4;
+      if (e < SLAB * DO) *reinterpret_cast<float4*>(&s_g[(e / DO) * LG + e % DO]) = g[u];
+    }
+#pragma unroll
+    for (int u = 0; u < P4; ++u) {
+      const int e = (u * 256 + tid) * 4;
+      if (e < SLAB * DI)
+        *reinterpret_cast<float4*>(&s_p[(e / DI) * LP + e % DI]) =
+            make_float4(hh[u].x * hn[u].x, hh[u].y * hn[u].y, hh[u].z * hn[u].z, hh[u].w * hn[u].w);
+    }
+    __syncthreads();
+    if (slab + (int32_t)gridDim.x < n_slabs) request(slab + gridDim.x);  // in flight while this slab is multiplied
+    if (w * 1 < TT) {
+#pragma unroll 4
+      for (int r0 = 0; r0 < SLAB; r0 += 4) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int tile = w + 4 * t;
+          if (tile < TT) {
+            const int cm = tile / TN, cn = tile % TN;
+            const float a = s_g[(r0 + q) * LG + 16 * cm + i];
+            const float b = s_p[(r0 + q) * LP + 16 * cn + i];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // C[m = 4q + j][n = i] of tile (cm, cn) -> partial[block][16 cm + 4q + j][16 cn + i]
+  float* out = partial + (size_t)blockIdx.x * DO * DI;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = w + 4 * t;
+    if (tile < TT) {
+      const int cm = tile / TN, cn = tile % TN;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[(size_t)(16 * cm + 4 * q + j) * DI + 16 * cn + i] = acc[t][j];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void mul2_kernel(int64_t n4, const float4* __restrict__ A, const float4* __restrict__ B,
                                                    const float4* __restrict__ C, float4* __restrict__ AB,
                                                    float4* __restrict__ AC) {
@@ -947,6 +1038,38 @@ int kgat_bi_interaction_bwd_input_f32(int64_t n_rows, int d_in, int d_out, const
   KGAT_BWD_CASE(128, 16) KGAT_BWD_CASE(128, 32) KGAT_BWD_CASE(128, 64) KGAT_BWD_CASE(128, 128)
 #undef KGAT_BWD_CASE
   set_error("bi_interaction_bwd_input: unsupported widths %d -> %d", d_in, d_out);
+  return KGAT_E_UNSUPPORTED;
+}
+
+int64_t kgat_bi_interaction_bwd_weight_partials(int64_t n_rows) {
+  int64_t nb = (n_rows + 63) / 64;
+  if (nb > 768) nb = 768;   // three workgroups per CU; each partial is d_out x d_in floats
+  return nb < 1 ? 1 : nb;
+}
+
+int kgat_bi_interaction_bwd_weight_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* H,
+                                       const float* HN, float* partials, int64_t n_partials, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX, "bi_interaction_bwd_weight: bad row count");
+  KGAT_CHECK_ARG(n_partials == kgat_bi_interaction_bwd_weight_partials(n_rows),
+                 "bi_interaction_bwd_weight: n_partials must be kgat_bi_interaction_bwd_weight_partials(n_rows)");
+  KGAT_CHECK_ARG(partials != nullptr && (n_rows == 0 || (grad_z && H && HN)), "bi_interaction_bwd_weight: null pointer");
+  if (!kgat_bi_interaction_bwd_input_supported(d_in, d_out)) {
+    set_error("bi_interaction_bwd_weight: unsupported widths %d -> %d", d_in, d_out);
+    return KGAT_E_UNSUPPORTED;
+  }
+#define KGAT_BWW_CASE(DO_, DI_)                                                                                        \
+  if (d_out == DO_ && d_in == DI_) {                                                                                  \
+    hipLaunchKernelGGL((bi_bwd_weight_kernel<DO_, DI_>), dim3((unsigned)n_partials), dim3(256), 0, as_stream(stream), \
+                       (int32_t)n_rows, grad_z, H, HN, partials);                                                     \
+    KGAT_CHECK_LAUNCH("bi_bwd_weight");                                                                               \
+    return KGAT_OK;                                                                                                   \
+  }
+  KGAT_BWW_CASE(16, 16) KGAT_BWW_CASE(16, 32) KGAT_BWW_CASE(16, 64) KGAT_BWW_CASE(16, 128)
+  KGAT_BWW_CASE(32, 16) KGAT_BWW_CASE(32, 32) KGAT_BWW_CASE(32, 64) KGAT_BWW_CASE(32, 128)
+  KGAT_BWW_CASE(64, 16) KGAT_BWW_CASE(64, 32) KGAT_BWW_CASE(64, 64) KGAT_BWW_CASE(64, 128)
+  KGAT_BWW_CASE(128, 16) KGAT_BWW_CASE(128, 32) KGAT_BWW_CASE(128, 64) KGAT_BWW_CASE(128, 128)
+#undef KGAT_BWW_CASE
+  set_error("bi_interaction_bwd_weight: unsupported widths %d -> %d", d_in, d_out);
   return KGAT_E_UNSUPPORTED;
 }
 

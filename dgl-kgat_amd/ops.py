@@ -687,6 +687,24 @@ def bi_interaction_bwd_input(grad_z, W2, H, HN):
     return t, gb
 
 
+def bi_interaction_bwd_weight(grad_z, H, HN):
+    """grad_W2 = grad_z^T (H * HN) (kgat_bi_interaction_bwd_weight_f32: per-workgroup partials over 64-row slabs, the
+    product formed on the way; the partials are added here in index order)."""
+    grad_z = _need(grad_z, torch.float32, "grad_z")
+    n, d_out = grad_z.shape
+    H = _need(H, torch.float32, "H")
+    d_in = H.shape[1]
+    HN = _need(HN, torch.float32, "HN", (n, d_in))
+    if H.shape[0] != n:
+        raise ValueError("H has %d rows, grad_z %d" % (H.shape[0], n))
+    lib = _lib.load()
+    nb = int(lib.kgat_bi_interaction_bwd_weight_partials(n))
+    partials = torch.empty((nb, d_out, d_in), dtype=torch.float32, device=H.device)
+    check(lib.kgat_bi_interaction_bwd_weight_f32(n, d_in, d_out, _ptr(grad_z), _ptr(H), _ptr(HN), _ptr(partials), nb,
+                                                 _stream(H)), "kgat_bi_interaction_bwd_weight_f32")
+    return partials.sum(0)
+
+
 def mul2(a, b, c):
     """(a * b, a * c) in one pass."""
     a = _need(a, torch.float32, "a")
@@ -774,6 +792,6 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]

@@ -490,7 +490,10 @@ class _ShardConv(torch.autograd.Function):
             gz = ops.bi_interaction_bwd_pre(z, g_loc, None, None, ctx.slope, ctx.drop_p, ctx.seed, row0=lo)
             h_loc = h[lo:hi]
             if need_w:
-                gw = tall_weight_grad(gz, h_loc * hn)
+                if ops.bi_interaction_bwd_input_supported(d_in, gz.shape[1]):
+                    gw = ops.bi_interaction_bwd_weight(gz, h_loc, hn)
+                else:
+                    gw = tall_weight_grad(gz, h_loc * hn)
             if need_h:
                 # grad_P * h (aggregated back to the sources), grad_P * h_N
                 if ops.bi_interaction_bwd_input_supported(w.shape[1], w.shape[0]):

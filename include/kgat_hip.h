@@ -416,6 +416,13 @@ int kgat_bi_interaction_bwd_input_supported(int d_in, int d_out);
 int kgat_bi_interaction_bwd_input_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* W2,
                                       const float* H, const float* HN, float* grad_hn_times_h, float* grad_h_direct,
                                       kgat_stream_t stream);
+/* grad_W2 = grad_z^T (H * HN) (d_out x d_in; reference models.py:66's res_fc_2 under autograd) as per-workgroup
+ * partial sums: partials[b] (b < n_partials = kgat_bi_interaction_bwd_weight_partials(n_rows), each d_out x d_in row-major)
+ * is the product over the 64-row slabs b, b + n_partials, ...; the caller adds the partials up (any fixed order:
+ * reproducible).  The product H * HN is formed on the way and never written.  Widths as kgat_bi_interaction_bwd_input. */
+int64_t kgat_bi_interaction_bwd_weight_partials(int64_t n_rows);
+int kgat_bi_interaction_bwd_weight_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* H,
+                                       const float* HN, float* partials, int64_t n_partials, kgat_stream_t stream);
 /* ab = a * b and ac = a * c elementwise in one pass (n a multiple of 4). */
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
                   kgat_stream_t stream);

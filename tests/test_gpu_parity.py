@@ -1037,6 +1037,28 @@ def test_bi_interaction_bwd_input_vs_fp64(K, dev, d_in, d_out):
                                      torch.randn(5, 64, device=dev), torch.randn(5, 64, device=dev))
 
 
+@pytest.mark.parametrize("d_in,d_out", [(64, 64), (64, 32), (32, 16), (128, 128), (16, 128), (128, 16), (16, 16)])
+def test_bi_interaction_bwd_weight_vs_fp64(K, dev, d_in, d_out):
+    """kgat_bi_interaction_bwd_weight_f32 - grad_W2 = grad_z^T (H * HN), reduced over all rows through per-workgroup
+    partials - against the fp64 product, relative to sum |grad_z| |H HN| per element; row counts around the 64-row
+    slab, one slab per workgroup and many; twice the same bits."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(140 + d_in + d_out)
+    for n in (1, 63, 64, 65, 4001, 159251):
+        gz = rng.standard_normal((n, d_out)).astype(np.float32)
+        H = rng.standard_normal((n, d_in)).astype(np.float32)
+        HN = rng.standard_normal((n, d_in)).astype(np.float32)
+        gw = ops.bi_interaction_bwd_weight(tf(gz, dev), tf(H, dev), tf(HN, dev))
+        assert tuple(gw.shape) == (d_out, d_in)
+        P = H.astype(np.float64) * HN.astype(np.float64)
+        ref = gz.astype(np.float64).T @ P
+        bound = np.abs(gz).astype(np.float64).T @ np.abs(P)
+        err = np.abs(gw.cpu().numpy().astype(np.float64) - ref)
+        # (fp32 products of fp32 values, fp32 accumulation over n terms in blocks: a few ulp of the absolute sum)
+        assert np.all(err <= 2e-6 * bound + 1e-30), (n, float((err / (bound + 1e-30)).max()))
+        assert torch.equal(gw, ops.bi_interaction_bwd_weight(tf(gz, dev), tf(H, dev), tf(HN, dev)))
+
+
 def test_autograd_matches_oracle(K, dev):
     from dgl_kgat_amd import synth
     from dgl_kgat_amd.autograd import edge_softmax, u_mul_e_sum
