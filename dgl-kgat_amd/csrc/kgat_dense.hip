@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void bi_bwd_weight_kernel(int32_t n_rows, cons
     }
     __syncthreads();
     if (slab + (int32_t)gridDim.x < n_slabs) request(slab + gridDim.x);  // in flight while this slab is multiplied
-    if (w * 1 < TT) {
+    if (w < TT) {  // (narrow results have fewer tiles than wavefronts)
 #pragma unroll 4
       for (int r0 = 0; r0 < SLAB; r0 += 4) {
 #pragma unroll
