@@ -88,8 +88,9 @@ struct EgoCopy {
 // KGAT_SPMM_DEFER_FINISH - its second launch (kgat_spmm_impl.h: spmm_finish_kernel) did not run, so the rows that
 // are the first or the last row of one of its edge tiles, and the rows without in-edges, are not in HN: this
 // kernel forms them on the way, from the row offsets and the tiles' boundary partials in the aggregation's
-// workspace, in the finish launch's order of additions (same bits).  A dependent launch costs its ~2 us boundary
-// plus a pass over 2 x tiles items: 4.4 us per layer on the benchmark graph (scripts/micro/step_ab.py).
+// workspace, in the finish launch's order of additions (same bits).  Stand-alone the second launch costs the
+// aggregation 5-6 us and forming its rows costs this kernel 2.5-3.4 (profiles/r04_defer_probe.txt); in the step the pair
+// saves 7 us of the 13 the three launches cost (profiles/r04_deferred_finish_step_ab.txt).
 // (Requesting a chain's first follower in the load step as well - one stage instead of two at d_in >= 64 for the
 // registers - changes nothing: 0.4093 vs 0.4088 ms per step.)
 struct DeferredRows {
