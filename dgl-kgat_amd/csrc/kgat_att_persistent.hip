@@ -1092,11 +1092,12 @@ constexpr int kFusedThreads = 512;
 #ifndef KGAT_ATT128_XCD_REMAP
 #define KGAT_ATT128_XCD_REMAP 0
 #endif
-// The packed position records (4 bytes per edge, read once per step) as non-temporal loads: they no longer displace
-// the embedding table and the layer rows from the Infinity Cache - step 0.4178 -> 0.4153 ms
-// (profiles/r04_step_ab_cache_policy.txt).  Bit 2 (A/B arm): the head-group node ids too.
+// KGAT_ATT_REC_NT (A/B arm, bit 1: the packed position records - 4 bytes per edge, read once per step - as
+// non-temporal loads; bit 2: the head-group node ids too).  With round-robin tile ranges bit 1 gained 2.5 us per step
+// (0.4178 -> 0.4153 ms); with the XCD-contiguous ranges above it LOSES 1.2-1.6 us (0.4108 vs 0.4096, 0.4121 vs
+// 0.4105: profiles/r04_step_ab_cache_policy.txt) - off.
 #ifndef KGAT_ATT_REC_NT
-#define KGAT_ATT_REC_NT 1
+#define KGAT_ATT_REC_NT 0
 #endif
 
 
