@@ -908,7 +908,7 @@ def test_bi_interaction_mul_same_bits_as_the_spmm_epilogue(K, dev, d_in, d_out):
 
 
 DEFER_GRAPHS = [  # (n, e, hub, isolated tail)
-    (1, 5, 0, 0), (17, 100, 0, 3), (300, 5000, 0, 40), (500, 20000, 9000, 100), (64, 7000, 7000, 0),
+    (5, 0, 0, 0), (1, 5, 0, 0), (17, 100, 0, 3), (300, 5000, 0, 40), (500, 20000, 9000, 100), (64, 7000, 7000, 0),
     (5000, 60000, 30000, 500), (40000, 2500000, 150000, 1000),
 ]
 
