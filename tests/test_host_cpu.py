@@ -33,6 +33,14 @@ def test_abi_library_exports_every_declared_symbol():
     assert b"spmm" in lib.kgat_last_error()
     assert lib.kgat_csr_from_coo_workspace_bytes(10, 1000) > 3 * 4000
     assert lib.kgat_spmm_workspace_bytes(3663302, 64) > 0
+    # host-only queries of the round-4 entries
+    assert lib.kgat_spmm_tile_edges(3663302, 64) == 1024 and lib.kgat_spmm_tile_edges(1000, 64) == 256
+    assert lib.kgat_spmm_tile_edges(1000, 8) == 0
+    assert lib.kgat_bi_interaction_bwd_input_supported(64, 32) == 1 and lib.kgat_bi_interaction_bwd_input_supported(8, 8) == 0
+    assert lib.kgat_bi_interaction_bwd_weight_partials(159251) == 768 and lib.kgat_bi_interaction_bwd_weight_partials(1) == 1
+    # the binding stub of INTEGRATION.md states the version it was written against
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "lib.kgat_version() == %d" % _lib.ABI_VERSION in doc
 
 
 def test_no_oracle_import_in_product():
