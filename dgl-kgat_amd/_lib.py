@@ -22,6 +22,7 @@ SOURCES = {
     "kgat_att_persistent.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "kgat_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "kgat_transr.hip": [],
+    "kgat_eval.hip": [],
 }
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "kgat_hip.h")
 
@@ -94,6 +95,12 @@ SIGNATURES = {
     "kgat_gather_probe_f32": (_i32, [_i64, _i32, _p, _p, _p, _p]),
     "kgat_gather_f32": (_i32, [_i64, _p, _p, _p, _p]),
     "kgat_gather_i32": (_i32, [_i64, _p, _p, _p, _p]),
+    "kgat_eval_supported": (_i32, [_i32, _i32]),
+    "kgat_eval_items_elems": (_i64, [_i64, _i32]),
+    "kgat_eval_items_kmajor_f32": (_i32, [_i64, _i32, _p, _i64, _p, _p, _p]),
+    "kgat_eval_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "kgat_eval_recall_ndcg_f32": (_i32, [_i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _sz, _p,
+                                         _p, _p, _p]),
 }
 
 _lib = None
@@ -112,7 +119,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def source_hash():

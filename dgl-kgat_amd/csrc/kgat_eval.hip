@@ -1,0 +1,392 @@
+// Evaluation of the reference's metric.py:36-68 (calc_recall_ndcg) for gfx950: per test user the scores
+// against every item (metric.py:48), the training items' scores set to 0.0 (:50), the K best of a
+// descending sort (:51-59, ties: lower item position first, as a stable sort gives), then recall@K
+// (:5-7) and ndcg@K against the user's OWN sorted hit list (:23-34).  SURVEY.md 8f #4.
+//
+// Three launches, no (users x items) score matrix in memory:
+//  1. eval_items_kmajor_kernel: the item rows as MFMA A fragments, [32-item tile][k pair][lane] - one
+//     coalesced 256-byte load per v_mfma_f32_32x32x2_f32 later.
+//  2. eval_topk_kernel: a wavefront owns 32 users (the B operand: their rows, kept in LDS for the whole
+//     launch) and a contiguous segment of item tiles; scores come out of the fp32 MFMA (an exact
+//     k-ordered fmaf chain, 157 TF peak: 620 GFLOP on the amazon-book shape) with the USER on the lane,
+//     so a lane compares its 16 scores of a tile with its user's current K-th best and only the rare
+//     survivors (about K ln(n / K) per user over the whole sweep) are appended to the user's candidate
+//     buffer in LDS.  A full buffer is pruned by the whole wavefront: entries that are training items
+//     are dropped (binary search in the user's sorted list), a 64-lane bitonic sort on (score
+//     descending, position ascending) keeps the K best and renews the threshold.
+//  3. eval_merge_kernel: one wavefront per user merges the segments' partial lists with the masked
+//     training items - min(K, |train_u|) entries (0.0, lowest positions), which is all of them that can
+//     rank - marks the hits (binary search in the sorted test list) and writes recall and ndcg in fp64.
+//
+// The order is total - (score descending, position ascending) - so the result does not depend on how
+// items were cut into tiles and segments: bitwise reproducible, equal to a stable descending sort.
+#include "kgat_common.h"
+
+namespace kgat {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kEvalCap = 64;      // candidate entries per user (K <= 32 kept + 32 a tile can add)
+constexpr int kEvalMaxK = 32;
+constexpr int kEvalTile = 32;     // items per MFMA tile
+constexpr int kEvalNT = 2;        // item tiles in flight per wavefront
+constexpr float kNegInf = -__builtin_inff();
+constexpr int kIdxPad = 0x7fffffff;
+
+__global__ __launch_bounds__(256) void eval_items_kmajor_kernel(int64_t n_items, int F, int FP2, int64_t n_tiles,
+                                                                const float* __restrict__ emb, int64_t emb_stride,
+                                                                const int32_t* __restrict__ item_ids,
+                                                                float* __restrict__ itemT) {
+  // one thread per (tile, k pair, lane): coalesced stores, gathered 4-byte loads (a 17 MB one-off per call)
+  const int64_t total = n_tiles * FP2 * 64;
+  for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(x & 63);
+    const int64_t ts = x >> 6;
+    const int s = (int)(ts % FP2);
+    const int64_t tile = ts / FP2;
+    const int64_t it = tile * kEvalTile + (lane & 31);
+    const int k = 2 * s + (lane >> 5);
+    float v = 0.f;
+    if (it < n_items && k < F) v = emb[(size_t)item_ids[it] * emb_stride + k];
+    itemT[x] = v;
+  }
+}
+
+// "a ranks before b": score descending, position ascending
+__device__ __forceinline__ bool ranks_before(float sa, int ia, float sb, int ib) {
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+// Descending bitonic sort of one (score, position) entry per lane over the wavefront.
+__device__ __forceinline__ void wave_sort_desc(float& s, int& i, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float so = __shfl_xor(s, j, 64);
+      const int io = __shfl_xor(i, j, 64);
+      const bool lower = (lane & j) == 0;          // this lane is the lower index of its pair
+      const bool desc = (lane & k) == 0;           // this block sorts descending (final k = 64: every lane)
+      const bool mine_first = ranks_before(s, i, so, io);
+      // the lower lane of a descending pair keeps the entry that ranks first
+      const bool keep = (lower == desc) ? mine_first : !mine_first;
+      s = keep ? s : so;
+      i = keep ? i : io;
+    }
+  }
+}
+
+// position `it` in the ascending list a[lo, hi)?
+__device__ __forceinline__ bool in_sorted(const int32_t* __restrict__ a, int32_t lo, int32_t hi, int32_t it) {
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    const int32_t v = a[mid];
+    if (v == it) return true;
+    if (v < it) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+struct EvalLds {
+  // per wavefront: cand_s / cand_i [32 users][kEvalCap], cnt / kept [32]; then the users' rows [FP2][64]
+  static __host__ __device__ size_t per_wave_bytes(int FP2) {
+    return (size_t)32 * kEvalCap * 8 + 32 * 4 * 2 + (size_t)FP2 * 64 * 4;
+  }
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
+    int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t n_tiles,
+    int n_seg, const float* __restrict__ emb, int64_t emb_stride, const float* __restrict__ itemT,
+    const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items, int K,
+    float* __restrict__ part_s, int32_t* __restrict__ part_i) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ul = lane & 31, half = lane >> 5;
+  char* base = s_raw + (size_t)w * EvalLds::per_wave_bytes(FP2);
+  float* cand_s = reinterpret_cast<float*>(base);
+  int32_t* cand_i = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 4);
+  int32_t* cnt = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 8);
+  int32_t* kept = cnt + 32;                                    // entries already known not to be training items
+  float* ub = reinterpret_cast<float*>(base + 32 * kEvalCap * 8 + 256);
+
+  const int64_t u0 = ((int64_t)blockIdx.x * NW + w) * 32;      // the wavefront's 32 users (positions in user_ids)
+  const int seg = blockIdx.y;
+  if (u0 >= n_users) return;                                   // (no workgroup barrier anywhere below)
+  const int64_t up = u0 + ul;
+  const bool u_ok = up < n_users;
+  const int64_t up_c = u_ok ? up : n_users - 1;
+  // B fragments: lane (user ul, half) holds the user's elements k = 2s + half
+  {
+    const float* row = emb + (size_t)user_ids[up_c] * emb_stride;
+    for (int s = 0; s < FP2; ++s) {
+      const int k = 2 * s + half;
+      ub[s * 64 + lane] = (u_ok && k < F) ? row[k] : 0.f;
+    }
+  }
+  if (lane < 32) { cnt[lane] = 0; kept[lane] = 0; }
+  const int32_t tr_lo = train_ptr[up_c], tr_hi = train_ptr[up_c + 1];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // the segment's tiles: an even split of the tile range
+  const int64_t t_lo = n_tiles * seg / n_seg, t_hi = n_tiles * (seg + 1) / n_seg;
+  float tau_s = kNegInf;  // the user's K-th best so far (score, position); -inf while fewer than K are held
+  int tau_i = kIdxPad;
+
+  // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.
+  auto prune = [&](int v) {
+    const int n = cnt[v], kp = kept[v];
+    float s = kNegInf;
+    int i = kIdxPad;
+    if (lane < n) { s = cand_s[v * kEvalCap + lane]; i = cand_i[v * kEvalCap + lane]; }
+    const int32_t lo = __shfl(tr_lo, v, 64), hi = __shfl(tr_hi, v, 64);
+    if (lane >= kp && lane < n && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
+    wave_sort_desc(s, i, lane);
+    const int valid = __popcll(__ballot(i != kIdxPad));
+    const int keep = valid < K ? valid : K;
+    if (lane < keep) { cand_s[v * kEvalCap + lane] = s; cand_i[v * kEvalCap + lane] = i; }
+    const float ts = __shfl(s, K - 1, 64);
+    const int ti = __shfl(i, K - 1, 64);
+    if (ul == v) {  // both lanes of the user
+      tau_s = keep == K ? ts : kNegInf;
+      tau_i = keep == K ? ti : kIdxPad;
+    }
+    if (lane == 0) { cnt[v] = keep; kept[v] = keep; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // A fragments: one coalesced 4-byte load per lane per MFMA, requested one group of U k pairs ahead (across
+  // tile groups too) - a wavefront has U * NT loads in flight while it issues the previous group's MFMAs
+  constexpr int U = 8;
+  const float* a_base = itemT + lane;
+  auto load_group = [&](float (&a)[U][kEvalNT], int64_t t0, int s) {
+#pragma unroll
+    for (int t = 0; t < kEvalNT; ++t) {
+      const int64_t tt = t0 + t < t_hi ? t0 + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
+      const float* ap = a_base + ((size_t)tt * FP2 + s) * 64;
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u][t] = ap[u * 64];
+    }
+  };
+  float a_next[U][kEvalNT];
+  if (t_lo < t_hi) load_group(a_next, t_lo, 0);
+  for (int64_t t0 = t_lo; t0 < t_hi; t0 += kEvalNT) {
+    floatx16 acc[kEvalNT];
+#pragma unroll
+    for (int t = 0; t < kEvalNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int s = 0; s < FP2; s += U) {  // FP2 is a multiple of U (zero padded)
+      float a[U][kEvalNT], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < kEvalNT; ++t) a[u][t] = a_next[u][t];
+      const bool last = s + U >= FP2;
+      const int64_t tn = last ? t0 + kEvalNT : t0;
+      if (tn < t_hi) load_group(a_next, tn, last ? 0 : s + U);
+#pragma unroll
+      for (int u = 0; u < U; ++u) b[u] = ub[(s + u) * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < kEvalNT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+    }
+    // acc[t][r]: user ul, item position 32 (t0 + t) + (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+    for (int t = 0; t < kEvalNT; ++t) {
+      if (t0 + t >= t_hi) break;  // wave-uniform
+      float m = acc[t][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
+      if (__ballot(u_ok && m >= tau_s) != 0ull) {
+        const int ib = (int)((t0 + t) * kEvalTile) + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sc = acc[t][r];
+          const int it = ib + (r & 3) + 8 * (r >> 2);
+          if (u_ok && sc >= tau_s && it < n_items && (sc > tau_s || it < tau_i)) {
+            const int slot = atomicAdd(&cnt[ul], 1);  // < kEvalCap: at most 32 per tile on top of <= 32 held
+            cand_s[ul * kEvalCap + slot] = sc;
+            cand_i[ul * kEvalCap + slot] = it;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long need = __ballot(half == 0 && cnt[ul] > kEvalCap - kEvalTile);
+        while (need) {
+          const int v = __builtin_ctzll(need);
+          need &= need - 1;
+          prune(v);
+        }
+      }
+    }
+  }
+  // the segment's list of every user: K entries, padded with (-inf, pad)
+  for (int v = 0; v < 32; ++v) {
+    if (u0 + v >= n_users) break;
+    prune(v);
+    const int n = cnt[v];
+    if (lane < K) {
+      const size_t o = ((size_t)(u0 + v) * n_seg + seg) * K + lane;
+      part_s[o] = lane < n ? cand_s[v * kEvalCap + lane] : kNegInf;
+      part_i[o] = lane < n ? cand_i[v * kEvalCap + lane] : kIdxPad;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void eval_merge_kernel(
+    int64_t n_users, int n_seg, int K, const float* __restrict__ part_s, const int32_t* __restrict__ part_i,
+    const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items,
+    const int32_t* __restrict__ test_ptr, const int32_t* __restrict__ test_items, const double* __restrict__ disc,
+    double* __restrict__ recall, double* __restrict__ ndcg, int32_t* __restrict__ topk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_users) return;
+  float s = kNegInf;
+  int i = kIdxPad;
+  // the masked training items (metric.py:50): score 0.0; only the K lowest positions can rank
+  const int32_t tr_lo = train_ptr[u], tr_hi = train_ptr[u + 1];
+  if (lane < K && tr_lo + lane < tr_hi) { s = 0.f; i = train_items[tr_lo + lane]; }
+  for (int g = 0; g < n_seg; ++g) {
+    if (lane >= 32 && lane - 32 < K) {
+      const size_t o = ((size_t)u * n_seg + g) * K + (lane - 32);
+      s = part_s[o];
+      i = part_i[o];
+    }
+    wave_sort_desc(s, i, lane);  // the K best so far in lanes [0, K), K <= 32
+  }
+  if (n_seg == 0) wave_sort_desc(s, i, lane);
+  const int32_t te_lo = test_ptr[u], te_hi = test_ptr[u + 1];
+  const bool hit = lane < K && i != kIdxPad && in_sorted(test_items, te_lo, te_hi, i);
+  const unsigned long long hits = __ballot(hit);
+  if (topk && lane < K) topk[(size_t)u * K + lane] = i == kIdxPad ? -1 : i;
+  if (lane == 0) {
+    const int nh = __popcll(hits);
+    const int n_pos = te_hi - te_lo;
+    double dcg = 0.0, ideal = 0.0;
+    for (int k = 0; k < K; ++k)
+      if (hits >> k & 1ull) dcg += disc[k];
+    for (int k = 0; k < nh; ++k) ideal += disc[k];
+    recall[u] = n_pos > 0 ? (double)nh / (double)n_pos : 0.0;
+    ndcg[u] = ideal > 0.0 ? dcg / ideal : 0.0;
+  }
+}
+
+// k pairs of a row, padded with zeros to the unroll of the MFMA loop
+static int eval_fp2(int F) { return ((F + 1) / 2 + 7) / 8 * 8; }
+
+static int eval_waves_per_block(int FP2) {
+  // the largest workgroup whose wavefronts' LDS (candidates + the users' rows) fits a CU
+  for (int nw = 4; nw >= 1; nw >>= 1)
+    if (EvalLds::per_wave_bytes(FP2) * nw <= (size_t)160 * 1024) return nw;
+  return 0;
+}
+
+static int eval_segments(int64_t n_users, int64_t n_tiles, int nw) {
+  const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
+  const int64_t want = (int64_t)device_cu_count() * 8;       // ~8 workgroups per CU: a smooth tail
+  int64_t seg = (want + blocks - 1) / (blocks > 0 ? blocks : 1);
+  const int64_t max_seg = n_tiles / 16 > 0 ? n_tiles / 16 : 1;  // at least 16 tiles (512 items) per segment
+  if (seg > max_seg) seg = max_seg;
+  if (seg > 64) seg = 64;
+  if (seg < 1) seg = 1;
+  return (int)seg;
+}
+
+}  // namespace kgat
+
+using namespace kgat;
+
+extern "C" {
+
+int kgat_eval_supported(int F, int K) {
+  const int FP2 = eval_fp2(F);
+  return F >= 1 && K >= 1 && K <= kEvalMaxK && eval_waves_per_block(FP2) > 0;
+}
+
+int64_t kgat_eval_items_elems(int64_t n_items, int F) {
+  if (n_items < 0 || F < 1) return 0;
+  const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
+  return n_tiles * eval_fp2(F) * 64;
+}
+
+int kgat_eval_items_kmajor_f32(int64_t n_items, int F, const float* emb, int64_t emb_stride, const int32_t* item_ids,
+                               float* itemT, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_items >= 0 && F >= 1 && emb_stride >= F, "eval_items_kmajor: bad sizes");
+  if (n_items == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(emb && item_ids && itemT, "eval_items_kmajor: null pointer");
+  const int FP2 = eval_fp2(F);
+  const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
+  const int64_t total = n_tiles * FP2 * 64;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 65536) grid = 65536;
+  hipLaunchKernelGGL(eval_items_kmajor_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), n_items, F, FP2,
+                     n_tiles, emb, emb_stride, item_ids, itemT);
+  KGAT_CHECK_LAUNCH("eval_items_kmajor");
+  return KGAT_OK;
+}
+
+size_t kgat_eval_workspace_bytes(int64_t n_users, int64_t n_items, int F, int K) {
+  if (n_users <= 0 || n_items <= 0 || !kgat_eval_supported(F, K)) return 256;
+  const int nw = eval_waves_per_block(eval_fp2(F));
+  const int seg = eval_segments(n_users, (n_items + kEvalTile - 1) / kEvalTile, nw);
+  return 2 * align_up((size_t)n_users * seg * K * 4, 256) + 256;
+}
+
+int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t n_items, int F, const float* emb,
+                              int64_t emb_stride, const float* itemT, const int32_t* train_ptr,
+                              const int32_t* train_items, const int32_t* test_ptr, const int32_t* test_items, int K,
+                              const double* disc, void* workspace, size_t workspace_bytes, double* recall_out,
+                              double* ndcg_out, int32_t* topk_out, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_users >= 0 && n_items >= 0 && F >= 1 && emb_stride >= F, "eval_recall_ndcg: bad sizes");
+  if (!kgat_eval_supported(F, K)) {
+    set_error("eval_recall_ndcg: K = %d (1..%d) or F = %d not supported", K, kEvalMaxK, F);
+    return KGAT_E_UNSUPPORTED;
+  }
+  if (n_users == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(n_items >= K, "eval_recall_ndcg: fewer items (%lld) than K (%d): the reference indexes rank K - 1",
+                 (long long)n_items, K);
+  KGAT_CHECK_ARG(user_ids && emb && itemT && train_ptr && test_ptr && disc && recall_out && ndcg_out && workspace,
+                 "eval_recall_ndcg: null pointer");
+  if (workspace_bytes < kgat_eval_workspace_bytes(n_users, n_items, F, K)) {
+    set_error("eval_recall_ndcg: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  const int FP2 = eval_fp2(F);
+  const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
+  const int nw = eval_waves_per_block(FP2);
+  const int seg = eval_segments(n_users, n_tiles, nw);
+  Carver cv(workspace);
+  float* part_s = cv.take<float>((size_t)n_users * seg * K);
+  int32_t* part_i = cv.take<int32_t>((size_t)n_users * seg * K);
+  const size_t lds = EvalLds::per_wave_bytes(FP2) * nw;
+  const dim3 grid((unsigned)((n_users + 32 * nw - 1) / (32 * nw)), (unsigned)seg);
+  hipStream_t st = as_stream(stream);
+#define KGAT_EVAL_LAUNCH(NW)                                                                                          \
+  do {                                                                                                                \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(eval_topk_kernel<NW>),                                      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                    \
+      set_error("eval_recall_ndcg: cannot reserve %zu bytes of LDS", lds);                                            \
+      return KGAT_E_HIP;                                                                                              \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((eval_topk_kernel<NW>), grid, dim3(NW * 64), lds, st, n_users, user_ids, n_items, FP2, F,      \
+                       n_tiles, seg, emb, emb_stride, itemT, train_ptr, train_items, K, part_s, part_i);             \
+  } while (0)
+  if (nw == 4) KGAT_EVAL_LAUNCH(4);
+  else if (nw == 2) KGAT_EVAL_LAUNCH(2);
+  else KGAT_EVAL_LAUNCH(1);
+#undef KGAT_EVAL_LAUNCH
+  KGAT_CHECK_LAUNCH("eval_topk");
+  hipLaunchKernelGGL(eval_merge_kernel, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, n_users, seg, K,
+                     part_s, part_i, train_ptr, train_items, test_ptr, test_items, disc, recall_out, ndcg_out,
+                     topk_out);
+  KGAT_CHECK_LAUNCH("eval_merge");
+  return KGAT_OK;
+}
+
+}  // extern "C"

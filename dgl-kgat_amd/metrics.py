@@ -1,19 +1,92 @@
-"""recall@K / ndcg@K of the reference (``metric.py:36-68``), batched on the device.
+"""recall@K / ndcg@K of the reference (``metric.py:36-68``) on the device.
 
 Same definitions, including the reference's quirks: training items are masked by setting their
 score to 0.0 (not -inf), and the ideal DCG of a user is the DCG of that user's *own* hit list
-sorted (``one_ndcg_at_k``), not the DCG of min(|positives|, K) leading ones.  Users are scored
-in batches with one matmul + one stable descending sort per batch instead of one sort per user
-(the reference's ``th.sort`` is stable on the CPU: among equal scores - the masked zeros - the
-lower item index ranks first; a top-K primitive would break such ties its own way).
+sorted (``one_ndcg_at_k``), not the DCG of min(|positives|, K) leading ones.
+
+``calc_recall_ndcg`` runs ``kgat_eval_recall_ndcg_f32`` (csrc/kgat_eval.hip): the user x item
+scores come out of the fp32 MFMA tile by tile and go straight into a running top-K per user -
+no (users x items) score matrix, no sort of 24,915 scores per user.  Equal scores rank by item
+position (what the reference's stable CPU ``th.sort`` gives: among the masked zeros the lower
+index first).  ``calc_recall_ndcg_sorted`` is the batched matmul + full stable sort of rounds
+1-4, kept as an independent check of the kernel (tests) and for K > 32.
 """
 import numpy as np
 import torch
 
 
-def calc_recall_ndcg(embedding, train_user_dict, test_user_dict, all_item_id_range, K=20, batch_users=2048):
-    """``embedding`` (N, F) node embeddings; the dicts map a user id to the array of its (raw,
-    un-shifted) item ids; ``all_item_id_range`` the node ids of the items."""
+class EvalPlan:
+    """The static part of an evaluation: test users, item node ids and the users' train / test item lists as CSR
+    arrays on the device (positions ascending per user).  Build once per (train, test) split."""
+
+    def __init__(self, train_user_dict, test_user_dict, all_item_id_range, device):
+        users = list(test_user_dict.keys())
+        self.n_users = len(users)
+
+        def csr(d):
+            lists = [np.sort(np.asarray(d.get(u, ()), dtype=np.int64)) for u in users]
+            ptr = np.zeros(len(users) + 1, dtype=np.int64)
+            if lists:
+                np.cumsum([len(x) for x in lists], out=ptr[1:])
+            flat = np.concatenate(lists) if lists and ptr[-1] > 0 else np.zeros(0, dtype=np.int64)
+            if ptr[-1] >= 2 ** 31:
+                raise ValueError("more than 2^31 (user, item) pairs")
+            return (torch.as_tensor(ptr.astype(np.int32), device=device),
+                    torch.as_tensor(flat.astype(np.int32), device=device))
+
+        items = np.asarray(all_item_id_range, dtype=np.int64)
+        self.n_items = len(items)
+        for name, d in (("train", train_user_dict), ("test", test_user_dict)):
+            for u in users:
+                x = np.asarray(d.get(u, ()), dtype=np.int64)
+                if x.size and (x.min() < 0 or x.max() >= self.n_items):
+                    # (the reference would index `score` out of range, metric.py:50)
+                    raise IndexError("%s items of user %r outside [0, %d)" % (name, u, self.n_items))
+        self.user_ids = torch.as_tensor(np.asarray(users, dtype=np.int64).astype(np.int32), device=device)
+        self.item_ids = torch.as_tensor(items.astype(np.int32), device=device)
+        self.train_ptr, self.train_items = csr(train_user_dict)
+        self.test_ptr, self.test_items = csr(test_user_dict)
+        self.key = (id(train_user_dict), id(test_user_dict), len(train_user_dict), len(test_user_dict),
+                    self.n_items, str(device))
+
+
+_last_plan = None
+
+
+def _plan_for(train_user_dict, test_user_dict, all_item_id_range, device):
+    global _last_plan
+    key = (id(train_user_dict), id(test_user_dict), len(train_user_dict), len(test_user_dict),
+           len(all_item_id_range), str(device))
+    if _last_plan is None or _last_plan.key != key:
+        _last_plan = EvalPlan(train_user_dict, test_user_dict, all_item_id_range, device)
+    return _last_plan
+
+
+def calc_recall_ndcg(embedding, train_user_dict, test_user_dict, all_item_id_range, K=20, plan=None,
+                     return_per_user=False):
+    """``embedding`` (N, F) node embeddings on the HIP device; the dicts map a user id to the array of its (raw,
+    un-shifted) item ids; ``all_item_id_range`` the node ids of the items.  ``plan``: a prebuilt ``EvalPlan`` (the
+    last one built is reused while the same dict objects are passed)."""
+    from . import ops
+    if plan is None:
+        plan = _plan_for(train_user_dict, test_user_dict, all_item_id_range, embedding.device)
+    if plan.n_users == 0:
+        raise ZeroDivisionError("no test users")   # (metric.py:65 divides by len(test_user_dict))
+    emb = embedding.detach()
+    if emb.dtype != torch.float32:
+        emb = emb.float()
+    if emb.stride(1) != 1:
+        emb = emb.contiguous()
+    with torch.no_grad():
+        recall, ndcg = ops.eval_recall_ndcg(emb, plan.user_ids, plan.item_ids, plan.train_ptr, plan.train_items,
+                                            plan.test_ptr, plan.test_items, K)
+    if return_per_user:
+        return recall, ndcg
+    return float(recall.sum()) / plan.n_users, float(ndcg.sum()) / plan.n_users
+
+
+def calc_recall_ndcg_sorted(embedding, train_user_dict, test_user_dict, all_item_id_range, K=20, batch_users=2048):
+    """The same metric by one matmul + one stable descending sort per user batch (torch operators; rounds 1-4)."""
     dev = embedding.device
     items = torch.as_tensor(np.asarray(all_item_id_range), device=dev, dtype=torch.long)
     item_emb = embedding.index_select(0, items).t().contiguous()

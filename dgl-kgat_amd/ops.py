@@ -795,3 +795,47 @@ __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order
            "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]
+
+
+def eval_supported(F, K):
+    return bool(_lib.load().kgat_eval_supported(int(F), int(K)))
+
+
+def eval_recall_ndcg(emb, user_ids, item_ids, train_ptr, train_items, test_ptr, test_items, K, want_topk=False):
+    """recall@K / ndcg@K per test user (reference metric.py:36-68) on the device: kgat_eval_items_kmajor_f32 +
+    kgat_eval_recall_ndcg_f32.  `emb` (N, F) fp32 rows (row stride = emb.stride(0)); user_ids / item_ids int32 node
+    ids; the CSR lists hold item POSITIONS (ascending per user).  Returns (recall, ndcg[, topk]) - float64 (n_users,)
+    and int32 (n_users, K)."""
+    if emb.dtype != torch.float32 or not emb.is_cuda or emb.dim() != 2 or emb.stride(1) != 1:
+        raise KGATLibraryError("eval_recall_ndcg: `emb` must be a float32 HIP matrix with unit column stride")
+    F, stride = emb.shape[1], emb.stride(0)
+    user_ids = _need(user_ids, torch.int32, "user_ids")
+    item_ids = _need(item_ids, torch.int32, "item_ids")
+    n_users, n_items = user_ids.numel(), item_ids.numel()
+    train_ptr = _need(train_ptr, torch.int32, "train_ptr", (n_users + 1,))
+    test_ptr = _need(test_ptr, torch.int32, "test_ptr", (n_users + 1,))
+    train_items = _need(train_items, torch.int32, "train_items")
+    test_items = _need(test_items, torch.int32, "test_items")
+    lib = _lib.load()
+    if not lib.kgat_eval_supported(F, K):
+        raise KGATLibraryError("eval_recall_ndcg: K = %d / F = %d outside the kernel's range" % (K, F))
+    dev = emb.device
+    import numpy as np
+    disc = torch.as_tensor(1.0 / np.log2(np.arange(2, K + 2)), dtype=torch.float64, device=dev)
+    recall = torch.zeros(n_users, dtype=torch.float64, device=dev)
+    ndcg = torch.zeros(n_users, dtype=torch.float64, device=dev)
+    topk = torch.empty((n_users, K), dtype=torch.int32, device=dev) if want_topk else None
+    if n_users == 0:
+        return (recall, ndcg, topk) if want_topk else (recall, ndcg)
+    itemT = torch.empty(max(int(lib.kgat_eval_items_elems(n_items, F)), 1), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.kgat_eval_workspace_bytes(n_users, n_items, F, K), dtype=torch.uint8, device=dev)
+    with _timed("eval_items_kmajor", (n_items, F)):
+        check(lib.kgat_eval_items_kmajor_f32(n_items, F, _ptr(emb), stride, _ptr(item_ids), _ptr(itemT), _stream(emb)),
+              "kgat_eval_items_kmajor_f32")
+    with _timed("eval_recall_ndcg", (n_users, n_items, F, K)):
+        check(lib.kgat_eval_recall_ndcg_f32(n_users, _ptr(user_ids), n_items, F, _ptr(emb), stride, _ptr(itemT),
+                                            _ptr(train_ptr), _ptr(train_items), _ptr(test_ptr), _ptr(test_items), K,
+                                            _ptr(disc), _ptr(ws), ws.numel(), _ptr(recall), _ptr(ndcg),
+                                            _ptr(topk) if want_topk else None, _stream(emb)),
+              "kgat_eval_recall_ndcg_f32")
+    return (recall, ndcg, topk) if want_topk else (recall, ndcg)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 7
+#define KGAT_ABI_VERSION 8
 
 enum {
   KGAT_OK = 0,
@@ -445,6 +445,31 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
                               const float* W_R, const float* rel, float reg_lambda, float* loss, float* grad_ent,
                               float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
                               kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- evaluation
+ * recall@K / ndcg@K of reference metric.py:36-68 (calc_recall_ndcg with one_recall_at_k :5-7, one_dcg_at_k :8-22
+ * method 1, one_ndcg_at_k :23-34) for a list of test users, without a users x items score matrix:
+ *   score[u][i] = <emb[user_ids[u]], emb[item_ids[i]]>  (metric.py:48; v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains)
+ *   score[u][train items of u] = 0.0                     (metric.py:50 - set to 0.0, not removed)
+ *   rank = the K first of a descending sort              (metric.py:51; equal scores: lower item position first)
+ *   recall[u] = hits / |test items of u| (0 for an empty list), ndcg[u] = dcg / dcg of the user's own sorted hit list
+ * `emb` (rows of emb_stride floats, the first F used) holds users and items; an item's POSITION i in item_ids is what
+ * the train / test lists hold (the reference indexes `score` with the raw item ids of its dicts).  train_ptr /
+ * test_ptr [n_users + 1] + train_items / test_items: CSR over the users in user_ids order, every list ASCENDING.
+ * kgat_eval_items_kmajor_f32 first lays the item rows out as MFMA fragments (itemT: kgat_eval_items_elems floats).
+ * disc[K] = 1 / log2(k + 2) in fp64 (host-computed, so the device divides by the very values numpy uses).
+ * recall_out / ndcg_out: n_users doubles; topk_out (optional, n_users x K): the ranked item positions.
+ * Needs 1 <= K <= 32, n_items >= K, F <= ~1100 (kgat_eval_supported).  Bitwise reproducible. */
+int kgat_eval_supported(int F, int K);
+int64_t kgat_eval_items_elems(int64_t n_items, int F);
+int kgat_eval_items_kmajor_f32(int64_t n_items, int F, const float* emb, int64_t emb_stride, const int32_t* item_ids,
+                               float* itemT, kgat_stream_t stream);
+size_t kgat_eval_workspace_bytes(int64_t n_users, int64_t n_items, int F, int K);
+int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t n_items, int F, const float* emb,
+                              int64_t emb_stride, const float* itemT, const int32_t* train_ptr,
+                              const int32_t* train_items, const int32_t* test_ptr, const int32_t* test_items, int K,
+                              const double* disc, void* workspace, size_t workspace_bytes, double* recall_out,
+                              double* ndcg_out, int32_t* topk_out, kgat_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,12 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.kgat_spmm_tile_edges(1000, 8) == 0
     assert lib.kgat_bi_interaction_bwd_input_supported(64, 32) == 1 and lib.kgat_bi_interaction_bwd_input_supported(8, 8) == 0
     assert lib.kgat_bi_interaction_bwd_weight_partials(159251) == 768 and lib.kgat_bi_interaction_bwd_weight_partials(1) == 1
+    # host-only queries of the round-5 entries (evaluation)
+    assert lib.kgat_eval_supported(176, 20) == 1 and lib.kgat_eval_supported(176, 33) == 0 and lib.kgat_eval_supported(4000, 20) == 0
+    assert lib.kgat_eval_items_elems(24915, 176) == 779 * 88 * 64 and lib.kgat_eval_items_elems(0, 176) == 0
+    assert lib.kgat_eval_workspace_bytes(70679, 24915, 176, 20) >= 2 * 70679 * 20 * 4
+    assert lib.kgat_eval_recall_ndcg_f32(1, None, 10, 176, None, 176, None, None, None, None, None, 40, None, None, 0,
+                                         None, None, None, None) == -2 and b"eval" in lib.kgat_last_error()
     # the binding stub of INTEGRATION.md states the version it was written against
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "lib.kgat_version() == %d" % _lib.ABI_VERSION in doc
