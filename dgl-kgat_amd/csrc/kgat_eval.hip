@@ -26,7 +26,7 @@ namespace kgat {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kEvalCap = 64;      // candidate entries per user (K <= 32 kept + 32 a tile can add)
+constexpr int kEvalCap = 64;      // candidate entries per user (one per lane of the pruning wavefront)
 constexpr int kEvalMaxK = 32;
 constexpr int kEvalTile = 32;     // items per MFMA tile
 constexpr int kEvalNT = 2;        // item tiles in flight per wavefront
@@ -88,7 +88,7 @@ __device__ __forceinline__ bool in_sorted(const int32_t* __restrict__ a, int32_t
 }
 
 struct EvalLds {
-  // per wavefront: cand_s / cand_i [32 users][kEvalCap], cnt / kept [32]; then the users' rows [FP2][64]
+  // per wavefront: cand_s / cand_i [32 users][kEvalCap], kept [32]; then the users' rows [FP2][64]
   static __host__ __device__ size_t per_wave_bytes(int FP2) {
     return (size_t)32 * kEvalCap * 8 + 32 * 4 * 2 + (size_t)FP2 * 64 * 4;
   }
@@ -96,18 +96,17 @@ struct EvalLds {
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
-    int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t n_tiles,
-    int n_seg, const float* __restrict__ emb, int64_t emb_stride, const float* __restrict__ itemT,
-    const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items, int K,
-    float* __restrict__ part_s, int32_t* __restrict__ part_i) {
+    int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t tile_lo,
+    int64_t tile_hi, int n_lists, int list0, int use_tau0, const float* __restrict__ emb, int64_t emb_stride,
+    const float* __restrict__ itemT, const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items,
+    int K, float* __restrict__ part_s, int32_t* __restrict__ part_i) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ul = lane & 31, half = lane >> 5;
   char* base = s_raw + (size_t)w * EvalLds::per_wave_bytes(FP2);
   float* cand_s = reinterpret_cast<float*>(base);
   int32_t* cand_i = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 4);
-  int32_t* cnt = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 8);
-  int32_t* kept = cnt + 32;                                    // entries already known not to be training items
+  int32_t* kept = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 8);  // entries known not to be training items
   float* ub = reinterpret_cast<float*>(base + 32 * kEvalCap * 8 + 256);
 
   const int64_t u0 = ((int64_t)blockIdx.x * NW + w) * 32;      // the wavefront's 32 users (positions in user_ids)
@@ -124,78 +123,85 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
       ub[s * 64 + lane] = (u_ok && k < F) ? row[k] : 0.f;
     }
   }
-  if (lane < 32) { cnt[lane] = 0; kept[lane] = 0; }
+  if (lane < 32) kept[lane] = 0;
   const int32_t tr_lo = train_ptr[up_c], tr_hi = train_ptr[up_c + 1];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // the segment's tiles: an even split of the tile range
-  const int64_t t_lo = n_tiles * seg / n_seg, t_hi = n_tiles * (seg + 1) / n_seg;
+  // the segment's tiles: an even split of this launch's tile range over gridDim.y
+  const int n_seg = gridDim.y;
+  const int64_t t_lo = tile_lo + (tile_hi - tile_lo) * seg / n_seg, t_hi = tile_lo + (tile_hi - tile_lo) * (seg + 1) / n_seg;
   float tau_s = kNegInf;  // the user's K-th best so far (score, position); -inf while fewer than K are held
   int tau_i = kIdxPad;
+  if (use_tau0) {
+    // the K-th best of the sample launch's list (list 0; (-inf, pad) if it found fewer than K): at least K
+    // entries rank at or before it, so nothing that ranks after it can be among the user's K best
+    tau_s = part_s[((size_t)up_c * n_lists) * K + K - 1];
+    tau_i = part_i[((size_t)up_c * n_lists) * K + K - 1];
+  }
+  int c_mine = 0;         // entries in the user's buffer (the same value in both lanes of the user)
 
-  // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.
+  // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.  An entry's
+  // place is the number of entries that rank before it (the order is total): n broadcast compares per lane instead
+  // of a sorting network's 42 dependent cross-lane exchanges.
   auto prune = [&](int v) {
-    const int n = cnt[v], kp = kept[v];
+    const int n = __builtin_amdgcn_readlane(c_mine, v), kp = kept[v];
     float s = kNegInf;
     int i = kIdxPad;
     if (lane < n) { s = cand_s[v * kEvalCap + lane]; i = cand_i[v * kEvalCap + lane]; }
-    const int32_t lo = __shfl(tr_lo, v, 64), hi = __shfl(tr_hi, v, 64);
+    const int32_t lo = __builtin_amdgcn_readlane(tr_lo, v), hi = __builtin_amdgcn_readlane(tr_hi, v);
     if (lane >= kp && lane < n && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
-    wave_sort_desc(s, i, lane);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), j));
+      const int ij = __builtin_amdgcn_readlane(i, j);
+      rank += ranks_before(sj, ij, s, i) ? 1 : 0;
+    }
     const int valid = __popcll(__ballot(i != kIdxPad));
     const int keep = valid < K ? valid : K;
-    if (lane < keep) { cand_s[v * kEvalCap + lane] = s; cand_i[v * kEvalCap + lane] = i; }
-    const float ts = __shfl(s, K - 1, 64);
-    const int ti = __shfl(i, K - 1, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                        // every lane has read its entry
+    if (i != kIdxPad && rank < keep) { cand_s[v * kEvalCap + rank] = s; cand_i[v * kEvalCap + rank] = i; }
+    const unsigned long long kth = __ballot(i != kIdxPad && rank == K - 1);
+    const int lk = kth ? __builtin_ctzll(kth) : 0;
+    const float ts = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), lk));
+    const int ti = __builtin_amdgcn_readlane(i, lk);
     if (ul == v) {  // both lanes of the user
       tau_s = keep == K ? ts : kNegInf;
       tau_i = keep == K ? ti : kIdxPad;
+      c_mine = keep;
     }
-    if (lane == 0) { cnt[v] = keep; kept[v] = keep; }
+    if (lane == 0) kept[v] = keep;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
 
-  // A fragments: one coalesced 4-byte load per lane per MFMA, requested one group of U k pairs ahead (across
-  // tile groups too) - a wavefront has U * NT loads in flight while it issues the previous group's MFMAs
+  // A fragments: one coalesced 4-byte load per lane per MFMA.  The sweep is a flat sequence of steps (tile group,
+  // group of U k pairs); a step's loads are issued while the previous step's MFMAs run (two register buffers,
+  // the loop unrolled by two so that no buffer is copied).
   constexpr int U = 8;
   const float* a_base = itemT + lane;
-  auto load_group = [&](float (&a)[U][kEvalNT], int64_t t0, int s) {
+  const int KG = FP2 / U;                                      // k groups per tile group (FP2 is a multiple of U)
+  struct Pos { int64_t t0; int g; };
+  auto advance = [&](Pos& p) { if (++p.g == KG) { p.g = 0; p.t0 += kEvalNT; } };
+  auto issue = [&](float (&a)[U][kEvalNT], const Pos& p) {
+    // (unconditional: a load under a branch makes the compiler's counted vmcnt waits conservative - it then waited
+    // for the NEXT step's loads before this step's MFMAs; past the end the clamped tile is loaded again, unused)
 #pragma unroll
     for (int t = 0; t < kEvalNT; ++t) {
-      const int64_t tt = t0 + t < t_hi ? t0 + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
-      const float* ap = a_base + ((size_t)tt * FP2 + s) * 64;
+      const int64_t tt = p.t0 + t < t_hi ? p.t0 + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
+      const float* ap = a_base + ((size_t)tt * FP2 + p.g * U) * 64;
 #pragma unroll
       for (int u = 0; u < U; ++u) a[u][t] = ap[u * 64];
     }
   };
-  float a_next[U][kEvalNT];
-  if (t_lo < t_hi) load_group(a_next, t_lo, 0);
-  for (int64_t t0 = t_lo; t0 < t_hi; t0 += kEvalNT) {
-    floatx16 acc[kEvalNT];
+  floatx16 acc[kEvalNT];
 #pragma unroll
-    for (int t = 0; t < kEvalNT; ++t)
+  for (int t = 0; t < kEvalNT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int s = 0; s < FP2; s += U) {  // FP2 is a multiple of U (zero padded)
-      float a[U][kEvalNT], b[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int t = 0; t < kEvalNT; ++t) a[u][t] = a_next[u][t];
-      const bool last = s + U >= FP2;
-      const int64_t tn = last ? t0 + kEvalNT : t0;
-      if (tn < t_hi) load_group(a_next, tn, last ? 0 : s + U);
-#pragma unroll
-      for (int u = 0; u < U; ++u) b[u] = ub[(s + u) * 64 + lane];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int t = 0; t < kEvalNT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
-    }
-    // acc[t][r]: user ul, item position 32 (t0 + t) + (r & 3) + 8 (r >> 2) + 4 half
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // acc[t][r]: user ul, item position 32 (t0 + t) + (r & 3) + 8 (r >> 2) + 4 half
+  auto check = [&](int64_t t0) {
 #pragma unroll
     for (int t = 0; t < kEvalNT; ++t) {
       if (t0 + t >= t_hi) break;  // wave-uniform
@@ -203,35 +209,93 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
       if (__ballot(u_ok && m >= tau_s) != 0ull) {
+        // which of the 16 registers hold a candidate in ANY lane: one bit per register, OR-ed over the wavefront
+        // (vector instructions only), then a scalar walk over the set bits - instead of 16 ballots, each a
+        // vector-compare -> scalar-branch round trip
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (u_ok && acc[t][r] >= tau_s) ? (1u << r) : 0u;
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0x141, 0xF, 0xF, true);   // row_half_mirror
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0x140, 0xF, 0xF, true);   // row_mirror: every lane has its row's OR
+        unsigned any = 0;
+#pragma unroll
+        for (int rw = 0; rw < 4; ++rw) any |= (unsigned)__builtin_amdgcn_readlane((int)bits, 16 * rw);
         const int ib = (int)((t0 + t) * kEvalTile) + 4 * half;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          if (!(any >> r & 1u)) continue;  // scalar test
           const float sc = acc[t][r];
           const int it = ib + (r & 3) + 8 * (r >> 2);
-          if (u_ok && sc >= tau_s && it < n_items && (sc > tau_s || it < tau_i)) {
-            const int slot = atomicAdd(&cnt[ul], 1);  // < kEvalCap: at most 32 per tile on top of <= 32 held
+          const bool c = u_ok && sc >= tau_s && it < n_items && (sc > tau_s || it < tau_i);
+          const unsigned long long mk = __ballot(c);
+          if (mk == 0ull) continue;  // wave-uniform
+          // a user's two lanes (halves) append behind each other: no atomics, the count stays in registers
+          const int lo_c = (int)(mk >> ul) & 1, hi_c = (int)(mk >> (ul + 32)) & 1;
+          if (c) {
+            const int slot = c_mine + (half ? lo_c : 0);  // < kEvalCap: c_mine <= kEvalCap - 2 here
             cand_s[ul * kEvalCap + slot] = sc;
             cand_i[ul * kEvalCap + slot] = it;
+          }
+          c_mine += lo_c + hi_c;
+          // a buffer that could not take the next register's two entries is pruned now (not "room for a whole
+          // tile": with K = 20 kept of 64 that left 12 appends between prunes - one prune per tile and wavefront)
+          unsigned long long need = __ballot(half == 0 && c_mine > kEvalCap - 2);
+          if (need) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            do {
+              const int v = __builtin_ctzll(need);
+              need &= need - 1;
+              prune(v);
+            } while (need);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        unsigned long long need = __ballot(half == 0 && cnt[ul] > kEvalCap - kEvalTile);
-        while (need) {
-          const int v = __builtin_ctzll(need);
-          need &= need - 1;
-          prune(v);
-        }
       }
+    }
+  };
+  auto compute = [&](const float (&a)[U][kEvalNT], const Pos& p) {
+    if (p.t0 >= t_hi) return;
+    float b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = ub[(p.g * U + u) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < kEvalNT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
+    if (p.g == KG - 1) {
+      check(p.t0);
+#pragma unroll
+      for (int t = 0; t < kEvalNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;   // (here, behind the check's branch: not a select per step)
+    }
+  };
+  {
+    float a0[U][kEvalNT], a1[U][kEvalNT];
+    Pos p0{t_lo, 0}, p1{t_lo, 0};
+    advance(p1);
+    issue(a0, p0);
+    while (p0.t0 < t_hi) {
+      issue(a1, p1);
+      compute(a0, p0);
+      advance(p0); advance(p0);
+      issue(a0, p0);
+      compute(a1, p1);
+      advance(p1); advance(p1);
     }
   }
   // the segment's list of every user: K entries, padded with (-inf, pad)
   for (int v = 0; v < 32; ++v) {
     if (u0 + v >= n_users) break;
     prune(v);
-    const int n = cnt[v];
+    const int n = __builtin_amdgcn_readlane(c_mine, v);
     if (lane < K) {
-      const size_t o = ((size_t)(u0 + v) * n_seg + seg) * K + lane;
+      const size_t o = ((size_t)(u0 + v) * n_lists + list0 + seg) * K + lane;
       part_s[o] = lane < n ? cand_s[v * kEvalCap + lane] : kNegInf;
       part_i[o] = lane < n ? cand_i[v * kEvalCap + lane] : kIdxPad;
     }
@@ -287,15 +351,30 @@ static int eval_waves_per_block(int FP2) {
   return 0;
 }
 
-static int eval_segments(int64_t n_users, int64_t n_tiles, int nw) {
+// Launch plan.  A first launch sweeps a SAMPLE of the items (the first kEvalSampleTiles tiles) for every user; the
+// K-th best of that list is a valid lower bound of the user's final K-th best, and every segment of the main launch
+// starts from it instead of warming its own threshold up from -inf (about K ln(1 + n_seg_items / sample) candidates
+// per user and segment instead of K ln(n_seg_items / K)).  The main launch splits the remaining tiles into segments
+// so that the grid has a few workgroups per CU.
+constexpr int kEvalSampleTiles = 16;  // 512 items
+struct EvalPlanH { int nw, sample_tiles, seg, n_lists; };
+static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
+  EvalPlanH p;
+  p.nw = eval_waves_per_block(eval_fp2(F));
+  const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
+  p.sample_tiles = n_tiles >= 4 * kEvalSampleTiles ? kEvalSampleTiles : 0;
+  const int64_t rest = n_tiles - p.sample_tiles;
+  const int nw = p.nw > 0 ? p.nw : 1;
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
-  const int64_t want = (int64_t)device_cu_count() * 8;       // ~8 workgroups per CU: a smooth tail
+  const int64_t want = (int64_t)device_cu_count() * 4;       // ~4 workgroups per CU
   int64_t seg = (want + blocks - 1) / (blocks > 0 ? blocks : 1);
-  const int64_t max_seg = n_tiles / 16 > 0 ? n_tiles / 16 : 1;  // at least 16 tiles (512 items) per segment
+  const int64_t max_seg = rest / 16 > 0 ? rest / 16 : 1;     // at least 16 tiles (512 items) per segment
   if (seg > max_seg) seg = max_seg;
   if (seg > 64) seg = 64;
   if (seg < 1) seg = 1;
-  return (int)seg;
+  p.seg = (int)seg;
+  p.n_lists = p.seg + (p.sample_tiles ? 1 : 0);
+  return p;
 }
 
 }  // namespace kgat
@@ -333,9 +412,8 @@ int kgat_eval_items_kmajor_f32(int64_t n_items, int F, const float* emb, int64_t
 
 size_t kgat_eval_workspace_bytes(int64_t n_users, int64_t n_items, int F, int K) {
   if (n_users <= 0 || n_items <= 0 || !kgat_eval_supported(F, K)) return 256;
-  const int nw = eval_waves_per_block(eval_fp2(F));
-  const int seg = eval_segments(n_users, (n_items + kEvalTile - 1) / kEvalTile, nw);
-  return 2 * align_up((size_t)n_users * seg * K * 4, 256) + 256;
+  const EvalPlanH pl = eval_plan(n_users, n_items, F);
+  return 2 * align_up((size_t)n_users * pl.n_lists * K * 4, 256) + 256;
 }
 
 int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t n_items, int F, const float* emb,
@@ -359,30 +437,42 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   }
   const int FP2 = eval_fp2(F);
   const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
-  const int nw = eval_waves_per_block(FP2);
-  const int seg = eval_segments(n_users, n_tiles, nw);
+  const EvalPlanH pl = eval_plan(n_users, n_items, F);
+  const int nw = pl.nw;
   Carver cv(workspace);
-  float* part_s = cv.take<float>((size_t)n_users * seg * K);
-  int32_t* part_i = cv.take<int32_t>((size_t)n_users * seg * K);
+  float* part_s = cv.take<float>((size_t)n_users * pl.n_lists * K);
+  int32_t* part_i = cv.take<int32_t>((size_t)n_users * pl.n_lists * K);
   const size_t lds = EvalLds::per_wave_bytes(FP2) * nw;
-  const dim3 grid((unsigned)((n_users + 32 * nw - 1) / (32 * nw)), (unsigned)seg);
+  const unsigned gx = (unsigned)((n_users + 32 * nw - 1) / (32 * nw));
   hipStream_t st = as_stream(stream);
-#define KGAT_EVAL_LAUNCH(NW)                                                                                          \
+#define KGAT_EVAL_LAUNCH(NW, GY, TLO, THI, LIST0, TAU0)                                                               \
   do {                                                                                                                \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(eval_topk_kernel<NW>),                                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                    \
       set_error("eval_recall_ndcg: cannot reserve %zu bytes of LDS", lds);                                            \
       return KGAT_E_HIP;                                                                                              \
     }                                                                                                                 \
-    hipLaunchKernelGGL((eval_topk_kernel<NW>), grid, dim3(NW * 64), lds, st, n_users, user_ids, n_items, FP2, F,      \
-                       n_tiles, seg, emb, emb_stride, itemT, train_ptr, train_items, K, part_s, part_i);             \
+    hipLaunchKernelGGL((eval_topk_kernel<NW>), dim3(gx, (unsigned)(GY)), dim3(NW * 64), lds, st, n_users, user_ids,   \
+                       n_items, FP2, F, (int64_t)(TLO), (int64_t)(THI), pl.n_lists, LIST0, TAU0, emb, emb_stride,    \
+                       itemT, train_ptr, train_items, K, part_s, part_i);                                            \
   } while (0)
-  if (nw == 4) KGAT_EVAL_LAUNCH(4);
-  else if (nw == 2) KGAT_EVAL_LAUNCH(2);
-  else KGAT_EVAL_LAUNCH(1);
+#define KGAT_EVAL_LAUNCH_NW(GY, TLO, THI, LIST0, TAU0)                  \
+  do {                                                                  \
+    if (nw == 4) KGAT_EVAL_LAUNCH(4, GY, TLO, THI, LIST0, TAU0);        \
+    else if (nw == 2) KGAT_EVAL_LAUNCH(2, GY, TLO, THI, LIST0, TAU0);   \
+    else KGAT_EVAL_LAUNCH(1, GY, TLO, THI, LIST0, TAU0);                \
+  } while (0)
+  if (pl.sample_tiles) {
+    KGAT_EVAL_LAUNCH_NW(1, 0, pl.sample_tiles, 0, 0);
+    KGAT_CHECK_LAUNCH("eval_topk (sample)");
+    KGAT_EVAL_LAUNCH_NW(pl.seg, pl.sample_tiles, n_tiles, 1, 1);
+  } else {
+    KGAT_EVAL_LAUNCH_NW(pl.seg, 0, n_tiles, 0, 0);
+  }
+#undef KGAT_EVAL_LAUNCH_NW
 #undef KGAT_EVAL_LAUNCH
   KGAT_CHECK_LAUNCH("eval_topk");
-  hipLaunchKernelGGL(eval_merge_kernel, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, n_users, seg, K,
+  hipLaunchKernelGGL(eval_merge_kernel, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, n_users, pl.n_lists, K,
                      part_s, part_i, train_ptr, train_items, test_ptr, test_items, disc, recall_out, ndcg_out,
                      topk_out);
   KGAT_CHECK_LAUNCH("eval_merge");
