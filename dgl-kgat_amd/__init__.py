@@ -14,6 +14,8 @@ from .ckg_io import CKGDataset  # noqa: F401
 from ._lib import KGATLibraryError  # noqa: F401
 from .lazy import enable as enable_lazy_edge_weights  # noqa: F401
 from .partition import GraphedForward  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 
 __all__ = ["DGLGraph", "DGLError", "ALL", "function", "edge_softmax", "KGATConv", "KGATPropagation",
-           "install_as_dgl", "accelerate", "KGATLibraryError", "CKGDataset", "enable_lazy_edge_weights", "GraphedForward"]
+           "install_as_dgl", "accelerate", "KGATLibraryError", "CKGDataset", "enable_lazy_edge_weights", "GraphedForward",
+           "FusedAdam"]

@@ -23,6 +23,8 @@ SOURCES = {
     "kgat_dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "kgat_transr.hip": [],
     "kgat_eval.hip": [],
+    "kgat_optim.hip": [],
+    "kgat_bpr.hip": [],
 }
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "kgat_hip.h")
 
@@ -84,6 +86,8 @@ SIGNATURES = {
     "kgat_transr_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "kgat_transr_loss_grad_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p,
                                          _p, _p, _p, _sz, _p]),
+    "kgat_transr_forward_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_float, _p, _p, _sz, _p]),
+    "kgat_transr_backward_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "kgat_bi_interaction_f32": (_i32, [_i64, _i32, _i32, _p, _p, C.c_float, _p, _p, _i64, _p]),
     "kgat_bi_interaction_mul_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, _p, _p, _i64, _p, _i64, _p]),
     "kgat_bi_interaction_mul_deferred_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, _p, _p, _i64, _p, _i64,
@@ -99,6 +103,11 @@ SIGNATURES = {
     "kgat_eval_items_elems": (_i64, [_i64, _i32]),
     "kgat_eval_items_kmajor_f32": (_i32, [_i64, _i32, _p, _i64, _p, _p, _p]),
     "kgat_eval_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "kgat_bpr_workspace_bytes": (_sz, [_i64]),
+    "kgat_bpr_loss_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
+    "kgat_bpr_grad_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
+    "kgat_adam_max_tensors": (_i32, []),
+    "kgat_adam_step_f32": (_i32, [_i32, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _p]),
     "kgat_eval_recall_ndcg_f32": (_i32, [_i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _sz, _p,
                                          _p, _p, _p]),
 }

@@ -97,30 +97,64 @@ def edge_softmax(graph, logits, eids=None):
 
 
 class _TransRLoss(torch.autograd.Function):
-    """TransR loss of a triplet batch (reference models.py:114-133) with its gradients computed in
-    the same handful of launches (kgat_transr_loss_grad_f32); backward only scales them."""
+    """TransR loss of a triplet batch (reference models.py:114-133).  Forward: the loss, the per-sample rows and the
+    weight-gradient partials (kgat_transr_forward_f32); backward: the ordered reductions into the three gradients,
+    which read the incoming gradient from device memory (kgat_transr_backward_f32) - no multiply passes."""
 
     @staticmethod
     def forward(ctx, ent, W_R, rel, h, r, pos_t, neg_t, reg_lambda):
         want = any(ctx.needs_input_grad[:3])
-        loss, g_ent, g_w, g_rel = ops.transr_loss_grad(h, r, pos_t, neg_t, ent.detach(), W_R.detach(), rel.detach(),
-                                                       reg_lambda, want_grad=want)
-        if want:
-            ctx.save_for_backward(g_ent, g_w, g_rel)
+        if not want:
+            return ops.transr_loss_grad(h, r, pos_t, neg_t, ent.detach(), W_R.detach(), rel.detach(), reg_lambda,
+                                        want_grad=False)[0]
+        loss, ws = ops.transr_forward(h, r, pos_t, neg_t, ent.detach(), W_R.detach(), rel.detach(), reg_lambda)
+        ctx.ws, ctx.shapes = ws, (tuple(ent.shape), tuple(W_R.shape))
+        ctx.save_for_backward(h, r, pos_t, neg_t)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        g_ent, g_w, g_rel = ctx.saved_tensors
+        h, r, pos_t, neg_t = ctx.saved_tensors
+        g_ent, g_w, g_rel = ops.transr_backward(h, r, pos_t, neg_t, ctx.shapes, ctx.ws,
+                                                grad_scale=grad_out.detach().to(torch.float32))
         need = ctx.needs_input_grad
-        return (g_ent * grad_out if need[0] else None, g_w * grad_out if need[1] else None,
-                g_rel * grad_out if need[2] else None, None, None, None, None, None)
+        return (g_ent if need[0] else None, g_w if need[1] else None, g_rel if need[2] else None,
+                None, None, None, None, None)
 
 
 def transr_loss(ent, W_R, rel, h, r, pos_t, neg_t, reg_lambda):
     """Differentiable fused TransR loss; index tensors of any integer dtype."""
-    i32 = [t.to(torch.int32).contiguous() for t in (h, r, pos_t, neg_t)]
+    i32 = [t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous() for t in (h, r, pos_t, neg_t)]
     return _TransRLoss.apply(ent, W_R, rel, *i32, float(reg_lambda))
+
+
+class _BPRLoss(torch.autograd.Function):
+    """BPR loss of the CF phase (reference models.py:170-178) as two launches forward and one sort + one scatter
+    backward (kgat_bpr_loss_f32 / kgat_bpr_grad_f32) instead of ~75 torch operator launches; the incoming gradient
+    is read by the scatter kernel from device memory."""
+
+    @staticmethod
+    def forward(ctx, emb, u, p, n, reg_lambda):
+        e = emb.detach()
+        loss, coef, ws = ops.bpr_loss(e, u, p, n, reg_lambda)
+        ctx.reg_lambda, ctx.ws = reg_lambda, ws
+        ctx.save_for_backward(e, u, p, n, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e, u, p, n, coef = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        g = ops.bpr_grad(e, u, p, n, coef, ctx.reg_lambda, grad_scale=grad_out.detach().to(torch.float32), workspace=ctx.ws)
+        return g, None, None, None, None
+
+
+def bpr_loss(embedding, src_ids, pos_dst_ids, neg_dst_ids, reg_lambda):
+    """Differentiable fused BPR loss; index tensors of any integer dtype (int32 is passed through as is)."""
+    i32 = [t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+           for t in (src_ids, pos_dst_ids, neg_dst_ids)]
+    return _BPRLoss.apply(embedding, *i32, float(reg_lambda))
 
 
 class _GNNTrain(torch.autograd.Function):

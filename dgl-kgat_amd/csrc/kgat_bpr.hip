@@ -1,0 +1,224 @@
+// BPR loss of the CF phase (reference models.py:170-178, get_loss; _L2_loss_mean :9-11) and its gradient with
+// respect to the readout, for gfx950.  The reference's expression is ~30 torch operators forward and ~45 backward
+// (gathers, batched dot products, logsigmoid, three regularisers, an index_put with a device sort): 75 launches of
+// a few microseconds each, 0.7 ms of the 1.6 ms CF step, all of it launch latency.  Here:
+//   forward   bpr_sample_kernel (one wavefront per sample: the three rows, five dot products) + bpr_reduce_kernel
+//   backward  stable radix sort of the 3B row ids (kgat_graph.hip) + zero fill + bpr_scatter_kernel
+//             (one wavefront per distinct row sums that row's contributions in sample order: fixed order of
+//             additions, no float atomics, bitwise reproducible), scaled by the incoming gradient read from
+//             device memory (no host synchronisation, no separate multiply pass)
+//   loss = -mean_b logsigmoid(<s,p> - <s,n>) + lambda (mean_b |s|^2/2 + mean_b |p|^2/2 + mean_b |n|^2/2)
+#include "kgat_common.h"
+
+namespace kgat {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// per sample b: out[b] = logsigmoid(x), out[B + b] = (|s|^2 + 0)/2 ..., coef[b] = sigmoid(-x)
+__global__ __launch_bounds__(256) void bpr_sample_kernel(int64_t batch, int64_t n_nodes, int F,
+                                                         const float* __restrict__ emb, int64_t stride, const int32_t* __restrict__ u,
+                                                         const int32_t* __restrict__ p, const int32_t* __restrict__ n,
+                                                         float* __restrict__ part, float* __restrict__ coef) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  if ((uint64_t)u[b] >= (uint64_t)n_nodes || (uint64_t)p[b] >= (uint64_t)n_nodes || (uint64_t)n[b] >= (uint64_t)n_nodes) {
+    // an id outside [0, n_nodes) (torch would fail a device-side assertion): NaN in the loss, no access
+    if (lane == 0) {
+      part[b] = __builtin_nanf(""); part[batch + b] = 0.f; part[2 * batch + b] = 0.f; part[3 * batch + b] = 0.f;
+      coef[b] = 0.f;
+    }
+    return;
+  }
+  const float* rs = emb + (size_t)u[b] * stride;
+  const float* rp = emb + (size_t)p[b] * stride;
+  const float* rn = emb + (size_t)n[b] * stride;
+  float sp = 0.f, sn = 0.f, ss = 0.f, pp = 0.f, nn = 0.f;
+  for (int c = lane * 4; c < F; c += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(rs + c);
+    const float4 x = *reinterpret_cast<const float4*>(rp + c);
+    const float4 y = *reinterpret_cast<const float4*>(rn + c);
+    sp += a.x * x.x + a.y * x.y + a.z * x.z + a.w * x.w;
+    sn += a.x * y.x + a.y * y.y + a.z * y.z + a.w * y.w;
+    ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    pp += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    nn += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+  }
+  sp = wave_sum(sp); sn = wave_sum(sn); ss = wave_sum(ss); pp = wave_sum(pp); nn = wave_sum(nn);
+  if (lane == 0) {
+    const float x = sp - sn;
+    // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)); sigmoid(-x) = 1 / (1 + exp(x))
+    part[b] = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+    part[batch + b] = 0.5f * ss;
+    part[2 * batch + b] = 0.5f * pp;
+    part[3 * batch + b] = 0.5f * nn;
+    coef[b] = x >= 0.f ? expf(-x) / (1.f + expf(-x)) : 1.f / (1.f + expf(x));
+  }
+}
+
+// loss = -mean(part[0:B]) + lambda (mean(part[B:2B]) + mean(part[2B:3B]) + mean(part[3B:4B])), fixed order
+__global__ __launch_bounds__(1024) void bpr_reduce_kernel(int64_t batch, const float* __restrict__ part,
+                                                          float reg_lambda, float* __restrict__ loss) {
+  __shared__ float s_red[4][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = threadIdx.x; i < batch; i += 1024)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += part[k * batch + i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[k] = wave_sum(acc[k]);
+    if (lane == 0) s_red[k][w] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = 0.f;
+      for (int j = 0; j < 16; ++j) x += s_red[k][j];
+      t[k] = x / (float)batch;
+    }
+    loss[0] = -t[0] + reg_lambda * (t[1] + t[2] + t[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bpr_keys_kernel(int64_t batch, const int32_t* __restrict__ u,
+                                                       const int32_t* __restrict__ p, const int32_t* __restrict__ n,
+                                                       int32_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * batch) return;
+  const int64_t b = i % batch;
+  const int role = (int)(i / batch);
+  keys[i] = role == 0 ? u[b] : (role == 1 ? p[b] : n[b]);
+}
+
+// One wavefront per sorted position; the wavefront at the first position of a row id sums the row's contributions in
+// sorted (= sample, the sort is stable) order and writes the row.  scale = grad_scale[0] / batch.
+__global__ __launch_bounds__(256) void bpr_scatter_kernel(int64_t batch, int64_t n_nodes, int F,
+                                                          const float* __restrict__ emb,
+                                                          int64_t stride, const int32_t* __restrict__ u,
+                                                          const int32_t* __restrict__ p, const int32_t* __restrict__ n,
+                                                          const float* __restrict__ coef, float reg_lambda,
+                                                          const float* __restrict__ grad_scale,
+                                                          const int32_t* __restrict__ sorted,
+                                                          const int32_t* __restrict__ order, float* __restrict__ grad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = 3 * batch;
+  if (q >= total) return;
+  const int32_t key = sorted[q];
+  if (q > 0 && sorted[q - 1] == key) return;
+  if ((uint64_t)key >= (uint64_t)n_nodes) return;   // (the forward already turned the loss into NaN)
+  const float scale = (grad_scale ? grad_scale[0] : 1.f) / (float)batch;
+  const float lam = reg_lambda * scale;
+  const float* own = emb + (size_t)key * stride;
+  for (int c = lane * 4; c < F; c += 256) {
+    const float4 o = *reinterpret_cast<const float4*>(own + c);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t j = q; j < total && sorted[j] == key; ++j) {
+      const int64_t idx = order[j];
+      const int64_t b = idx % batch;
+      const int role = (int)(idx / batch);
+      const int32_t ub = u[b], pb = p[b], nb = n[b];
+      if ((uint64_t)ub >= (uint64_t)n_nodes || (uint64_t)pb >= (uint64_t)n_nodes || (uint64_t)nb >= (uint64_t)n_nodes)
+        continue;                         // (a sample with an id outside the table: the forward made the loss NaN)
+      const float cs = coef[b] * scale;   // -dL/dx
+      float4 d;
+      if (role == 0) {   // source row: dL/ds = dL/dx (p - n)
+        const float4 x = *reinterpret_cast<const float4*>(emb + (size_t)pb * stride + c);
+        const float4 y = *reinterpret_cast<const float4*>(emb + (size_t)nb * stride + c);
+        d = make_float4(-cs * (x.x - y.x), -cs * (x.y - y.y), -cs * (x.z - y.z), -cs * (x.w - y.w));
+      } else {           // positive / negative row: dL/dp = dL/dx s, dL/dn = -dL/dx s
+        const float4 a = *reinterpret_cast<const float4*>(emb + (size_t)ub * stride + c);
+        const float sg = role == 1 ? -cs : cs;
+        d = make_float4(sg * a.x, sg * a.y, sg * a.z, sg * a.w);
+      }
+      acc.x += d.x + lam * o.x; acc.y += d.y + lam * o.y; acc.z += d.z + lam * o.z; acc.w += d.w + lam * o.w;
+    }
+    *reinterpret_cast<float4*>(grad + (size_t)key * F + c) = acc;
+  }
+}
+
+static int bits_for_id(int64_t max_id) {
+  int b = 1;
+  while (b < 31 && ((int64_t)1 << b) <= max_id) ++b;
+  return b;
+}
+
+}  // namespace kgat
+
+using namespace kgat;
+
+extern "C" {
+
+size_t kgat_bpr_workspace_bytes(int64_t batch) {
+  if (batch < 1) batch = 1;
+  // per-sample partials (4 B floats) | keys, order (3 B int32 each) | radix sort scratch
+  return align_up((size_t)batch * 4 * 4, 256) + 2 * align_up((size_t)batch * 3 * 4, 256) +
+         radix_sort_workspace_bytes(3 * batch) + 256;
+}
+
+int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
+                      const int32_t* p, const int32_t* n, float reg_lambda, float* loss, float* coef, void* workspace,
+                      size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 0 && batch >= 1 && F >= 4 && F % 4 == 0 && emb_stride >= F && emb_stride % 4 == 0,
+                 "bpr_loss: bad sizes (F and the row stride must be multiples of 4, batch >= 1)");
+  KGAT_CHECK_ARG(batch < ((int64_t)1 << 29), "bpr_loss: batch too large");
+  KGAT_CHECK_ARG(emb && u && p && n && loss && coef && workspace, "bpr_loss: null pointer");
+  KGAT_CHECK_ARG((reinterpret_cast<uintptr_t>(emb) & 15) == 0, "bpr_loss: emb must be 16-byte aligned");
+  if (workspace_bytes < kgat_bpr_workspace_bytes(batch)) {
+    set_error("bpr_loss: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  Carver cv(workspace);
+  float* part = cv.take<float>((size_t)batch * 4);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bpr_sample_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F, emb,
+                     emb_stride, u, p, n, part, coef);
+  KGAT_CHECK_LAUNCH("bpr_sample");
+  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, batch, (const float*)part, reg_lambda, loss);
+  KGAT_CHECK_LAUNCH("bpr_reduce");
+  return KGAT_OK;
+}
+
+int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
+                      const int32_t* p, const int32_t* n, const float* coef, float reg_lambda, const float* grad_scale,
+                      float* grad, void* workspace, size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_nodes >= 1 && batch >= 1 && F >= 4 && F % 4 == 0 && emb_stride >= F && emb_stride % 4 == 0,
+                 "bpr_grad: bad sizes (F and the row stride must be multiples of 4, batch >= 1)");
+  KGAT_CHECK_ARG(batch < ((int64_t)1 << 29), "bpr_grad: batch too large");
+  KGAT_CHECK_ARG(emb && u && p && n && coef && grad && workspace, "bpr_grad: null pointer");
+  KGAT_CHECK_ARG(((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0,
+                 "bpr_grad: emb and grad must be 16-byte aligned");
+  if (workspace_bytes < kgat_bpr_workspace_bytes(batch)) {
+    set_error("bpr_grad: workspace too small");
+    return KGAT_E_WORKSPACE;
+  }
+  Carver cv(workspace);
+  cv.take<float>((size_t)batch * 4);
+  int32_t* keys = cv.take<int32_t>((size_t)batch * 3);
+  int32_t* order = cv.take<int32_t>((size_t)batch * 3);
+  void* sort_ws = cv.base + cv.off;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((3 * batch + 255) / 256)), dim3(256), 0, st, batch, u, p, n, keys);
+  KGAT_CHECK_LAUNCH("bpr_keys");
+  const int32_t* sorted = nullptr;
+  const int rc = radix_sort_index(keys, 3 * batch, bits_for_id(n_nodes - 1), order, &sorted, sort_ws,
+                                  workspace_bytes - cv.off, st);
+  if (rc != KGAT_OK) return rc;
+  if (hipMemsetAsync(grad, 0, (size_t)n_nodes * F * sizeof(float), st) != hipSuccess) {
+    set_error("bpr_grad: memset failed");
+    return KGAT_E_HIP;
+  }
+  hipLaunchKernelGGL(bpr_scatter_kernel, dim3((unsigned)((3 * batch + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F,
+                     emb, emb_stride, u, p, n, coef, reg_lambda, grad_scale, sorted, (const int32_t*)order, grad);
+  KGAT_CHECK_LAUNCH("bpr_scatter");
+  return KGAT_OK;
+}
+
+}  // extern "C"

@@ -110,19 +110,22 @@ int exclusive_scan_i32(int32_t* data, int64_t n, int32_t* ws, hipStream_t st) {
 // the 64 keys of a step with wave ballots (peers with the same digit and a lower lane), so
 // equal keys keep their input order: the sort is stable, which is what makes edge ids
 // ascend inside every CSR row.
-constexpr int kSortTile = 4096;
+constexpr int kSortTile = 4096;       // keys per block on large inputs (graph builds: millions of keys)
+constexpr int kSortTileSmall = 256;   // below 2^20 keys: one wavefront walking 4,096 keys in 64 dependent steps is
+                                      // latency, not work (30,720 BPR row ids: 8 blocks, 240 us for three passes)
 constexpr int kDigits = 256;
+static int sort_tile(int64_t n) { return n >= ((int64_t)1 << 20) ? kSortTile : kSortTileSmall; }
 
 __global__ __launch_bounds__(kWave) void sort_hist_kernel(const int32_t* __restrict__ keys,
                                                           int64_t n, int shift,
                                                           int32_t* __restrict__ hist,
-                                                          int nblk) {
+                                                          int nblk, int tile) {
   __shared__ int32_t cnt[kDigits];
   const int lane = threadIdx.x;
   for (int i = lane; i < kDigits; i += kWave) cnt[i] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortTile;
-  for (int j = lane; j < kSortTile; j += kWave) {
+  const int64_t base = (int64_t)blockIdx.x * tile;
+  for (int j = lane; j < tile; j += kWave) {
     const int64_t idx = base + j;
     if (idx < n) atomicAdd(&cnt[((uint32_t)keys[idx] >> shift) & (kDigits - 1)], 1);
   }
@@ -132,15 +135,15 @@ __global__ __launch_bounds__(kWave) void sort_hist_kernel(const int32_t* __restr
 
 __global__ __launch_bounds__(kWave) void sort_scatter_kernel(
     const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int64_t n,
-    int shift, const int32_t* __restrict__ offs, int nblk, int32_t* __restrict__ keys_out,
+    int shift, const int32_t* __restrict__ offs, int nblk, int tile, int32_t* __restrict__ keys_out,
     int32_t* __restrict__ vals_out) {
   __shared__ int32_t run[kDigits];
   const int lane = threadIdx.x;
   for (int i = lane; i < kDigits; i += kWave) run[i] = offs[(size_t)i * nblk + blockIdx.x];
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  const int64_t base = (int64_t)blockIdx.x * tile;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  for (int step = 0; step < kSortTile / kWave; ++step) {
+  for (int step = 0; step < tile / kWave; ++step) {
     const int64_t idx = base + (int64_t)step * kWave + lane;
     const bool valid = idx < n;
     const int32_t key = valid ? keys_in[idx] : 0;
@@ -172,7 +175,7 @@ struct SortPlan {
 
 static SortPlan sort_plan(int64_t n) {
   SortPlan p;
-  p.nblk = (int)((n + kSortTile - 1) / kSortTile);
+  p.nblk = (int)((n + sort_tile(n) - 1) / sort_tile(n));
   if (p.nblk < 1) p.nblk = 1;
   p.hist_elems = (size_t)kDigits * p.nblk;
   p.scan_elems = scan_workspace_elems((int64_t)p.hist_elems);
@@ -212,12 +215,12 @@ int radix_sort_index(const int32_t* keys_in, int64_t n, int key_bits, int32_t* v
   for (int j = 0; j < passes; ++j) {
     const int sel = (passes - 1 - j) & 1;  // the last pass lands in K[0] / vals_out
     hipLaunchKernelGGL(sort_hist_kernel, dim3(p.nblk), dim3(kWave), 0, st, kin, n, 8 * j, hist,
-                       p.nblk);
+                       p.nblk, sort_tile(n));
     KGAT_CHECK_LAUNCH("sort_hist");
     int rc = exclusive_scan_i32(hist, (int64_t)p.hist_elems, scan_ws, st);
     if (rc != KGAT_OK) return rc;
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(p.nblk), dim3(kWave), 0, st, kin, vin, n, 8 * j,
-                       (const int32_t*)hist, p.nblk, K[sel], V[sel]);
+                       (const int32_t*)hist, p.nblk, sort_tile(n), K[sel], V[sel]);
     KGAT_CHECK_LAUNCH("sort_scatter");
     kin = K[sel];
     vin = V[sel];

@@ -404,9 +404,11 @@ __global__ __launch_bounds__(256) void transr_reduce_kernel(int32_t batch, int d
                                                             const float* __restrict__ part,
                                                             const float* __restrict__ losses,
                                                             float* __restrict__ grad_W, float* __restrict__ grad_rel,
-                                                            float* __restrict__ loss) {
+                                                            float* __restrict__ loss,
+                                                            const float* __restrict__ grad_scale) {
   const int r = blockIdx.x;
   if (r == n_rel) {
+    if (loss == nullptr) return;
     __shared__ float s_l[256];
     float v = 0.f;
     for (int32_t s = threadIdx.x; s < batch; s += 256) v += losses[s];
@@ -422,9 +424,11 @@ __global__ __launch_bounds__(256) void transr_reduce_kernel(int32_t batch, int d
   if (grad_W == nullptr) return;
   const int dk = d * k;
   const int first = chunk_ptr[r], n_mine = chunk_ptr[r + 1] - first;
+  const float sc = grad_scale ? grad_scale[0] : 1.f;   // the gradient arriving at the loss (device scalar)
   for (int e = threadIdx.x; e < dk + k; e += 256) {
     float v = 0.f;
     for (int q = 0; q < n_mine; ++q) v += part[(size_t)(first + q) * (dk + k) + e];
+    if (grad_scale) v *= sc;
     if (e < dk) grad_W[(size_t)r * dk + e] = v;
     else grad_rel[(size_t)r * k + (e - dk)] = v;
   }
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(256) void transr_scatter_kernel(int32_t n_rows, int
                                                              const int32_t* __restrict__ sorted_ids,
                                                              const int32_t* __restrict__ row_order,
                                                              const float* __restrict__ DX,
-                                                             float* __restrict__ grad_ent) {
+                                                             float* __restrict__ grad_ent,
+                                                             const float* __restrict__ grad_scale) {
   const int sl = threadIdx.x & 15;
   const int32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (p >= n_rows) return;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256) void transr_scatter_kernel(int32_t n_rows, int
 #pragma unroll
   for (int c = 0; c < kTrMaxDim / 16; ++c) {
     const int i = sl + 16 * c;
-    if (i < d) grad_ent[(size_t)id * d + i] = acc[c];
+    if (i < d) grad_ent[(size_t)id * d + i] = grad_scale ? acc[c] * grad_scale[0] : acc[c];
   }
 }
 
@@ -509,19 +514,25 @@ size_t kgat_transr_workspace_bytes(int64_t batch, int d, int k, int n_rel) {
   return w;
 }
 
-int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h,
-                              const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, const float* ent,
-                              const float* W_R, const float* rel, float reg_lambda, float* loss, float* grad_ent,
-                              float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
-                              kgat_stream_t stream) {
+// stage bits of transr_run: FORWARD = relation sort + per-sample kernel (+ the weight-gradient partials) + the loss;
+// BACKWARD = the ordered reductions into grad_W / grad_rel and the sorted scatter into grad_ent, scaled by
+// grad_scale[0] when given.  The workspace carries the per-sample rows from one to the other.
+enum { kTrForward = 1, kTrBackward = 2 };
+
+static int transr_run(int stage, int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h,
+                      const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, const float* ent,
+                      const float* W_R, const float* rel, float reg_lambda, float* loss, const float* grad_scale,
+                      float* grad_ent, float* grad_W, float* grad_rel, bool want_grad, void* workspace,
+                      size_t workspace_bytes, kgat_stream_t stream) {
   if (!kgat_transr_supported(n_nodes, d, k, n_rel, batch)) {
     set_error("transr: needs d, k multiples of 4 and <= %d, batch <= %d, n_nodes < 2^31 (d=%d k=%d batch=%lld n_nodes=%lld)", kTrMaxDim,
               kTrSmallSort / 3, d, k, (long long)batch, (long long)n_nodes);
     return KGAT_E_UNSUPPORTED;
   }
-  KGAT_CHECK_ARG(h && r && pos_t && neg_t && ent && W_R && rel && loss && workspace, "transr: null pointer");
-  const bool want_grad = grad_ent || grad_W || grad_rel;
-  KGAT_CHECK_ARG(!want_grad || (grad_ent && grad_W && grad_rel), "transr: all three gradients or none");
+  KGAT_CHECK_ARG(h && r && pos_t && neg_t && workspace, "transr: null pointer");
+  KGAT_CHECK_ARG(!(stage & kTrForward) || (ent && W_R && rel && loss), "transr: null pointer");
+  KGAT_CHECK_ARG(!(stage & kTrBackward) || !want_grad || (grad_ent && grad_W && grad_rel),
+                 "transr: all three gradients or none");
   if (workspace_bytes < kgat_transr_workspace_bytes(batch, d, k, n_rel)) {
     set_error("transr: workspace too small");
     return KGAT_E_WORKSPACE;
@@ -546,28 +557,40 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   int rel_bits = 1, id_bits = 1;
   while ((1 << rel_bits) < n_rel) ++rel_bits;
   while ((1ll << id_bits) < n_nodes) ++id_bits;
-  hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, B, rel_bits, r, (const int32_t*)nullptr,
-                     (const int32_t*)nullptr, order, (int32_t*)nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks);
-  KGAT_CHECK_LAUNCH("transr_sort_relations");
-  const unsigned sb = (unsigned)((B + 3) / 4);
-  if (!want_grad) {
-    hipLaunchKernelGGL(transr_sample_kernel<false>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
+  if (stage & kTrForward) {
+    hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, B, rel_bits, r, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, order, (int32_t*)nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks);
+    KGAT_CHECK_LAUNCH("transr_sort_relations");
+    const unsigned sb = (unsigned)((B + 3) / 4);
+    if (!want_grad) {
+      hipLaunchKernelGGL(transr_sample_kernel<false>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
+                         pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
+      KGAT_CHECK_LAUNCH("transr_sample");
+      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
+                         (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss,
+                         (const float*)nullptr);
+      KGAT_CHECK_LAUNCH("transr_reduce");
+      return KGAT_OK;
+    }
+    hipLaunchKernelGGL(transr_sample_kernel<true>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
                        pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
     KGAT_CHECK_LAUNCH("transr_sample");
-    hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
-                       (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss);
-    KGAT_CHECK_LAUNCH("transr_reduce");
-    return KGAT_OK;
+    hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part), dim3(256), 0, st, d, k, n_rel,
+                       (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
+                       (const int32_t*)chunk_ptr, (const int2*)chunks, part);
+    KGAT_CHECK_LAUNCH("transr_wgrad_partial");
+    if (!(stage & kTrBackward)) {
+      // the loss alone now (block n_rel of the reduction); the row ids are sorted here too - graph of the batch only
+      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
+                         (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss,
+                         (const float*)nullptr);
+      KGAT_CHECK_LAUNCH("transr_reduce");
+    }
   }
-  hipLaunchKernelGGL(transr_sample_kernel<true>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
-                     pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
-  KGAT_CHECK_LAUNCH("transr_sample");
-  hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part), dim3(256), 0, st, d, k, n_rel,
-                     (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
-                     (const int32_t*)chunk_ptr, (const int2*)chunks, part);
-  KGAT_CHECK_LAUNCH("transr_wgrad_partial");
+  if (!(stage & kTrBackward) || !want_grad) return KGAT_OK;
   hipLaunchKernelGGL(transr_reduce_kernel, dim3((unsigned)n_rel + 1), dim3(256), 0, st, B, d, k, n_rel,
-                     (const int32_t*)chunk_ptr, (const float*)part, (const float*)losses, grad_W, grad_rel, loss);
+                     (const int32_t*)chunk_ptr, (const float*)part, (const float*)losses, grad_W, grad_rel,
+                     (stage & kTrForward) ? loss : (float*)nullptr, grad_scale);
   KGAT_CHECK_LAUNCH("transr_reduce");
   if (hipMemsetAsync(grad_ent, 0, sizeof(float) * (size_t)n_nodes * d, st) != hipSuccess) {
     set_error("transr: memset failed");
@@ -581,9 +604,37 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
                        sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
   KGAT_CHECK_LAUNCH("transr_sort_ids");
   hipLaunchKernelGGL(transr_scatter_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, st, 3 * B, d,
-                     (const int32_t*)sorted_ids, (const int32_t*)row_order, (const float*)DX, grad_ent);
+                     (const int32_t*)sorted_ids, (const int32_t*)row_order, (const float*)DX, grad_ent, grad_scale);
   KGAT_CHECK_LAUNCH("transr_scatter");
   return KGAT_OK;
+}
+
+int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h,
+                              const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, const float* ent,
+                              const float* W_R, const float* rel, float reg_lambda, float* loss, float* grad_ent,
+                              float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
+                              kgat_stream_t stream) {
+  const bool want_grad = grad_ent || grad_W || grad_rel;
+  KGAT_CHECK_ARG(!want_grad || (grad_ent && grad_W && grad_rel), "transr: all three gradients or none");
+  return transr_run(kTrForward | kTrBackward, n_nodes, n_rel, d, k, batch, h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda,
+                    loss, nullptr, grad_ent, grad_W, grad_rel, want_grad, workspace, workspace_bytes, stream);
+}
+
+int kgat_transr_forward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h, const int32_t* r,
+                            const int32_t* pos_t, const int32_t* neg_t, const float* ent, const float* W_R,
+                            const float* rel, float reg_lambda, float* loss, void* workspace, size_t workspace_bytes,
+                            kgat_stream_t stream) {
+  return transr_run(kTrForward, n_nodes, n_rel, d, k, batch, h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, loss, nullptr,
+                    nullptr, nullptr, nullptr, true, workspace, workspace_bytes, stream);
+}
+
+int kgat_transr_backward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h, const int32_t* r,
+                             const int32_t* pos_t, const int32_t* neg_t, const float* grad_scale, float* grad_ent,
+                             float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
+                             kgat_stream_t stream) {
+  KGAT_CHECK_ARG(grad_ent && grad_W && grad_rel, "transr_backward: null gradient pointer");
+  return transr_run(kTrBackward, n_nodes, n_rel, d, k, batch, h, r, pos_t, neg_t, nullptr, nullptr, nullptr, 0.f, nullptr,
+                    grad_scale, grad_ent, grad_W, grad_rel, true, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

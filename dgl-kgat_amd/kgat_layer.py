@@ -357,8 +357,18 @@ class KGATPropagation(nn.Module):
             off += widths[li]
         return out
 
-    def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids):
-        """BPR loss of reference models.py:170-178 (harness only)."""
+    def get_loss(self, embedding, src_ids, pos_dst_ids, neg_dst_ids, fused=None):
+        """BPR loss of reference models.py:170-178.  On the GPU in fp32 (readout width a multiple of 4): the fused
+        loss / gradient kernels (kgat_bpr_loss_f32, kgat_bpr_grad_f32; ~15 launches forward + backward against ~75
+        torch operator launches, 0.7 ms of the CF step); fused=False (and CPU / float64) takes the torch
+        restatement below, which is what the parity tests compare the kernels with."""
+        if fused is None:
+            fused = (embedding.is_cuda and embedding.dtype == torch.float32 and embedding.dim() == 2 and
+                     embedding.shape[1] % 4 == 0 and embedding.stride(1) == 1 and embedding.stride(0) % 4 == 0 and
+                     src_ids.numel() > 0)
+        if fused:
+            from .autograd import bpr_loss
+            return bpr_loss(embedding, src_ids, pos_dst_ids, neg_dst_ids, self._reg_lambda_gnn)
         # one gather of the three id lists (one dense zero-fill + one sorted scatter in backward
         # instead of three), then split: the same rows as embedding[src_ids] etc.
         b = src_ids.shape[0]

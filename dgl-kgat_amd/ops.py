@@ -403,6 +403,43 @@ def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=Tr
     return loss, g_ent, g_w, g_rel
 
 
+def transr_forward(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda):
+    """TransR loss with the per-sample rows left in the returned workspace for transr_backward
+    (kgat_transr_forward_f32)."""
+    ent = _need(ent, torch.float32, "ent")
+    n_rel, d, k = W_R.shape
+    W_R = _need(W_R, torch.float32, "W_R")
+    rel = _need(rel, torch.float32, "rel", (n_rel, k))
+    h = _need(h, torch.int32, "h")
+    b = h.numel()
+    for name, t in (("r", r), ("pos_t", pos_t), ("neg_t", neg_t)):
+        _need(t, torch.int32, name, (b,))
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=ent.device)
+    ws = _workspace(lib.kgat_transr_workspace_bytes(b, d, k, n_rel), ent.device)
+    with _timed("transr_forward", (b, d, k)):
+        check(lib.kgat_transr_forward_f32(ent.shape[0], n_rel, d, k, b, _ptr(h), _ptr(r), _ptr(pos_t), _ptr(neg_t),
+                                          _ptr(ent), _ptr(W_R), _ptr(rel), float(reg_lambda), _ptr(loss), _ptr(ws),
+                                          ws.numel(), _stream(ent)), "kgat_transr_forward_f32")
+    return loss, ws
+
+
+def transr_backward(h, r, pos_t, neg_t, shapes, ws, grad_scale=None):
+    """The three gradients of transr_forward's loss (kgat_transr_backward_f32), times the device scalar grad_scale."""
+    (n_nodes, d), (n_rel, _, k) = shapes
+    dev = ws.device
+    g_ent = torch.empty((n_nodes, d), dtype=torch.float32, device=dev)
+    g_w = torch.empty((n_rel, d, k), dtype=torch.float32, device=dev)
+    g_rel = torch.empty((n_rel, k), dtype=torch.float32, device=dev)
+    if grad_scale is not None:
+        grad_scale = _need(grad_scale.reshape(1), torch.float32, "grad_scale")
+    with _timed("transr_backward", (h.numel(), d, k)):
+        check(_lib.load().kgat_transr_backward_f32(n_nodes, n_rel, d, k, h.numel(), _ptr(h), _ptr(r), _ptr(pos_t),
+                                                   _ptr(neg_t), _ptr(grad_scale), _ptr(g_ent), _ptr(g_w), _ptr(g_rel),
+                                                   _ptr(ws), ws.numel(), _stream(ws)), "kgat_transr_backward_f32")
+    return g_ent, g_w, g_rel
+
+
 def edge_softmax(indptr, row_of, eid, logits, in_csr_order=False, e_range=None, want_out=True,
                  want_csr=False, three_pass=False):
     """Softmax over each destination's in-edges (`indptr`, `row_of`, `eid` of the destination-major
@@ -839,3 +876,38 @@ def eval_recall_ndcg(emb, user_ids, item_ids, train_ptr, train_items, test_ptr, 
                                             _ptr(topk) if want_topk else None, _stream(emb)),
               "kgat_eval_recall_ndcg_f32")
     return (recall, ndcg, topk) if want_topk else (recall, ndcg)
+
+
+def bpr_loss(emb, u, p, n, reg_lambda):
+    """BPR loss of reference models.py:170-178 on the readout (kgat_bpr_loss_f32).  Returns (loss (0-dim), coef (B,),
+    workspace) - the last two feed bpr_grad."""
+    if emb.dtype != torch.float32 or not emb.is_cuda or emb.dim() != 2 or emb.stride(1) != 1:
+        raise KGATLibraryError("bpr_loss: `emb` must be a float32 HIP matrix with unit column stride")
+    u, p, n = (_need(t, torch.int32, name) for t, name in ((u, "u"), (p, "p"), (n, "n")))
+    b = u.numel()
+    if p.numel() != b or n.numel() != b or b < 1:
+        raise ValueError("bpr_loss: the three id lists must have one common, non-zero length")
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=emb.device)
+    coef = torch.empty(b, dtype=torch.float32, device=emb.device)
+    ws = _workspace(lib.kgat_bpr_workspace_bytes(b), emb.device)
+    with _timed("bpr_loss", (b, emb.shape[1])):
+        check(lib.kgat_bpr_loss_f32(emb.shape[0], emb.shape[1], _ptr(emb), emb.stride(0), b, _ptr(u), _ptr(p), _ptr(n),
+                                    float(reg_lambda), _ptr(loss), _ptr(coef), _ptr(ws), ws.numel(), _stream(emb)),
+              "kgat_bpr_loss_f32")
+    return loss, coef, ws
+
+
+def bpr_grad(emb, u, p, n, coef, reg_lambda, grad_scale=None, workspace=None):
+    """d loss / d emb, dense (N, F), scaled by the device scalar `grad_scale` (kgat_bpr_grad_f32)."""
+    lib = _lib.load()
+    b = u.numel()
+    grad = torch.empty((emb.shape[0], emb.shape[1]), dtype=torch.float32, device=emb.device)
+    if grad_scale is not None:
+        grad_scale = _need(grad_scale.reshape(1), torch.float32, "grad_scale")
+    ws = workspace if workspace is not None else _workspace(lib.kgat_bpr_workspace_bytes(b), emb.device)
+    with _timed("bpr_grad", (b, emb.shape[1])):
+        check(lib.kgat_bpr_grad_f32(emb.shape[0], emb.shape[1], _ptr(emb), emb.stride(0), b, _ptr(u), _ptr(p), _ptr(n),
+                                    _ptr(coef), float(reg_lambda), _ptr(grad_scale), _ptr(grad), _ptr(ws), ws.numel(),
+                                    _stream(emb)), "kgat_bpr_grad_f32")
+    return grad

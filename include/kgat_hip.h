@@ -445,6 +445,20 @@ int kgat_transr_loss_grad_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
                               const float* W_R, const float* rel, float reg_lambda, float* loss, float* grad_ent,
                               float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
                               kgat_stream_t stream);
+/* The same computation in the two halves autograd asks for.  kgat_transr_forward_f32: the loss, with the per-sample
+ * rows and the weight-gradient partials left in `workspace`; kgat_transr_backward_f32 (same batch arrays, same
+ * workspace, untouched in between): the three gradients, multiplied by grad_scale[0] - a DEVICE scalar, the gradient
+ * arriving at the loss (NULL = 1) - inside the final ordered reductions: no host synchronisation and no extra pass
+ * over the dense n_nodes x d gradient (round 4 multiplied the three gradients by it in three torch launches, 22 us
+ * of the 0.3 ms KG step).  Same bits as kgat_transr_loss_grad_f32 for grad_scale = 1. */
+int kgat_transr_forward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h, const int32_t* r,
+                            const int32_t* pos_t, const int32_t* neg_t, const float* ent, const float* W_R,
+                            const float* rel, float reg_lambda, float* loss, void* workspace, size_t workspace_bytes,
+                            kgat_stream_t stream);
+int kgat_transr_backward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h, const int32_t* r,
+                             const int32_t* pos_t, const int32_t* neg_t, const float* grad_scale, float* grad_ent,
+                             float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
+                             kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- evaluation
  * recall@K / ndcg@K of reference metric.py:36-68 (calc_recall_ndcg with one_recall_at_k :5-7, one_dcg_at_k :8-22
@@ -470,6 +484,38 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
                               const int32_t* train_items, const int32_t* test_ptr, const int32_t* test_items, int K,
                               const double* disc, void* workspace, size_t workspace_bytes, double* recall_out,
                               double* ndcg_out, int32_t* topk_out, kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- optimiser of the training loop (8f #1, #3)
+ * One step of torch.optim.Adam (reference kgat.py:85: optim.Adam(model.parameters(), lr); amsgrad off, no weight
+ * decay) over up to kgat_adam_max_tensors() parameter tensors in ONE launch - dense semantics: every element moves,
+ * also where the gradient is zero.  Per element in fp32, in torch's order of operations:
+ *   m <- m + (1 - beta1)(g - m);  v <- v beta2 + (1 - beta2) g g;
+ *   p <- p - (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * `*_host` arrays are HOST arrays of n_tensors entries (device pointers / element counts / the tensor's step count
+ * t >= 1 AFTER this step, which may differ between tensors: a parameter that had no gradient in some steps lags).
+ * zero_grads != 0 also clears the gradients it has read (optimizer.zero_grad(set_to_none=False) in the same pass). */
+int kgat_adam_max_tensors(void);
+int kgat_adam_step_f32(int n_tensors, const int64_t* sizes_host, float* const* params_host, float* const* grads_host,
+                       float* const* exp_avg_host, float* const* exp_avg_sq_host, const int64_t* steps_host, double lr,
+                       double beta1, double beta2, double eps, int zero_grads, kgat_stream_t stream);
+
+/* ---------------------------------------------------------------- BPR loss of the CF phase (8f #1)
+ * reference models.py:170-178 (get_loss; _L2_loss_mean :9-11) on the readout `emb` (n_nodes rows of emb_stride
+ * floats, the first F used; F and emb_stride multiples of 4):
+ *   loss = -mean_b logsigmoid(<s_b,p_b> - <s_b,n_b>) + reg_lambda (mean_b |s_b|^2/2 + mean_b |p_b|^2/2 + mean_b |n_b|^2/2)
+ * with s, p, n = rows u[b], p[b], n[b] (ids in [0, n_nodes); an id outside makes the loss NaN, nothing is accessed).
+ * kgat_bpr_loss_f32: loss (1 float) and coef[batch] = sigmoid(-(x_b)) for the backward.
+ * kgat_bpr_grad_f32: d loss / d emb as a DENSE n_nodes x F matrix (rows outside the batch zero - what torch's
+ * index backward produces), times grad_scale[0] (DEVICE scalar = the gradient arriving at the loss; NULL = 1): rows
+ * that occur several times are summed in sample order after a stable sort of the 3 x batch row ids - fixed order of
+ * additions, no float atomics, bitwise reproducible.  Same workspace size for both. */
+size_t kgat_bpr_workspace_bytes(int64_t batch);
+int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
+                      const int32_t* p, const int32_t* n, float reg_lambda, float* loss, float* coef, void* workspace,
+                      size_t workspace_bytes, kgat_stream_t stream);
+int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
+                      const int32_t* p, const int32_t* n, const float* coef, float reg_lambda, const float* grad_scale,
+                      float* grad, void* workspace, size_t workspace_bytes, kgat_stream_t stream);
 
 #ifdef __cplusplus
 }

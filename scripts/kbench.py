@@ -161,13 +161,13 @@ def main():
         torch.manual_seed(0)
         model = K.KGATPropagation(n, R, D, D, 3, D, dropout=0.1).to(dev)
         graph = synth.build_graph(n, trip, dev)
-        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        opt = K.FusedAdam(model.parameters(), lr=0.01)
         with torch.no_grad():
             graph.edata["w"] = model.compute_attention(graph)
         B = 10240
-        u = torch.randint(0, 70679, (B,), device=dev)
-        pi = torch.randint(70679, 95594, (B,), device=dev)
-        ni = torch.randint(70679, 95594, (B,), device=dev)
+        u = torch.randint(0, 70679, (B,), device=dev).int()
+        pi = torch.randint(70679, 95594, (B,), device=dev).int()
+        ni = torch.randint(70679, 95594, (B,), device=dev).int()
 
         def step():
             loss = model.get_loss(model.gnn(graph), u, pi, ni)
@@ -200,9 +200,13 @@ def main():
         h, r, pt = dst[idx].long(), et[idx].long(), src[idx].long()
         nt = torch.randint(0, n, (B,), device=dev)
 
-        for fused in (True, False, "fused+fusedAdam"):
+        h32, r32, pt32, nt32 = h.int(), r.int(), pt.int(), nt.int()
+        for fused in (True, False, "fused+fusedAdam", "fused+FusedAdam(ours)+int32"):
             if fused == "fused+fusedAdam":
                 opt = torch.optim.Adam(model.parameters(), lr=0.01, fused=True)
+            if fused == "fused+FusedAdam(ours)+int32":
+                opt = K.FusedAdam(model.parameters(), lr=0.01)
+                h, r, pt, nt = h32, r32, pt32, nt32
             def step():
                 loss = model.transR(h, r, pt, nt, fused=bool(fused))
                 loss.backward()
@@ -217,7 +221,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.rounds
-            print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, {True: "fused kernels", False: "torch ops"}.get(fused, "fused kernels + torch's fused Adam"), dt * 1e3))
+            print("KG step (TransR fwd+bwd+Adam, batch %d, %s): %.3f ms" % (B, {True: "fused kernels", False: "torch ops", "fused+fusedAdam": "fused kernels + torch's fused Adam"}.get(fused, "fused kernels + kgat FusedAdam + int32 ids"), dt * 1e3))
     else:
         logits = torch.randn(E, generator=g).to(dev)
         fns = {"softmax_eid": lambda: ops.edge_softmax(indptr, row_of, eid, logits, want_out=True, want_csr=True),

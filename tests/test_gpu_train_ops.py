@@ -1,0 +1,173 @@
+"""Training-step kernels of round 5 against their torch restatements: the fused BPR loss / gradient
+(kgat_bpr_loss_f32, kgat_bpr_grad_f32; reference models.py:170-178) and the one-launch Adam
+(kgat_adam_step_f32; reference kgat.py:85 optim.Adam)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _model(n, dev, F_dims=(64, 3, 64)):
+    import dgl_kgat_amd as K
+    return K.KGATPropagation(n, 4, F_dims[0], F_dims[0], F_dims[1], F_dims[2], dropout=0.0).to(dev)
+
+
+@pytest.mark.parametrize("n,F,B", [(500, 176, 1000), (97, 8, 13), (3000, 48, 10240), (64, 260, 300)])
+def test_bpr_loss_and_gradient_vs_torch(dev, n, F, B):
+    """Loss and d loss / d readout of the fused kernels against the torch restatement of get_loss evaluated in
+    float64 (rows repeated many times inside a batch, every role; the gradient scaled by what arrives at the loss),
+    and bit for bit the same on a second call."""
+    torch.manual_seed(n + F)
+    m = _model(n, dev)
+    emb = torch.randn(n, F, device=dev)
+    u = torch.randint(0, max(n // 3, 1), (B,), device=dev)
+    p = torch.randint(0, n, (B,), device=dev)
+    q = torch.randint(0, n, (B,), device=dev)
+    p[:5] = u[:5]                                   # a row that is source and positive of the same sample
+    outs = []
+    for fused, dt in ((True, torch.float32), (True, torch.float32), (False, torch.float64)):
+        e = emb.to(dt).clone().requires_grad_(True)
+        loss = m.get_loss(e, u, p, q, fused=fused)
+        (loss * 2.5).backward()
+        outs.append((loss.detach().double().cpu().numpy(), e.grad.double().cpu().numpy()))
+    (l0, g0), (l1, g1), (lr, gr) = outs
+    assert np.array_equal(l0, l1) and np.array_equal(g0, g1)          # fixed order of additions
+    assert abs(l0 - lr) <= 2e-6 * abs(lr)
+    scale = np.abs(gr).max()
+    assert np.abs(g0 - gr).max() <= 2e-6 * scale, np.abs(g0 - gr).max() / scale
+    assert np.array_equal(g0 == 0, gr == 0) or np.abs(g0[gr == 0]).max() == 0   # rows outside the batch: exact zeros
+    # int32 ids are taken as they are
+    e = emb.clone().requires_grad_(True)
+    l2 = m.get_loss(e, u.int(), p.int(), q.int())
+    assert float(l2.detach()) == float(l0)
+
+
+def test_bpr_under_the_training_stack(dev):
+    """get_loss(gnn(g)) -> backward through the fused propagation stack: parameter gradients equal to those of the
+    torch-operator loss."""
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.amazon_book_ckg(scale=0.02)
+    torch.manual_seed(5)
+    m = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+    g = synth.build_graph(n, trip, dev)
+    with torch.no_grad():
+        g.edata["w"] = m.compute_attention(g)
+    B = 2048
+    u, p, q = (torch.randint(0, n, (B,), device=dev) for _ in range(3))
+    grads = []
+    for fused in (True, False):
+        m.zero_grad()
+        m.get_loss(m.gnn(g), u, p, q, fused=fused).backward()
+        grads.append([x.grad.clone() for x in m.parameters() if x.grad is not None])
+    assert len(grads[0]) == len(grads[1]) >= 4
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+
+
+def _ulp_diff(a, b):
+    a, b = a.detach().cpu().numpy().ravel(), b.detach().cpu().numpy().ravel()
+    ai, bi = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7fffffff), ai)
+    bi = np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    return int(np.abs(ai - bi).max())
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """Step by step from the same state: parameters and both moments within 1 ulp of torch.optim.Adam's (the same
+    fp32 operations in the same order), over tensors of every alignment / size class, parameters that get a gradient
+    only in some steps (their step count lags), state_dict interchange, and the gradient-clearing variant."""
+    import dgl_kgat_amd as K
+    torch.manual_seed(0)
+    shapes = [(1000, 64), (41, 64, 64), (41, 64), (64, 64), (7,), (1,), (3, 5), (4099,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    our_p = [torch.nn.Parameter(x.detach().clone()) for x in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=0.01)
+    ours = K.FusedAdam(our_p, lr=0.01)
+    worst = 0
+    for it in range(12):
+        for k, (a, b) in enumerate(zip(ref_p, our_p)):
+            if k == 3 and it % 3 != 0:          # a parameter without a gradient in most steps
+                a.grad = b.grad = None
+                continue
+            gscale = 10.0 ** ((it % 5) - 3)
+            gr = torch.randn_like(a) * gscale
+            if k == 0:
+                gr[torch.rand(gr.shape[0], device=dev) < 0.9] = 0     # mostly zero rows: the dense semantics
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        ours.step()
+        for a, b in zip(ref_p, our_p):
+            worst = max(worst, _ulp_diff(a, b))
+            assert _ulp_diff(a, b) <= 1, (it, a.shape, _ulp_diff(a, b))
+            sa, sb = ref.state[a], ours.state[b]
+            if sa:
+                assert float(sa["step"]) == float(sb["step"])
+                assert _ulp_diff(sa["exp_avg"], sb["exp_avg"]) <= 1 and _ulp_diff(sa["exp_avg_sq"], sb["exp_avg_sq"]) <= 1
+            # re-synchronise: the next step starts from identical state (a 1-ulp difference must not accumulate into the bar)
+            with torch.no_grad():
+                b.copy_(a)
+                if sa:
+                    sb["exp_avg"].copy_(sa["exp_avg"]); sb["exp_avg_sq"].copy_(sa["exp_avg_sq"])
+    print("[adam] worst difference over 12 steps x 8 tensors: %d ulp" % worst)
+    # state_dict moves between the two classes
+    sd = copy.deepcopy(ref.state_dict())
+    ours2 = K.FusedAdam([torch.nn.Parameter(x.detach().clone()) for x in ref_p], lr=0.01)
+    ours2.load_state_dict(sd)
+    ref2 = torch.optim.Adam([torch.nn.Parameter(x.detach().clone()) for x in ref_p], lr=0.01)
+    ref2.load_state_dict(copy.deepcopy(ours.state_dict()))
+    # the gradient-clearing variant: same update, gradients zero afterwards
+    z = K.FusedAdam([torch.nn.Parameter(torch.ones(1000, 64, device=dev))], lr=0.1, zero_grads=True)
+    pz = z.param_groups[0]["params"][0]
+    pz.grad = torch.full_like(pz, 2.0)
+    z.step()
+    assert float(pz.grad.abs().max()) == 0 and abs(float(pz[0, 0]) - 0.9) < 1e-6
+    with pytest.raises(NotImplementedError):
+        K.FusedAdam(our_p, lr=0.01, weight_decay=0.1)
+    with pytest.raises(K.KGATLibraryError):
+        cpu = K.FusedAdam([torch.nn.Parameter(torch.ones(3))], lr=0.1)
+        cpu.param_groups[0]["params"][0].grad = torch.ones(3)
+        cpu.step()
+
+
+def test_training_steps_with_fused_loss_and_optimiser(dev):
+    """A few CF and KG steps of the epoch structure (kgat.py:114-168) with FusedAdam and the fused losses: the loss
+    falls, and the parameters stay within rounding of the same steps taken with torch.optim.Adam."""
+    import dgl_kgat_amd as K
+    from dgl_kgat_amd import synth
+    n, trip, R = synth.amazon_book_ckg(scale=0.02)
+    g = synth.build_graph(n, trip, dev)
+    B = 1024
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    one = tuple(torch.randint(0, n, (B,), generator=gen).to(dev) for _ in range(3))
+    batches = [one] * 5          # the same batch every step: the loss has to fall
+    finals, losses = [], []
+    for fused in (True, False):
+        torch.manual_seed(9)
+        m = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+        opt = K.FusedAdam(m.parameters(), lr=0.01) if fused else torch.optim.Adam(m.parameters(), lr=0.01)
+        ls = []
+        for u, p, q in batches:
+            r = (u % R)
+            loss = m.transR(u, r, p, q)
+            loss.backward(); opt.step(); opt.zero_grad()
+            with torch.no_grad():
+                g.edata["w"] = m.compute_attention(g)
+            loss = m.get_loss(m.gnn(g), u, p, q, fused=fused)
+            loss.backward(); opt.step(); opt.zero_grad()
+            ls.append(float(loss))
+        finals.append([x.detach().clone() for x in m.parameters()])
+        losses.append(ls)
+    assert losses[0][-1] < losses[0][0] and losses[1][-1] < losses[1][0], losses
+    assert max(abs(a - b) for a, b in zip(*losses)) <= 1e-3 * abs(losses[1][0]), losses
+    for a, b in zip(*finals):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, float((a - b).abs().max())
