@@ -330,6 +330,41 @@ class KGATPropagation(nn.Module):
         reg = sum((v.pow(2).sum(1) / 2.0).mean() for v in (h_vec, r_vec, pos_vec, neg_vec))
         return loss + reg_lambda_kg * reg
 
+    def kg_step(self, h, r, pos_t, neg_t, optimizer, reg_lambda_kg=0.01):
+        """One iteration of the KG phase (reference kgat.py:116-136: transR -> backward -> optimizer.step ->
+        zero_grad) without the autograd bookkeeping around it: kgat_transr_loss_grad_f32 writes the loss and the three
+        dense gradients into buffers kept with the model, they become the parameters' ``.grad``, ``optimizer.step()``
+        runs (any torch optimiser; FusedAdam makes the whole iteration two library calls), the gradients are dropped.
+        The same kernels on the same data as ``transR(...).backward()``: the same bits.  int32 index tensors are used
+        as they are.  Returns the loss (a 0-dim device tensor; reading it synchronises, as loss.item() does)."""
+        from . import ops
+        ent, W_R, rel = self.entity_embed.weight, self.W_R, self.relation_embed.weight
+        if not (ent.is_cuda and ent.dtype == torch.float32 and ops_transr_supported(self, h)):
+            loss = self.transR(h, r, pos_t, neg_t, reg_lambda_kg)
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            return loss.detach()
+        ids = [t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+               for t in (h, r, pos_t, neg_t)]
+        buf = getattr(self, "_kg_buffers", None)
+        if buf is None or buf[1].shape != ent.shape or buf[1].device != ent.device:
+            buf = self._kg_buffers = [torch.empty((), dtype=torch.float32, device=ent.device), torch.empty_like(ent),
+                                      torch.empty_like(W_R), torch.empty_like(rel), None, -1]
+        if buf[4] is None or buf[5] != ids[0].numel():
+            buf[4:] = [ops.transr_workspace(ids[0].numel(), W_R.shape[1], W_R.shape[2], W_R.shape[0], ent.device),
+                       ids[0].numel()]
+        with torch.no_grad():
+            out = ops.transr_loss_grad(*ids, ent.detach(), W_R.detach(), rel.detach(), reg_lambda_kg, out=buf[:4],
+                                       workspace=buf[4])
+        ent.grad, W_R.grad, rel.grad = buf[1], buf[2], buf[3]
+        for p_ in self.parameters():       # (parameters the KG loss does not reach have no gradient in this phase)
+            if p_ is not ent and p_ is not W_R and p_ is not rel:
+                p_.grad = None
+        optimizer.step()
+        ent.grad = W_R.grad = rel.grad = None
+        return out[0]
+
     def _gnn_fused_sharded(self, g):
         """No-grad path on a destination-range shard: per layer the local aggregation, the
         bi-interaction kernel on the owned rows, one all-reduce, and the row normalisation of the

@@ -375,11 +375,15 @@ def transr_supported(n_nodes, d, k, n_rel, batch):
     return bool(_lib.load().kgat_transr_supported(int(n_nodes), int(d), int(k), int(n_rel), int(batch)))
 
 
-def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=True):
+def transr_workspace(batch, d, k, n_rel, device):
+    return _workspace(_lib.load().kgat_transr_workspace_bytes(batch, d, k, n_rel), device)
+
+
+def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=True, out=None, workspace=None):
     """TransR loss of a triplet batch and, if want_grad, its gradients with respect to the entity
     table (dense), W_R and the relation table (kgat_transr_loss_grad_f32).  Index tensors are
     int32.  Returns (loss 0-d tensor, grad_ent, grad_W, grad_rel) - gradients None without
-    want_grad."""
+    want_grad.  `out` = (loss, grad_ent, grad_W, grad_rel) and `workspace` reuse buffers of an earlier call."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
@@ -390,11 +394,18 @@ def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=Tr
         _need(t, torch.int32, name, (b,))
     lib = _lib.load()
     dev = ent.device
-    loss = torch.empty((), dtype=torch.float32, device=dev)
-    g_ent = torch.empty_like(ent) if want_grad else None
-    g_w = torch.empty_like(W_R) if want_grad else None
-    g_rel = torch.empty_like(rel) if want_grad else None
-    ws = _workspace(lib.kgat_transr_workspace_bytes(b, d, k, n_rel), dev)
+    if out is not None:
+        loss, g_ent, g_w, g_rel = out
+        _need(g_ent, torch.float32, "grad_ent", ent.shape)
+        _need(g_w, torch.float32, "grad_W", W_R.shape)
+        _need(g_rel, torch.float32, "grad_rel", rel.shape)
+    else:
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        g_ent = torch.empty_like(ent) if want_grad else None
+        g_w = torch.empty_like(W_R) if want_grad else None
+        g_rel = torch.empty_like(rel) if want_grad else None
+    need = lib.kgat_transr_workspace_bytes(b, d, k, n_rel)
+    ws = workspace if workspace is not None and workspace.numel() >= need else _workspace(need, dev)
     with _timed("transr", (b, d, k)):
         check(lib.kgat_transr_loss_grad_f32(ent.shape[0], n_rel, d, k, b, _ptr(h), _ptr(r), _ptr(pos_t), _ptr(neg_t),
                                             _ptr(ent), _ptr(W_R), _ptr(rel), float(reg_lambda), _ptr(loss),

@@ -171,3 +171,33 @@ def test_training_steps_with_fused_loss_and_optimiser(dev):
     assert max(abs(a - b) for a, b in zip(*losses)) <= 1e-3 * abs(losses[1][0]), losses
     for a, b in zip(*finals):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, float((a - b).abs().max())
+
+
+def test_kg_step_same_bits_as_the_autograd_path(dev):
+    """KGATPropagation.kg_step (loss + gradients written straight into .grad, then the optimiser) against
+    transR(...).backward(); optimizer.step(): the same parameters bit for bit after several iterations, with
+    FusedAdam and with torch.optim.Adam, int64 and int32 ids."""
+    import dgl_kgat_amd as K
+    n, R, B = 4000, 7, 1500
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    batches = [tuple(torch.randint(0, hi, (B,), generator=gen).to(dev) for hi in (n, R, n, n)) for _ in range(4)]
+    for opt_cls in (K.FusedAdam, torch.optim.Adam):
+        finals = []
+        for direct in (True, False):
+            torch.manual_seed(3)
+            m = K.KGATPropagation(n, R, 64, 64, 2, 64, dropout=0.0).to(dev)
+            opt = opt_cls(m.parameters(), lr=0.01)
+            losses = []
+            for i, (h, r, pt, nt) in enumerate(batches):
+                if direct:
+                    ids = (h.int(), r.int(), pt.int(), nt.int()) if i % 2 else (h, r, pt, nt)
+                    losses.append(float(m.kg_step(*ids, opt, reg_lambda_kg=1e-3)))
+                else:
+                    loss = m.transR(h, r, pt, nt, reg_lambda_kg=1e-3)
+                    loss.backward(); opt.step(); opt.zero_grad()
+                    losses.append(float(loss.detach()))
+            finals.append(([p.detach().clone() for p in m.parameters()], losses))
+            assert all(p.grad is None for p in m.parameters())
+        for a, b in zip(finals[0][0], finals[1][0]):
+            assert torch.equal(a, b)
+        assert finals[0][1] == finals[1][1]
