@@ -231,6 +231,12 @@ def _build_locked(force):
     return SO_PATH
 
 
+def _under_profiler():
+    """rocprofv3 / rocprof run their target with a tool library preloaded (and ROCPROF* / ROCP_* variables set)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre.lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ)
+
+
 def load():
     """dlopen libkgat_hip.so and bind every declared symbol.  `import torch` must have
     happened first so that libamdhip64 resolves to the runtime torch already loaded (one HIP
@@ -242,6 +248,12 @@ def load():
         return _lib
     import torch  # noqa: F401  (loads torch's libamdhip64.so first)
     if needs_build():
+        if _under_profiler():
+            # a rebuild would spawn hipcc from inside the profiled process: its children inherit the profiler's
+            # preload, which initialises the GPU before hipcc execs clang - the launcher hop this pool forbids
+            raise KGATLibraryError(
+                "libkgat_hip.so (%s) is missing or stale and this process runs under a profiler preload: build first "
+                "(`python -c 'import __graft_entry__ as g; g.build()'`), then profile" % SO_PATH)
         try:
             build()
         except (OSError, subprocess.CalledProcessError) as e:

@@ -181,20 +181,15 @@ static int launch_att_mfma(const AttArgs& a) {
   return KGAT_OK;
 }
 
-// variant bits (A/B tuning): bit 0 = one 16-edge tile per wave step of the chunk kernel
-// (default two, except d = 128), bit 1 = device-library tanhf instead of the exp2/rcp form,
-// bit 2 = workgroup-chunk kernel (W_r in LDS) instead of the persistent-wavefront kernel,
-// bit 3 = force one persistent wave per SIMD (default: what the occupancy query admits).
+// The MFMA forms of the one-kernel attention: persistent wavefronts with W_r in registers (d <= 64), or - at d = 128,
+// beyond kAttMaxRelLds relations, for tables of 4 GiB and more, and when asked for (KGAT_ATT_ALGO_MFMA_CHUNK) - the
+// workgroup-chunk kernel with W_r in LDS (two 16-edge tiles per wave step; one at d = 128).
 template <int D_>
-static int dispatch_att_variant(AttArgs a, int variant) {
-  const bool one_tile = (variant & 1) || D_ >= 128;
-  const bool acc = variant & 2;
-  const bool chunk = (variant & 4) || D_ >= 128 || a.n_rel > kAttMaxRelLds || a.table_bytes >= (1ull << 32);
-  a.waves_per_simd = (variant & 8) ? 1 : 0;  // 0 = as many as are resident
-  if (D_ <= 64 && !chunk) return launch_att_persistent_any(D_, acc, a);
-  if (one_tile) return acc ? launch_att_mfma<D_, D_, 1, 1>(a) : launch_att_mfma<D_, D_, 1, 0>(a);
-  if constexpr (D_ < 128) return acc ? launch_att_mfma<D_, D_, 2, 1>(a) : launch_att_mfma<D_, D_, 2, 0>(a);
-  return KGAT_E_UNSUPPORTED;
+static int dispatch_att_mfma(const AttArgs& a, bool force_chunk) {
+  const bool chunk = force_chunk || D_ >= 128 || a.n_rel > kAttMaxRelLds || a.table_bytes >= (1ull << 32);
+  if (D_ <= 64 && !chunk) return launch_att_persistent_any(D_, a);
+  if constexpr (D_ >= 128) return launch_att_mfma<D_, D_, 1, 0>(a);
+  else return launch_att_mfma<D_, D_, 2, 0>(a);
 }
 
 // Per-edge half of the folded form (head half: att_fold_head_kernel): logit = e_t . V[group].
@@ -450,16 +445,13 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
   if (n_edges == 0) return KGAT_OK;
   KGAT_CHECK_ARG(logits != nullptr, "att_score: logits is null");
   KGAT_CHECK_ARG(logits_csr == nullptr || pos_g != nullptr, "att_score: logits_csr needs pos_g");
-  KGAT_CHECK_ARG((algo >= KGAT_ATT_ALGO_AUTO && algo <= KGAT_ATT_ALGO_GENERIC) ||
-                     (algo >= KGAT_ATT_ALGO_VARIANT_BASE && algo < KGAT_ATT_ALGO_VARIANT_BASE + 16),
-                 "att_score: bad algo");
+  KGAT_CHECK_ARG(algo >= KGAT_ATT_ALGO_AUTO && algo <= KGAT_ATT_ALGO_MFMA_CHUNK, "att_score: bad algo");
   hipStream_t st = as_stream(stream);
   // edges whose type is outside [0, R) keep logit 0 (DGL zero-initialised column): the
   // persistent kernel clears that tail itself, the other kernels rely on a memset
   const bool persistent = (d == k) && (d == 16 || d == 32 || d == 64) && n_rel > 0 &&
                           n_rel <= kAttMaxRelLds && (unsigned long long)n_nodes * d * 4ull < (1ull << 32) &&
-                          (algo == KGAT_ATT_ALGO_AUTO || algo == KGAT_ATT_ALGO_MFMA ||
-                           (algo >= KGAT_ATT_ALGO_VARIANT_BASE && !((algo - KGAT_ATT_ALGO_VARIANT_BASE) & 4)));
+                          (algo == KGAT_ATT_ALGO_AUTO || algo == KGAT_ATT_ALGO_MFMA);
   if (!persistent) {
     hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)n_edges, st);
     if (e == hipSuccess && logits_csr) e = hipMemsetAsync(logits_csr, 0, sizeof(float) * (size_t)n_edges, st);
@@ -479,21 +471,18 @@ int kgat_att_score_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel
   a.n_edges = n_edges;
   const unsigned grid = a.grid;
   const bool mfma_ok = (d == k) && (d == 16 || d == 32 || d == 64 || d == 128);
-  int variant = 0;
-  if (algo >= KGAT_ATT_ALGO_VARIANT_BASE) {
-    variant = algo - KGAT_ATT_ALGO_VARIANT_BASE;
-    algo = KGAT_ATT_ALGO_MFMA;
-  }
+  const bool force_chunk = algo == KGAT_ATT_ALGO_MFMA_CHUNK;
+  if (force_chunk) algo = KGAT_ATT_ALGO_MFMA;
   if (algo == KGAT_ATT_ALGO_MFMA && !mfma_ok) {
     set_error("att_score: the MFMA kernel covers d == k in {16,32,64,128}, got d=%d k=%d", d, k);
     return KGAT_E_UNSUPPORTED;
   }
   if (mfma_ok && algo != KGAT_ATT_ALGO_GENERIC) {
     switch (d) {
-      case 16: return dispatch_att_variant<16>(a, variant);
-      case 32: return dispatch_att_variant<32>(a, variant);
-      case 64: return dispatch_att_variant<64>(a, variant);
-      default: return dispatch_att_variant<128>(a, variant);
+      case 16: return dispatch_att_mfma<16>(a, force_chunk);
+      case 32: return dispatch_att_mfma<32>(a, force_chunk);
+      case 64: return dispatch_att_mfma<64>(a, force_chunk);
+      default: return dispatch_att_mfma<128>(a, force_chunk);
     }
   }
   const size_t lds = sizeof(float) * (size_t)d * k;

@@ -89,7 +89,6 @@ struct AttArgs {
   const float *ent, *W_R, *rel;
   float *logits, *logits_csr;
   const int32_t* pos_g;
-  int waves_per_simd = 0;
   // split form (head groups): gid per grouped position, gptr per relation, g_node per group,
   // G table (n_groups x k)
   const int32_t *gid = nullptr, *gptr = nullptr, *g_node = nullptr;
@@ -106,7 +105,7 @@ struct AttArgs {
 
 // kgat_att_persistent.hip (compiled with -amdgpu-mfma-vgpr-form: its epilogue reads the MFMA
 // results from VGPRs directly); returns KGAT_E_UNSUPPORTED for widths it does not cover.
-int launch_att_persistent_any(int d, bool accurate_tanh, const AttArgs& a);
+int launch_att_persistent_any(int d, const AttArgs& a);
 int launch_att_split_any(int d, const AttArgs& a);
 int launch_att_fold_head_any(int d, const AttArgs& a);
 int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);  // writes V (n_groups x d) into a.G_tab

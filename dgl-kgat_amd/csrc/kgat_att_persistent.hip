@@ -204,7 +204,7 @@ static int launch_att_persistent(const AttArgs& a) {
       nb = 1;
     blocks_per_cu = nb > 8 ? 8 : nb;
   }
-  const int per_cu = a.waves_per_simd > 0 ? a.waves_per_simd : blocks_per_cu;
+  const int per_cu = blocks_per_cu;
   const unsigned grid = (unsigned)(cus * per_cu);  // 4 waves per block, one per SIMD
   hipLaunchKernelGGL((att_score_persistent_kernel<D_, ACC_TANH>), dim3(grid), dim3(kAttThreads), 0, a.st,
                      a.n_rel, a.n_edges, a.rel_ptr, a.perm, a.src_g, a.dst_g, a.ent, a.W_R, a.rel, a.logits,
@@ -223,9 +223,6 @@ static int launch_att_persistent(const AttArgs& a) {
 // arithmetic per edge is unchanged (same fma chains, same reduction order), so results are
 // bit-identical to the one-kernel form.
 constexpr int MODE_HEAD = 1, MODE_TAIL = 2;
-#ifndef KGAT_ATT_SPLIT_RING
-#define KGAT_ATT_SPLIT_RING 1
-#endif
 
 template <int D_, int MODE, bool LOGITS_EID>
 __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
@@ -383,7 +380,6 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
       }
     };
 
-#if KGAT_ATT_SPLIT_RING
     // Three-deep ring: step n computes tile n while the rows of tiles n+1 and n+2 are in
     // flight (a tile is ~2,700 cycles of issue here, less than the gather latency under load,
     // so one tile of look-ahead is not enough).  Inside a step the small index loads are
@@ -422,19 +418,6 @@ __global__ __launch_bounds__(kAttThreads) void att_split_kernel(
       KGAT_SPLIT_STEP(b2, b1)
     }
 #undef KGAT_SPLIT_STEP
-#else
-    // no software prefetch: latency is hidden by wavefront-level parallelism (the register
-    // budget of this form admits 3-4 waves per SIMD)
-    for (int32_t n = 0; n < n_seg; ++n) {
-      LIdx l;
-      OIdx o;
-      Buf b;
-      load_l(n, l);
-      load_o(n, o);
-      load_rows(b, l);
-      tile(n, b, o);
-    }
-#endif
     t = seg_end;
   }
 }
@@ -650,24 +633,6 @@ static int launch_att_fold_head(const AttArgs& a) {
   return KGAT_OK;
 }
 
-#ifdef KGAT_ATT_STAMPS
-// Diagnostic build only (-DKGAT_ATT_STAMPS, scripts/micro/att_stamps.py): start / end s_memtime of
-// every workgroup of the fused kernel.  Never compiled into the shipped library.
-__device__ unsigned long long* g_att_stamps = nullptr;
-#define KGAT_ATT_STAMP(k)                                                               \
-  do {                                                                                  \
-    if (g_att_stamps && threadIdx.x == 0)                                               \
-      g_att_stamps[(size_t)blockIdx.x * 2 + (k)] = __builtin_amdgcn_s_memtime();        \
-  } while (0)
-// per-wave phase totals: [workgroup][wave][issue, mfma, first chunk, later chunks, tiles]
-__device__ unsigned long long* g_att_phases = nullptr;
-#define KGAT_ATT_PHASE_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define KGAT_ATT_PHASE_ADD(k, a, b) ph[k] += (b) - (a)
-#else
-#define KGAT_ATT_STAMP(k) do { } while (0)
-#define KGAT_ATT_PHASE_T(var) do { } while (0)
-#define KGAT_ATT_PHASE_ADD(k, a, b) do { } while (0)
-#endif
 
 // Products at fp32 accuracy on the bf16 matrix pipe (X3 = true in the kernels below; d = k a
 // multiple of 32).  Every fp32 operand x is cut into three bf16 pieces x = h + m + l by rounding to
@@ -718,7 +683,7 @@ __device__ __forceinline__ floatx4 mfma_bf16(const uintx4& a, const uintx4& b, c
                                                  0);
 }
 
-// fp16 pieces for the second product of the d <= 64 fused kernel (KGAT_ATT_F16_SECOND, default 1 since round 4;
+// fp16 pieces for the second product of the d <= 64 fused kernel (kAttF16Second, default 1 since round 4;
 // built and measured in round 3: W_r * 2^shift as three fp16 pieces, the tanh values * 2^14 as two, five piece
 // products).  Measured on the amazon-book graph, d = 64: stand-alone 0.1555 vs 0.1614 ms, inside the step 137.3 vs
 // 140.6 us; against fp64 max error 9.98e-7 / mean 1.09e-7 (three-bf16-piece form: 9.4e-7 / 1.23e-7; fp32 MFMA:
@@ -787,7 +752,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
     int n_rel, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
     float* __restrict__ V_tab) {
-  KGAT_ATT_STAMP(0);
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFoldLdsThreads / kWave;
   // X3: one image of W_r per bf16 piece, [row d][column k] with 256-byte rows whose 16-byte
@@ -820,9 +784,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
   const int i = lane & 15, q = lane >> 4;
   const int32_t t_begin = (int32_t)((int64_t)n_tiles * blockIdx.x / gridDim.x);
   const int32_t t_end = (int32_t)((int64_t)n_tiles * (blockIdx.x + 1) / gridDim.x);
-#ifdef KGAT_ATT_STAMPS
-  unsigned long long ph[5] = {0, 0, 0, 0, 0};
-#endif
 
   struct Buf { float a[KS]; };
   auto load_rows = [&](Buf& f, int32_t row) {
@@ -880,7 +841,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
       return g_node[g];
     };
     auto tile = [&](int32_t n, const Buf& f) {
-      KGAT_ATT_PHASE_T(pt0);
       floatx4 acc[KT];
 #pragma unroll
       for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -941,7 +901,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
             acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[16 * c], f.a[s], acc[c], 0, 0, 0);
         }
       }
-      KGAT_ATT_PHASE_T(pt1);
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
         const float4 rv = *reinterpret_cast<const float4*>(s_rel + 16 * c + 4 * q);
@@ -953,7 +912,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
 #pragma unroll
       for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_sched_barrier(0);
-      KGAT_ATT_PHASE_T(pt2);
       if (X3) {
         // Second product, V^T = W T: row 16c2 + i of the image, contraction index
         // 32s + 16 (jj / 4) + 4q + jj % 4 = accumulator tile 2s + jj / 4, register jj % 4.
@@ -1009,7 +967,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
           }
       }
       __builtin_amdgcn_sched_barrier(0);
-      KGAT_ATT_PHASE_T(pt3);
       const int32_t g = rbeg + ((n - tfirst) << 4) + i;
       if (g < rend) {
 #pragma unroll
@@ -1019,10 +976,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
           *reinterpret_cast<float4*>(V_tab + (size_t)g * D_ + 16 * c2 + 4 * q) = o;
         }
       }
-      KGAT_ATT_PHASE_T(pt4);
-      KGAT_ATT_PHASE_ADD(0, pt0, pt1); KGAT_ATT_PHASE_ADD(1, pt1, pt2);
-      KGAT_ATT_PHASE_ADD(2, pt2, pt3); KGAT_ATT_PHASE_ADD(3, pt3, pt4);
-      KGAT_ATT_PHASE_ADD(4, 0, 1);
     };
     int32_t n = t + w;
     if (n < seg_end) {
@@ -1048,12 +1001,6 @@ __global__ __launch_bounds__(kFoldLdsThreads) void att_fold_head_lds_kernel(
     }
     t = seg_end;
   }
-#ifdef KGAT_ATT_STAMPS
-  if (g_att_phases && lane == 0)
-    for (int k2 = 0; k2 < 5; ++k2) g_att_phases[((size_t)blockIdx.x * NW + w) * 5 + k2] = ph[k2];
-  __syncthreads();
-  KGAT_ATT_STAMP(1);
-#endif
 }
 
 template <int D_>
@@ -1081,25 +1028,17 @@ static int launch_att_fold_head_lds(const AttArgs& a) {
 // with their indices requested one chunk ahead; their tail rows are not (the row buffer is 64
 // registers), so tiles are capped and hub groups recompute V per `cap` positions instead.
 constexpr int kFusedThreads = 512;
-// KGAT_ATT_XCD_REMAP=1: every XCD a contiguous eighth of the workgroups' tile ranges (xcd_contiguous, kgat_common.h)
+// kAttXcdRemap: every XCD a contiguous eighth of the workgroups' tile ranges (xcd_contiguous, kgat_common.h)
 // - neighbouring ranges, which share head nodes and relation tables, behind one L2.  Stand-alone within the noise at
 // d = 64 (0.172 vs 0.176 ms, round 3); in the step 0.4116 -> 0.4098 and 0.4121 -> 0.4107 ms on two boxes
 // (profiles/r04_step_ab_cache_policy.txt): default since round 4 for d <= 64.  2 % slower at d = 128
-// (KGAT_ATT128_XCD_REMAP, off).
-#ifndef KGAT_ATT_XCD_REMAP
-#define KGAT_ATT_XCD_REMAP 1
-#endif
-#ifndef KGAT_ATT128_XCD_REMAP
-#define KGAT_ATT128_XCD_REMAP 0
-#endif
-// KGAT_ATT_REC_NT (A/B arm, bit 1: the packed position records - 4 bytes per edge, read once per step - as
-// non-temporal loads; bit 2: the head-group node ids too).  With round-robin tile ranges bit 1 gained 2.5 us per step
-// (0.4178 -> 0.4153 ms); with the XCD-contiguous ranges above it LOSES 1.2-1.6 us (0.4108 vs 0.4096, 0.4121 vs
-// 0.4105: profiles/r04_step_ab_cache_policy.txt) - off.
-#ifndef KGAT_ATT_REC_NT
-#define KGAT_ATT_REC_NT 0
-#endif
-
+// (kAtt128XcdRemap, off).
+constexpr int kAttXcdRemap = 1;
+constexpr int kAtt128XcdRemap = 0;
+// (Round 4 also measured the packed position records - 4 bytes per edge, read once per step - and the head-group
+// node ids as non-temporal loads: with round-robin tile ranges the records gained 2.5 us per step (0.4178 -> 0.4153 ms),
+// with the XCD-contiguous ranges above they LOSE 1.2-1.6 us (0.4108 vs 0.4096, 0.4121 vs 0.4105:
+// profiles/r04_step_ab_cache_policy.txt): plain loads.)
 
 // X3: the two products as bf16-piece products (above); W_r's pieces sit in LDS already in fragment
 // order, one 16-byte read per lane per fragment.
@@ -1122,7 +1061,6 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   constexpr int K_ = D_;
   constexpr int KS = D_ / 4, KT = K_ / 16, LD = K_ + 4, NW = kFusedThreads / kWave;
   constexpr int LPE = kFusedLanesPerEdge<D_>();    // lanes per edge in the edge phase
-  KGAT_ATT_STAMP(0);
   constexpr int VPL = D_ / (4 * LPE);             // float4 pieces of a row per lane
   constexpr int LDV = D_ + 4;
   static_assert(D_ <= 64, "one float4 per lane per row");
@@ -1134,10 +1072,8 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   __shared__ uintx4 s_a[X3 ? 2 * 3 * NFRAG : 1];
   __shared__ __attribute__((aligned(16))) float s_v[NW][16 * LDV];
   __shared__ int32_t s_next;  // next unclaimed tile of the current relation segment
-#ifndef KGAT_ATT_F16_SECOND
-#define KGAT_ATT_F16_SECOND 1  // default since round 4 (-3.3 us in the step at equal error; 0: three bf16 pieces on both products)
-#endif
-  constexpr bool F16B = X3 && KGAT_ATT_F16_SECOND != 0;  // second product on fp16 pieces: W_r three, tanh values two
+constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step at equal error; 0: three bf16 pieces on both products)
+  constexpr bool F16B = X3 && kAttF16Second != 0;  // second product on fp16 pieces: W_r three, tanh values two
   __shared__ unsigned s_wmax;                             // F16B: bits of max |W_r| of the current relation
   const int tid = threadIdx.x;
   const int lane = tid % kWave, w = tid / kWave;
@@ -1155,13 +1091,10 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
   }
   const int32_t n_tiles = rel_tptr[n_rel];
   // the workgroup's contiguous tile range: cost balanced (kgat_fold_tile_parts) or equal counts
-  const unsigned part = KGAT_ATT_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const unsigned part = kAttXcdRemap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
   const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
-#ifdef KGAT_ATT_STAMPS
-  unsigned long long ph[5] = {0, 0, 0, 0, 0};
-#endif
 
   int32_t t = t_begin;
   while (t < t_end) {  // workgroup-uniform loop over relation segments
@@ -1252,21 +1185,13 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     auto head_idx = [&](const int4& d) -> int32_t {
       int32_t g = d.y + i;
       g = g < rend ? g : rend - 1;
-#if KGAT_ATT_REC_NT & 2
-      return __builtin_nontemporal_load(g_node + g);
-#else
       return g_node[g];
-#endif
     };
     auto chunk_idx = [&](const int4& d, int32_t p0) -> CIdx {
       int32_t p = p0 + lane;
       p = p < d.w ? p : d.w - 1;
       CIdx c;
-#if KGAT_ATT_REC_NT & 1
-      const uint32_t rec = (uint32_t)__builtin_nontemporal_load(rec_g + p);
-#else
       const uint32_t rec = (uint32_t)rec_g[p];
-#endif
       // byte offset of the source row: N * d * 4 < 4 GiB (checked by the caller), so the node id ends
       // below bit 32 - ROW_SHIFT and the shift drops exactly the slot bits
       c.row_off = (int32_t)(rec << ROW_SHIFT);
@@ -1452,7 +1377,6 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
       load_head(hb0, h0);
 #define KGAT_FUSED_STEP(HCUR, HNEXT)                                                   \
       {                                                                                \
-        KGAT_ATT_PHASE_T(pt0);                                                         \
         const int32_t n3 = claim();                                                    \
         const int4 d3 = desc_of(n3);                                                   \
         const int32_t h2 = head_idx(d2);                                               \
@@ -1467,13 +1391,10 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
         load_edges(eb0, c0);                                                           \
         load_head(HNEXT, h1);                                                          \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        KGAT_ATT_PHASE_T(pt1);                                                         \
         mfma_phase(HCUR);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        KGAT_ATT_PHASE_T(pt2);                                                         \
         edge_phase(eb0, c0, d0.z, d0.w);                                               \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        KGAT_ATT_PHASE_T(pt3);                                                         \
         if (d0.z + kWave < d0.w) {                                                     \
           load_edges(eb0, cx);                                                         \
           edge_phase(eb0, cx, d0.z + kWave, d0.w);                                     \
@@ -1494,10 +1415,6 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
           }                                                                            \
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        KGAT_ATT_PHASE_T(pt4);                                                         \
-        KGAT_ATT_PHASE_ADD(0, pt0, pt1); KGAT_ATT_PHASE_ADD(1, pt1, pt2);              \
-        KGAT_ATT_PHASE_ADD(2, pt2, pt3); KGAT_ATT_PHASE_ADD(3, pt3, pt4);              \
-        KGAT_ATT_PHASE_ADD(4, 0, 1);                                                   \
         d0 = d1; d1 = d2; d2 = d3;                                                     \
         h1 = h2;                                                                       \
         c0 = c1;                                                                       \
@@ -1513,12 +1430,6 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     }
     t = seg_end;
   }
-#ifdef KGAT_ATT_STAMPS
-  if (g_att_phases && lane == 0)
-    for (int k2 = 0; k2 < 5; ++k2) g_att_phases[((size_t)blockIdx.x * NW + w) * 5 + k2] = ph[k2];
-  __syncthreads();
-  KGAT_ATT_STAMP(1);
-#endif
 }
 
 template <int D_, int OUT, bool X3>
@@ -1536,23 +1447,10 @@ static void launch_att_fold_fused_out(const AttArgs& a, const int32_t* rel_tptr,
   else launch_att_fold_fused_form<D_, 0, X3>(a, rel_tptr, tiles);
 }
 
-#ifdef KGAT_ATT_WAVE_ROLES
-template <int D_>
-static void launch_att_fold_ws(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);
-#endif
 
 template <int D_>
 static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
   constexpr bool kCanSplit = D_ % 32 == 0;
-#ifdef KGAT_ATT_WAVE_ROLES
-  if constexpr (D_ == 64) {
-    if (!a.f32_products && !a.logits && !a.logits_csr && a.logits_g && !getenv("KGAT_ATT_NO_WAVE_ROLES")) {
-      launch_att_fold_ws<64>(a, rel_tptr, tiles);
-      KGAT_CHECK_LAUNCH("att_fold_ws");
-      return KGAT_OK;
-    }
-  }
-#endif
   if (kCanSplit && !a.f32_products) launch_att_fold_fused_out<D_, kCanSplit>(a, rel_tptr, tiles);
   else launch_att_fold_fused_out<D_, false>(a, rel_tptr, tiles);
   KGAT_CHECK_LAUNCH("att_fold_fused");
@@ -1586,10 +1484,8 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
   constexpr int D_ = 128, K_ = 128, KS = D_ / 4, KT = K_ / 16, NW = kFused128Threads / kWave;
   constexpr int S3 = D_ / 32, ROWB = D_ * 2, IMG = D_ * ROWB;
   constexpr int LPE = 8, VPL = D_ / (4 * LPE);
-#ifndef KGAT_F128_PASSES
-#define KGAT_F128_PASSES 2
-#endif
-  constexpr int NPASS = KGAT_F128_PASSES, HALF = LPE / NPASS;  // row-gather passes per 64-position chunk
+constexpr int kF128Passes = 2;
+  constexpr int NPASS = kF128Passes, HALF = LPE / NPASS;  // row-gather passes per 64-position chunk
   constexpr bool LOGITS_EID = OUT == 2;
   constexpr int ROW_SHIFT = 9;  // 512-byte rows
   __shared__ __attribute__((aligned(16))) unsigned char s_img[3 * IMG];
@@ -1609,7 +1505,7 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
     }
   }
   const int32_t n_tiles = rel_tptr[n_rel];
-  const unsigned part = KGAT_ATT128_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const unsigned part = kAtt128XcdRemap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
   const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
@@ -1871,9 +1767,6 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
 }
 
 // Round 3's wave-role experiments (producer / consumer waves; measured, not adopted - notes in the file)
-#ifdef KGAT_ATT_WAVE_ROLES
-#include "../../scripts/micro/att_wave_roles_experiment.h"  // measured and rejected (round 3); not product code, not in the build hash
-#endif
 
 template <int OUT>
 static void launch_att_fold_fused128_form(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
@@ -1884,13 +1777,6 @@ static void launch_att_fold_fused128_form(const AttArgs& a, const int32_t* rel_t
 }
 
 static int launch_att_fold_fused128(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
-#ifdef KGAT_ATT_WAVE_ROLES
-  if (!a.logits && !a.logits_csr && a.logits_g && !getenv("KGAT_ATT_NO_WAVE_ROLES")) {
-    launch_att_fold_roles128(a, rel_tptr, tiles);
-    KGAT_CHECK_LAUNCH("att_fold_roles128");
-    return KGAT_OK;
-  }
-#endif
   if (a.logits) launch_att_fold_fused128_form<2>(a, rel_tptr, tiles);
   else if (a.logits_csr) launch_att_fold_fused128_form<1>(a, rel_tptr, tiles);
   else launch_att_fold_fused128_form<0>(a, rel_tptr, tiles);
@@ -1898,14 +1784,6 @@ static int launch_att_fold_fused128(const AttArgs& a, const int32_t* rel_tptr, c
   return KGAT_OK;
 }
 
-#ifdef KGAT_ATT_STAMPS
-extern "C" int kgat_debug_set_att_stamps(void* dev_ptr) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
-}
-extern "C" int kgat_debug_set_att_phases(void* dev_ptr) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_att_phases), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
-}
-#endif
 
 int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
   switch (d) {
@@ -1936,11 +1814,11 @@ int launch_att_split_any(int d, const AttArgs& a) {
   }
 }
 
-int launch_att_persistent_any(int d, bool acc, const AttArgs& a) {
+int launch_att_persistent_any(int d, const AttArgs& a) {
   switch (d) {
-    case 16: return acc ? launch_att_persistent<16, 1>(a) : launch_att_persistent<16, 0>(a);
-    case 32: return acc ? launch_att_persistent<32, 1>(a) : launch_att_persistent<32, 0>(a);
-    case 64: return acc ? launch_att_persistent<64, 1>(a) : launch_att_persistent<64, 0>(a);
+    case 16: return launch_att_persistent<16, 0>(a);
+    case 32: return launch_att_persistent<32, 0>(a);
+    case 64: return launch_att_persistent<64, 0>(a);
     default: return KGAT_E_UNSUPPORTED;
   }
 }

@@ -31,20 +31,8 @@ __device__ __forceinline__ float row16_sum_d(float v) {
   return v;
 }
 
-#ifndef KGAT_BI_MUL_AT_LOAD
-#define KGAT_BI_MUL_AT_LOAD 0   // A/B builds: the first form of MODE >= 1 (h * h_N multiplied in the load step)
-#endif
-#define KGAT_BI_MUL_AT_LOAD_V (KGAT_BI_MUL_AT_LOAD != 0)
-#ifndef KGAT_BI_NT_LOADS
-#define KGAT_BI_NT_LOADS 0   // A/B builds, bit mask: 1 = the rows of H (P), 2 = the rows of HN as non-temporal loads
-#endif
-#ifndef KGAT_BI_NT_STORES
-// The normalised slice and the ego block - the readout, which nothing in the step reads again - leave as non-temporal
-// stores.  Stand-alone launches do not change (profiles/r04_bi_probe.txt); the STEP does: 0.4236 -> 0.4078 ms
-// (profiles/r04_step_ab_cache_policy.txt) - the 112 MB readout no longer pushes the embedding table, the layer's rows
-// and the edge records out of the 256 MiB Infinity Cache before the next launches gather from them.
-#define KGAT_BI_NT_STORES 1
-#endif
+constexpr bool kBiMulAtLoad = false;   // (true: the first form of MODE >= 1, h * h_N multiplied in the load step - round 4's A/B)
+constexpr int kBiNtLoads = 0;   // A/B builds, bit mask: 1 = the rows of H (P), 2 = the rows of HN as non-temporal loads
 template <bool NT>
 __device__ __forceinline__ float4 ld_row4(const float4* p) {
   if constexpr (NT) {
@@ -55,12 +43,8 @@ __device__ __forceinline__ float4 ld_row4(const float4* p) {
   }
 }
 __device__ __forceinline__ void st_final4(float4* p, const float4& v) {
-#if KGAT_BI_NT_STORES
   const floatx4_d x = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(x, reinterpret_cast<floatx4_d*>(p));
-#else
-  *p = v;
-#endif
 }
 
 // Dropout mask of the training form: a counter-based hash of (seed, element index), so the backward
@@ -107,7 +91,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     float* __restrict__ h_out, float* __restrict__ norm_out, int64_t norm_stride, const EgoCopy ego,
     const DeferredRows df) {
   constexpr bool TRAIN = MODE == 2;
-  static_assert(!DEFER || (MODE == 1 && !KGAT_BI_MUL_AT_LOAD_V), "the deferred rows go with the late product");
+  static_assert(!DEFER || (MODE == 1 && !kBiMulAtLoad), "the deferred rows go with the late product");
   constexpr int KS = DI / 4, KT = DO / 16;
   // W2 is staged once per workgroup through LDS (coalesced 16-byte reads of the whole matrix),
   // laid out in B-fragment order so that every wave then pulls its fragments with
@@ -141,10 +125,8 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   // W2's fragments live in registers for the whole launch - except at 128 x 128, where they would
   // need 256 VGPRs: there every MFMA takes its fragment from the LDS copy (one conflict-free
   // ds_read_b32 each)
-#ifndef KGAT_BI_W_LDS_ABOVE
-#define KGAT_BI_W_LDS_ABOVE 128  // (A/B builds: 0 = fragments always from LDS, fewer registers, more wavefronts per SIMD)
-#endif
-  constexpr bool W_IN_LDS = KS * KT > KGAT_BI_W_LDS_ABOVE;
+constexpr int kBiWLdsAbove = 128;  // (A/B builds: 0 = fragments always from LDS, fewer registers, more wavefronts per SIMD)
+  constexpr bool W_IN_LDS = KS * KT > kBiWLdsAbove;
   float wreg[W_IN_LDS ? 1 : KS][W_IN_LDS ? 1 : KT];
   if (!W_IN_LDS) {
 #pragma unroll
@@ -156,13 +138,11 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
   // MODE >= 1: the rows of H and of HN are REQUESTED here and multiplied when the tile is computed (round 4, second
   // form).  The first form multiplied here, which put the waits for both row sets - one after the other, the ego
   // copy in between - into the load step: two exposed memory round trips per tile with nothing else of the
-  // wavefront in flight, and no overlap with the previous tile's matrix work whatever KGAT_BI_PREFETCH said
-  // (A/B builds: KGAT_BI_MUL_AT_LOAD=1).
-  constexpr bool LATE_MUL = MODE >= 1 && !KGAT_BI_MUL_AT_LOAD;
-#ifndef KGAT_BI_PREFETCH
-#define KGAT_BI_PREFETCH 2
-#endif
-  constexpr int PF = KS * KGAT_BI_PREFETCH <= 64 ? KGAT_BI_PREFETCH : (64 / KS >= 2 ? 64 / KS : 2);  // <= 64 VGPRs of rows in flight (x 2 with HN)
+  // wavefront in flight, and no overlap with the previous tile's matrix work whatever kBiPrefetch said
+  // (kBiMulAtLoad = true restores that form.)
+  constexpr bool LATE_MUL = MODE >= 1 && !kBiMulAtLoad;
+constexpr int kBiPrefetch = 2;
+  constexpr int PF = KS * kBiPrefetch <= 64 ? kBiPrefetch : (64 / KS >= 2 ? 64 / KS : 2);  // <= 64 VGPRs of rows in flight (x 2 with HN)
   // DEFER: per stage, the offsets of the row this lane loads NEXT (requested one load step ahead), and what the load
   // step found out for the tile step: nf = followers of the row's chain of tile partials (-1: a row without in-edges,
   // 0: an ordinary row or a one-partial chain), bh = the chain's head tile
@@ -180,7 +160,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     const float4* pa = reinterpret_cast<const float4*>(P + (size_t)ra * DI) + q;
 #pragma unroll
     for (int m = 0; m < DI / 16; ++m) {
-      const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 1) != 0>(pa + m * 4);
+      const float4 v = ld_row4<(kBiNtLoads & 1) != 0>(pa + m * 4);
       a[4 * m + 0] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
     if constexpr (LATE_MUL) {
@@ -201,7 +181,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       }
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
-        const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 2) != 0>(pb + m * 4);
+        const float4 v = ld_row4<(kBiNtLoads & 2) != 0>(pb + m * 4);
         b[4 * m + 0] = v.x; b[4 * m + 1] = v.y; b[4 * m + 2] = v.z; b[4 * m + 3] = v.w;
       }
       if constexpr (DEFER) row_offsets(t + PF, d);  // (clamped to the last row past the end)
@@ -214,7 +194,7 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
       const float4* pb = reinterpret_cast<const float4*>(HN + (size_t)ra * DI) + q;
 #pragma unroll
       for (int m = 0; m < DI / 16; ++m) {
-        const float4 v = ld_row4<(KGAT_BI_NT_LOADS & 2) != 0>(pb + m * 4);
+        const float4 v = ld_row4<(kBiNtLoads & 2) != 0>(pb + m * 4);
         a[4 * m + 0] *= v.x; a[4 * m + 1] *= v.y; a[4 * m + 2] *= v.z; a[4 * m + 3] *= v.w;
       }
     }
@@ -299,17 +279,12 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     // operands swapped (A = W2 fragment, B = the tile's rows): the accumulators hold Z^T, i.e.
     // acc[c][j] = Z[row0 + i][16c + 4q + j] - four consecutive columns per lane, so the results
     // leave as 16-byte stores (a quarter of the store instructions of the row-major result)
-#ifdef KGAT_BI_STRIP_MFMA  // A/B builds (WRONG results): the launch without its matrix work - what the row streams alone take
-#pragma unroll
-    for (int c = 0; c < KT; ++c) acc[c] = (floatx4_d){a[(4 * c) % KS], a[(4 * c + 1) % KS], a[(4 * c + 2) % KS], a[(4 * c + 3) % KS]};
-#else
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < KT; ++c)
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             W_IN_LDS ? s_w[(s * KT + c) * kWave + lane] : wreg[W_IN_LDS ? 0 : s][W_IN_LDS ? 0 : c], a[s], acc[c], 0, 0, 0);
-#endif
     const int32_t row = row0 + i;
     // row norm: per 16-column tile the sum of squares over the row's four lanes (i, q = 0..3), then the tiles'
     // partials in tile order - the order of the fused aggregation + dense launch (kgat_spmm_impl.h: tile_ssq),
@@ -350,36 +325,12 @@ __global__ __launch_bounds__(256) void bi_interaction_kernel(
     }
   };
 
-  // Ring of PF stages: the rows of tile t + PF are requested once tile t is computed.  (A/B form KGAT_BI_PIPELINE=1:
-  // an explicit two-buffer loop, load t + 1 / compute t, whose load steps stand unconditionally - under an
-  // `if (t + p < t_end)` the compiler sees two possible numbers of requests in flight at the next wait and waits
-  // for all of them.  Stand-alone it is faster at 64 -> 64 (37.2 vs 38.9 us) and slower at 32 -> 16 (14.8 vs
-  // 14.0); inside the step the ring wins, 0.4374 vs 0.4395 ms: profiles/r04_bi_late_mul_ab.txt.  Round 4 had
+  // Ring of PF stages: the rows of tile t + PF are requested once tile t is computed.  (Round 4 measured an explicit
+  // two-buffer loop, load t + 1 / compute t, with unconditional load steps against it: stand-alone faster at 64 -> 64
+  // (37.2 vs 38.9 us), slower at 32 -> 16 (14.8 vs 14.0); inside the step the ring wins, 0.4374 vs 0.4395 ms:
+  // profiles/r04_bi_late_mul_ab.txt; that form is in the history, commit c6eba96 and before.  Round 4 had
   // also tried PF = 4, W2's fragments from LDS with 4 and 8 workgroups per CU and a 1,024-block grid:
   // profiles/r04_bi_probe.txt - the launch runs at the rate of a device copy of its bytes.)
-#ifndef KGAT_BI_PIPELINE
-#define KGAT_BI_PIPELINE 0
-#endif
-  if constexpr (KGAT_BI_PIPELINE != 0 && !DEFER) {
-    float a0[KS], a1[KS], b0[LATE_MUL ? KS : 1], b1[LATE_MUL ? KS : 1];
-    Defer d0{0, 0, 0, 0, 0};
-    load_a(t_begin, a0, b0, d0);
-    for (int32_t t = t_begin;; t += 2) {
-      if (t + 1 >= t_end) {
-        tile(t, a0, b0, 0, 0, 0);
-        break;
-      }
-      load_a(t + 1, a1, b1, d0);
-      tile(t, a0, b0, 0, 0, 0);
-      if (t + 2 >= t_end) {
-        tile(t + 1, a1, b1, 0, 0, 0);
-        break;
-      }
-      load_a(t + 2, a0, b0, d0);
-      tile(t + 1, a1, b1, 0, 0, 0);
-    }
-    return;
-  }
   float a[PF][KS], b[PF][LATE_MUL ? KS : 1];
   Defer d[PF];
 #pragma unroll
@@ -545,10 +496,8 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
                      int mode, const EgoCopy ego, const DeferredRows* defer = nullptr) {
   const int64_t tiles = (n_rows + 15) / 16;
   int64_t blocks = (tiles + 3) / 4;  // at least one tile per wave ...
-#ifndef KGAT_BI_MAX_BLOCKS
-#define KGAT_BI_MAX_BLOCKS 512
-#endif
-  if (blocks > KGAT_BI_MAX_BLOCKS) blocks = KGAT_BI_MAX_BLOCKS;    // ... two workgroups per CU (each stages W2 once; measured 256: 22.7, 512: 21.2, 1024: 22.1, 2048: 24.1 us avg)
+constexpr int kBiMaxBlocks = 512;
+  if (blocks > kBiMaxBlocks) blocks = kBiMaxBlocks;    // ... two workgroups per CU (each stages W2 once; measured 256: 22.7, 512: 21.2, 1024: 22.1, 2048: 24.1 us avg)
   // 16-byte stores into the normalised copy need its slice 16-byte aligned with a row stride that keeps it so
   const bool vec = norm_out == nullptr ||
                    ((reinterpret_cast<uintptr_t>(norm_out) & 15u) == 0 && norm_stride % 4 == 0);
@@ -558,10 +507,6 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
                      (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,     \
                      norm_out, norm_stride, ego, no_defer)
   if (mode == 1 && defer != nullptr) {
-#if KGAT_BI_MUL_AT_LOAD_V
-    set_error("bi_interaction_mul_deferred: not in a KGAT_BI_MUL_AT_LOAD build");
-    return KGAT_E_UNSUPPORTED;
-#else
     if (vec)
       hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, 1, true, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                          (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,
@@ -570,7 +515,6 @@ static int launch_bi(int64_t n_rows, const float* P, const float* HN, const floa
       hipLaunchKernelGGL((bi_interaction_kernel<DI, DO, 1, false, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                          (int32_t)n_rows, P, HN, W2, slope, dr.threshold, dr.keep_scale, dr.seed, dr.index0, h_out,
                          norm_out, norm_stride, ego, *defer);
-#endif
   } else if (mode == 2) {
     if (vec) KGAT_BI_LAUNCH(2, true); else KGAT_BI_LAUNCH(2, false);
   } else if (mode == 1) {

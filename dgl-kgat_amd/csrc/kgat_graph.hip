@@ -269,18 +269,15 @@ __global__ void fold_parts_kernel(int n_rel, int64_t t_max, const int32_t* __res
 // gathered sectors).  Pointers with 16-byte alignment take the vector path.
 // fp32 gathers are the permutations of per-edge weights between CSR order and edge-id / reversed-CSR order: the result is
 // either never read on the path (the edge-id-ordered attention tensor) or read once by the next launch's record stream,
-// the index is read once - both as non-temporal accesses (KGAT_GATHER_NT=0: A/B arm; eager step 0.4431 -> 0.4386 ms,
+// the index is read once - both as non-temporal accesses (round 4's A/B: eager step 0.4431 -> 0.4386 ms,
 // profiles/r04_step_ab_cache_policy.txt).  Integer gathers (structure build) stay plain.
-#ifndef KGAT_GATHER_NT
-#define KGAT_GATHER_NT 1
-#endif
 template <typename T>
 __global__ __launch_bounds__(256) void gather4_kernel(int64_t n, const int32_t* __restrict__ index,
                                                       const T* __restrict__ in, T* __restrict__ out) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     typedef int i4g __attribute__((ext_vector_type(4)));
-    constexpr bool NT = KGAT_GATHER_NT != 0 && std::is_same<T, float>::value;
+    constexpr bool NT = std::is_same<T, float>::value;
     int4 ix;
     if constexpr (NT) {
       const i4g ix4 = __builtin_nontemporal_load(reinterpret_cast<const i4g*>(index + i));

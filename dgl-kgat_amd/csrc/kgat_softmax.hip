@@ -18,23 +18,12 @@
 
 #include "kgat_common.h"
 
-// Cache policy of the sweep's streams (bit mask KGAT_SM_NT): 2 = the position map (read once per step) as
-// non-temporal loads - step 0.4178 -> 0.4132 ms, it no longer displaces reused rows from the Infinity Cache; 1 = the
-// logits too (A/B arm: SLOWER, 0.4251 - they are gathered through the map and their lines are hit several times);
-// 4 = the destination rows (A/B arm).  profiles/r04_step_ab_cache_policy.txt
-#ifndef KGAT_SM_NT
-#define KGAT_SM_NT 2
-#endif
-#if KGAT_SM_NT & 1
-#define SM_LD_LOGIT(p) __builtin_nontemporal_load(p)
-#else
+// Cache policy of the sweep's streams: the position map (read once per step) as non-temporal loads - step 0.4178 ->
+// 0.4132 ms, it no longer displaces reused rows from the Infinity Cache.  Measured and not taken
+// (profiles/r04_step_ab_cache_policy.txt): the logits too (SLOWER, 0.4251 - they are gathered through the map and
+// their lines are hit several times), the destination rows.
 #define SM_LD_LOGIT(p) (*(p))
-#endif
-#if KGAT_SM_NT & 2
 #define SM_LD_MAP(p) __builtin_nontemporal_load(p)
-#else
-#define SM_LD_MAP(p) (*(p))
-#endif
 namespace kgat {
 
 constexpr float kFixScale = 1099511627776.0f;       // 2^40
@@ -210,10 +199,7 @@ __global__ __launch_bounds__(256) void softmax_norm_kernel(
 // positions, where the sweep is a latency chain rather than a stream and twice the wavefronts with half
 // the chain each finish sooner.
 constexpr int kSmMaxEPL = 16;
-#ifndef KGAT_SM_SMALL_EDGES
-#define KGAT_SM_SMALL_EDGES (8 << 20)
-#endif
-constexpr int64_t kSmSmallEdges = KGAT_SM_SMALL_EDGES;  // (a macro for A/B builds: scripts/micro/softmax_ab.py)
+constexpr int64_t kSmSmallEdges = 8 << 20;
 template <int EPL> struct SmGeom {
   static constexpr int EPW = kWave * EPL;   // positions per wavefront
 };
@@ -371,24 +357,15 @@ __device__ __forceinline__ void sm_sweep(int64_t e0, int64_t e1, int64_t w, int6
   if (FAST) {
 #pragma unroll
     for (int v = 0; v < kSmEPL / 4; ++v) {
-#if KGAT_SM_NT & 4
-      typedef int i4r __attribute__((ext_vector_type(4)));
-      const i4r b = __builtin_nontemporal_load(reinterpret_cast<const i4r*>(ro + lane * kSmEPL + 4 * v));
-#else
       const int4 b = *reinterpret_cast<const int4*>(ro + lane * kSmEPL + 4 * v);
-#endif
       r[4 * v] = b.x; r[4 * v + 1] = b.y; r[4 * v + 2] = b.z; r[4 * v + 3] = b.w;
     }
     if (need_gi) {
       const int32_t* ei = eid + base;
 #pragma unroll
       for (int v = 0; v < kSmEPL / 4; ++v) {
-#if KGAT_SM_NT & 2
         typedef int i4v __attribute__((ext_vector_type(4)));
         const i4v b = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(ei + lane * kSmEPL + 4 * v));
-#else
-        const int4 b = *reinterpret_cast<const int4*>(ei + lane * kSmEPL + 4 * v);
-#endif
         gi[4 * v] = b.x; gi[4 * v + 1] = b.y; gi[4 * v + 2] = b.z; gi[4 * v + 3] = b.w;
       }
     }

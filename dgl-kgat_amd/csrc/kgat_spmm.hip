@@ -64,12 +64,6 @@ __global__ __launch_bounds__(256) void gather_probe_kernel(int64_t n_edges, cons
   constexpr int64_t kPerWave = 512;
   const int64_t base = wave * kPerWave;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef KGAT_PROBE_LDS
-  // A/B builds: LDS ballast = fewer resident workgroups per CU (how the rate depends on the rows in flight)
-  __shared__ float s_ballast[KGAT_PROBE_LDS / 4];
-  if (n_edges < 0) s_ballast[threadIdx.x] = 1.f;
-  if (n_edges < -1) acc.x = s_ballast[threadIdx.x ^ 1];
-#endif
   for (int64_t p0 = base; p0 < base + kPerWave && p0 < n_edges; p0 += EPS * U) {
     int c[U];
 #pragma unroll
@@ -92,11 +86,6 @@ using namespace kgat;
 
 extern "C" {
 
-#ifdef KGAT_SPMM_STAMPS
-int kgat_debug_set_spmm_stamps(void* dev_ptr) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_spmm_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
-}
-#endif
 
 size_t kgat_spmm_workspace_bytes(int64_t n_edges, int D) {
   const int lpr = lpr_for(D);
@@ -175,9 +164,7 @@ int kgat_spmm_umule_sum_f32(int64_t n_rows, int64_t row0, int64_t e_begin, int64
   return eid ? dispatch_width<false, true>(a) : dispatch_width<false, false>(a);
 }
 
-#ifndef KGAT_PROBE_U
-#define KGAT_PROBE_U 8  // rows in flight per lane group (A/B builds)
-#endif
+constexpr int kProbeU = 8;  // rows in flight per lane group (A/B builds)
 int kgat_gather_probe_f32(int64_t n_edges, int D, const int32_t* col, const float* X, float* sink, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_edges >= 0, "gather_probe: bad size");
   if (n_edges == 0) return KGAT_OK;
@@ -188,7 +175,7 @@ int kgat_gather_probe_f32(int64_t n_edges, int D, const int32_t* col, const floa
   switch (D) {
     case 16: hipLaunchKernelGGL((gather_probe_kernel<4, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
     case 32: hipLaunchKernelGGL((gather_probe_kernel<8, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
-    case 64: hipLaunchKernelGGL((gather_probe_kernel<16, KGAT_PROBE_U>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
+    case 64: hipLaunchKernelGGL((gather_probe_kernel<16, kProbeU>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
     case 128: hipLaunchKernelGGL((gather_probe_kernel<32, 8>), dim3(blocks), dim3(256), 0, as_stream(stream), n_edges, col, X4, s4); break;
     default:
       set_error("gather_probe: D must be 16, 32, 64 or 128 (got %d)", D);

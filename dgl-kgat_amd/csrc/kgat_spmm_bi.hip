@@ -14,9 +14,6 @@
 // Rows of a tile beyond the buffer's capacity spill their P row to a global scratch and are read back by the
 // same workgroup (L2-local).  The buffer's size is set by occupancy, not by the typical tile (44 rows):
 // profiles/r04_spmm_lds_ballast_ab.txt.
-#ifdef KGAT_SPMM_THREADS
-#undef KGAT_SPMM_THREADS  // (A/B builds of the plain operator's workgroup size: the fused form is laid out for 256 threads)
-#endif
 #include "kgat_spmm_impl.h"
 
 using namespace kgat;
@@ -32,11 +29,6 @@ int launch_fused(const SpmmArgs& a) {
 
 extern "C" {
 
-#ifdef KGAT_SPMM_STAMPS
-int kgat_debug_set_spmm_bi_stamps(void* dev_ptr) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(kgat::g_spmm_stamps), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -4;
-}
-#endif
 
 int kgat_spmm_bi_fused_supported(int d_in, int d_out) {
   auto ok = [](int d) { return d == 16 || d == 32 || d == 64; };

@@ -4,12 +4,6 @@
 #pragma once
 #include "kgat_common.h"
 
-#ifndef KGAT_SPMM_STORE_NT
-#define KGAT_SPMM_STORE_NT 0
-#endif
-#ifndef KGAT_SPMM_TIMING_SKIP_FINISH
-#define KGAT_SPMM_TIMING_SKIP_FINISH 0
-#endif
 namespace kgat {
 
 __device__ __forceinline__ float4 fma4(float a, const float4& x, const float4& c) {
@@ -22,10 +16,8 @@ __device__ __forceinline__ float4 mul4(const float4& a, const float4& b) {
   return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
 
-#ifndef KGAT_SPMM_THREADS
-#define KGAT_SPMM_THREADS 256  // (A/B builds.  128-thread workgroups with half-size tiles, round 3: D = 64 0.0993 vs 0.0987 ms, D = 128 0.187 vs 0.179, D = 8 0.058 vs 0.066)
-#endif
-constexpr int kSpmmThreads = KGAT_SPMM_THREADS;
+// (128-thread workgroups with half-size tiles, round 3: D = 64 0.0993 vs 0.0987 ms, D = 128 0.187 vs 0.179, D = 8 0.058 vs 0.066)
+constexpr int kSpmmThreads = 256;
 
 // Threads per workgroup of the kernels that are laid out in lane groups of LPR lanes.  D <= 8 (two lanes per
 // row and fewer): 128 - a 256-thread workgroup holds 128 runs there, i.e. 256 run partials to combine per
@@ -68,15 +60,13 @@ typedef float floatx4_s __attribute__((ext_vector_type(4)));
 // capacity keeps a workgroup's LDS within a fifth of the CU's 160 KB at the fused run length below
 // (profiles/r04_spmm_lds_ballast_ab.txt: 4 resident workgroups per CU instead of 5 cost the D = 64 launch
 // 1 % as LDS ballast alone, but 25-30 % once the workgroups also spend a sixth of their time in the dense tail).
-#ifndef KGAT_FUSED_CAP16
-#define KGAT_FUSED_CAP16 17  // (A/B builds: 49 = four workgroups per CU at the full run length)
-#endif
+constexpr int kFusedCap16 = 17;  // (A/B builds: 49 = four workgroups per CU at the full run length)
 template <int LPR>
 struct FusedGeom {
   static constexpr int PS4 = LPR + 1;                                    // row stride in float4
   // rows of the tile held in LDS: slot 0 (the tile's first row, never used) + whole 16-row blocks, so that a
   // block of the dense tail comes either from LDS or from the spill scratch, never from both
-  static constexpr int CAP = LPR >= 16 ? KGAT_FUSED_CAP16 : 49;
+  static constexpr int CAP = LPR >= 16 ? kFusedCap16 : 49;
   static_assert((CAP - 1) % 16 == 0, "the row buffer holds whole 16-row blocks");
 };
 
@@ -130,10 +120,6 @@ template <int LPR, bool MUL_SELF, bool COPY_SELF = false>
 __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4* __restrict__ X,
                                           int32_t row, int32_t row0, int sl, float4 v,
                                           const SelfCopy sc = SelfCopy{nullptr, 0}) {
-#ifdef KGAT_SPMM_STRIP_EPILOGUE  // A/B builds (WRONG results): what the launch takes without its row epilogue
-  if (v.x == 12345.678f) out[(size_t)(row - row0) * LPR + sl] = v;
-  return;
-#endif
   if (MUL_SELF) {
     const float4 x = X[(size_t)row * LPR + sl];
     v = mul4(v, x);
@@ -141,13 +127,7 @@ __device__ __forceinline__ void store_row(float4* __restrict__ out, const float4
   }
   // (round 4 tried write-through `sc1` stores here, which do not keep the output rows' lines in the XCD's L2: no change,
   // 0.0867 vs 0.0868 ms - profiles/r04_spmm_cache_policy_ab.txt)
-#if KGAT_SPMM_STORE_NT  // A/B arm: the output rows as non-temporal stores
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  const f4v x = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(out + (size_t)(row - row0) * LPR + sl));
-#else
   out[(size_t)(row - row0) * LPR + sl] = v;
-#endif
 }
 
 template <int LPR, int C, bool MUL_SELF, bool HAS_EID>
@@ -271,18 +251,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge_kernel(
 // the current group is consumed.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-#ifdef KGAT_SPMM_STAMPS
-// Diagnostic build only (-DKGAT_SPMM_STAMPS): per-tile phase stamps of the merge kernel, read
-// back by scripts/micro/spmm_stamps.py.  Never compiled into the shipped library.
-static __device__ unsigned long long* g_spmm_stamps = nullptr;  // one per translation unit, each with its setter
-#define KGAT_STAMP(k)                                                                  \
-  do {                                                                                 \
-    if (g_spmm_stamps && threadIdx.x == 0)                                             \
-      g_spmm_stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();      \
-  } while (0)
-#else
-#define KGAT_STAMP(k) do { } while (0)
-#endif
 
 struct alignas(16) EdgeRec {
   int32_t c;  // source row
@@ -291,9 +259,6 @@ struct alignas(16) EdgeRec {
   int32_t pad;
 };
 
-#ifndef KGAT_SPMM_REC_NT
-#define KGAT_SPMM_REC_NT 1
-#endif
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false, int DO = 0>
 __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     int64_t e0, int64_t e1, int32_t row0, const int32_t* __restrict__ col,
@@ -304,13 +269,8 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   constexpr bool FUSED = DO > 0;
   constexpr int DI = 4 * LPR;
   static_assert(!FUSED || MUL_SELF, "the fused dense part consumes h * h_N");
-#ifndef KGAT_SPMM_GROUP
-#define KGAT_SPMM_GROUP 4
-#endif
-#ifndef KGAT_SPMM_PREFETCH
-#define KGAT_SPMM_PREFETCH 1
-#endif
-  constexpr int G = (C % KGAT_SPMM_GROUP == 0) ? KGAT_SPMM_GROUP : 4;  // edges per group
+constexpr int kSpmmGroup = 4;
+  constexpr int G = (C % kSpmmGroup == 0) ? kSpmmGroup : 4;  // edges per group
   static_assert(C % G == 0, "run length must be a multiple of the group size");
   // the edge records and the run partials share one block of LDS: once the combine is done the fused form
   // reuses all of it as the staging area of spilled P rows (below)
@@ -325,13 +285,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   static_assert(!FUSED || (KT <= WAVES && WAVES % KT == 0), "one wavefront per column tile");
   __shared__ float4 s_P[FUSED ? CAP * PS4 : 1];
   __shared__ float s_ss[FUSED ? 2 * GROUPS * KT * 16 : 1];
-#ifdef KGAT_SPMM_EXTRA_LDS
-  // A/B builds: ballast that lowers the number of resident workgroups per CU (occupancy probe for the
-  // fused aggregation + bi-interaction kernel, whose row buffer costs LDS)
-  __shared__ float s_ballast[KGAT_SPMM_EXTRA_LDS / 4];
-  if (e0 < 0) s_ballast[threadIdx.x] = 1.f;
-  if (e0 < -1) bpart[0].x = s_ballast[threadIdx.x ^ 1];
-#endif
 
   // KGAT_SPMM_XCD_REMAP=1 (A/B builds): every XCD takes a contiguous eighth of the tiles instead of
   // every eighth tile.  Measured slower on both CKG shapes (round 3, scripts/micro/spmm_runlen_ab.py with
@@ -339,39 +292,23 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   // 0.066 ms): with the round-robin placement the eight L2s work on neighbouring destination ranges at
   // the same time and miss on the same source rows together - one fetch from the Infinity Cache serves
   // requests that are in flight in several XCDs -, a contiguous eighth per XCD spreads the misses in time.
-#ifndef KGAT_SPMM_XCD_REMAP
-#define KGAT_SPMM_XCD_REMAP 0
-#endif
+constexpr int kSpmmXcdRemap = 0;
   const int tid = threadIdx.x;
   const int sub = tid / LPR, sl = tid % LPR;
-  const unsigned tile = KGAT_SPMM_XCD_REMAP ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const unsigned tile = kSpmmXcdRemap ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int64_t tile0 = e0 + (int64_t)tile * TE;
   const int64_t tile1 = (tile0 + TE < e1) ? tile0 + TE : e1;
   const int n_tile = (int)(tile1 - tile0);
-  KGAT_STAMP(0);
-
   for (int k = tid; k < TE; k += SpmmGeom<LPR>::THREADS) {
     EdgeRec rec;
     if (k < n_tile) {
       const int64_t p = tile0 + k;
-#ifdef KGAT_SPMM_STRIP_STAGE  // A/B builds (WRONG results): records made up instead of loaded
-      rec.c = (int32_t)(((uint32_t)p * 2654435761u) % (uint32_t)(e1 - e0 > 159251 ? 159251 : 1));
-      rec.r = (int32_t)(p >> 5) + row0;
-      rec.w = 1.0f;
-#else
-#if KGAT_SPMM_REC_NT  // the record streams (12 bytes per edge, read once per launch) as non-temporal loads: stand-alone
                       // launches gain 3 % (D = 64) / 7 % (D = 32) - profiles/r04_spmm_cache_policy_ab.txt -, the step
                       // 6.6 us (0.4244 -> 0.4178 ms, profiles/r04_step_ab_cache_policy.txt; the first step-level
                       // comparison, on per-kernel averages of separate runs, had not resolved it)
       rec.c = __builtin_nontemporal_load(col + p);
       rec.r = __builtin_nontemporal_load(row_of + p);
       rec.w = __builtin_nontemporal_load(w + p);
-#else
-      rec.c = col[p];
-      rec.r = row_of[p];
-      rec.w = w[p];
-#endif
-#endif
     } else {
       rec.c = 0;
       rec.r = -1;
@@ -384,7 +321,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     for (int k = tid; k < CAP * PS4; k += SpmmGeom<LPR>::THREADS) s_P[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  KGAT_STAMP(1);
   // (wave-uniform values read from LDS: pinned in SGPRs, the edge loop is at its VGPR limit)
   const int32_t first_row = __builtin_amdgcn_readfirstlane(s_rec[0].r);
   const int32_t last_row = __builtin_amdgcn_readfirstlane(s_rec[n_tile - 1].r);
@@ -421,13 +357,8 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   // 77.5 us for the plain operator, profiles/r04_spmm_epilogue_probe.txt).  A/B arm KGAT_SPMM_SELF_PREFETCH=1:
   // request it when the row OPENS instead.  The layer now forms h * h_N in the bi-interaction kernel
   // (kgat_bi_interaction_mul_f32) and calls the plain operator.
-#ifndef KGAT_SPMM_COMBINE_ENTRYWISE
-#define KGAT_SPMM_COMBINE_ENTRYWISE 0
-#endif
-#ifndef KGAT_SPMM_SELF_PREFETCH
-#define KGAT_SPMM_SELF_PREFETCH 0  // measured SLOWER (100.7 vs 91.4 us at D = 64): the conditional load makes every later wait of the loop conservative
-#endif
-  constexpr bool SELF_PF = MUL_SELF && !FUSED && KGAT_SPMM_SELF_PREFETCH != 0;
+constexpr int kSpmmSelfPrefetch = 0;  // measured SLOWER (100.7 vs 91.4 us at D = 64): the conditional load makes every later wait of the loop conservative
+  constexpr bool SELF_PF = MUL_SELF && !FUSED && kSpmmSelfPrefetch != 0;
   float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto open_row = [&](int32_t row) {
     cur_row = row;
@@ -479,7 +410,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     }
   };
 
-#if KGAT_SPMM_PREFETCH
   EdgeRec ra[G], rb[G];
   float4 xa[G], xb[G];
   if (ng > 0) load_group(0, ra, xa);
@@ -490,14 +420,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     if (g + 2 < ng) load_group(g + 2, ra, xa);
     consume(rb, xb);
   }
-#else
-  for (int g = 0; g < ng; ++g) {
-    EdgeRec ra[G];
-    float4 xa[G];
-    load_group(g, ra, xa);
-    consume(ra, xa);
-  }
-#endif
   for (int j = ng * G; j < n_run; ++j) {  // only the last run of the edge range is ragged
     const EdgeRec rec = run[j];
     const float4 x = X[(size_t)rec.c * LPR + sl];
@@ -507,8 +429,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
     }
     accum(rec.w, x);
   }
-
-  KGAT_STAMP(2);
   // the run's last open row: head slot if the run never changed row, else tail slot
   {
     const float4 acc = make_float4(a01.x, a01.y, a23.x, a23.y);
@@ -534,7 +454,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
   // instead: its lane groups stride over the segment's entries and a fixed shuffle tree adds
   // their sums.  (One lane group walking a long segment alone was the largest phase of a D = 8
   // tile: median 16.7 k of 34.9 k cycles, 90 k on hub tiles.)
-  KGAT_STAMP(3);
   // fused form: this wavefront's W2 fragments (column tile c_tile) are requested now and land while the combine runs
   const int wave_e = __builtin_amdgcn_readfirstlane(tid / kWave), lane_e = tid % kWave;  // (SGPR: uniform branches below)
   const int c_tile = wave_e % KT, grp = wave_e / KT;
@@ -553,33 +472,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       else if (FUSED) put_row(rr, v);
       else store_row<LPR, MUL_SELF, COPY_SELF>(out, X, rr, row0, sl, v, sc);
     };
-#if KGAT_SPMM_COMBINE_ENTRYWISE  // A/B arm: the first form of the walk, one dependent LDS read per entry
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int k = 2 * sub + t;
-      const int32_t rr = s_row[sub][t];
-      bool starts = rr >= 0;
-      if (starts && k > 0) {
-        // previous valid entry: entry k-1, or k-2 when k-1 is an unused tail slot
-        int32_t prev = s_row[(k - 1) >> 1][(k - 1) & 1];
-        if (prev < 0 && k > 1) prev = s_row[(k - 2) >> 1][(k - 2) & 1];
-        starts = prev != rr;
-      }
-      bool is_long = false;
-      if (starts) {
-        float4 v = s_part[sub][t][sl];
-        int taken = 1;
-        for (int k2 = k + 1; k2 < NE; ++k2) {
-          const int32_t r2 = s_row[k2 >> 1][k2 & 1];
-          if (r2 < 0) continue;
-          if (r2 != rr) break;
-          if (taken == kShortSeg) { is_long = true; break; }
-          v = add4(v, s_part[k2 >> 1][k2 & 1][sl]);
-          ++taken;
-        }
-        if (!is_long) emit(rr, v);
-      }
-#else
     // Round 4: the rows of the entries around this lane group's two (2 sub - 2 .. 2 sub + 5) and the partials of
     // entries 2 sub .. 2 sub + 4 are requested TOGETHER, up front - one LDS round trip - and the common segments
     // (up to four entries) are summed from registers.  (The first form read s_row / s_part entry by entry, each read
@@ -639,7 +531,6 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
         }
         if (starts && !is_long) emit(rr, v);
       }
-#endif
       if (LPR < kWave) {  // (one lane group per wavefront: the walk above is all there is)
         unsigned long long todo = __ballot(is_long && sl == 0);
         while (todo) {
@@ -677,13 +568,11 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       }
     }
   }
-  KGAT_STAMP(4);
   if constexpr (FUSED) {
     // the dense part on the tile's interior rows (first_row, last_row): all complete, their P rows in s_P
     // (slots 1 ..) or, beyond its capacity, in `out`.  Wavefront w owns column tile w % KT of the 16-row blocks
     // of stream w / KT; the row norms meet through LDS (one barrier per block, partials double-buffered).
     __syncthreads();  // every P row is written
-    KGAT_STAMP(5);
     const int32_t n_int = last_row - first_row - 1;
     const int32_t n_blocks = n_int > 0 ? (n_int + 15) >> 4 : 0;
     const int i = lane_e & 15, q = lane_e >> 4;
@@ -750,9 +639,7 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge2_kernel(
       __syncthreads();
       dense_rows(s_chunk, nrows, first_row + slot0);
     }
-    KGAT_STAMP(6);
   } else {
-    KGAT_STAMP(5);
   }
 }
 
@@ -1041,16 +928,12 @@ constexpr int64_t kShortRunTileLimit = 4096;  // use the short runs while they g
 // graph), and half-length tiles halve that tail: D = 32 0.079 -> 0.066 ms, D = 16 0.066 -> 0.060
 // (quarter length: 0.076; at D = 64 / 128, 16-KB tiles of 1,024 edges, half length changes nothing,
 // at D = 8 it costs 6-10 %: scripts/micro/spmm_runlen_ab.py).  The two macros exist for that A/B build only.
-#ifndef KGAT_SPMM_MID_DIV
-#define KGAT_SPMM_MID_DIV 2
-#endif
+constexpr int kSpmmMidDiv = 2;
 constexpr int mid_run_len(int lpr) {
-  return (lpr == 8 || lpr == 4) ? run_len(lpr) / KGAT_SPMM_MID_DIV : run_len(lpr);
+  return (lpr == 8 || lpr == 4) ? run_len(lpr) / kSpmmMidDiv : run_len(lpr);
 }
-#ifndef KGAT_SPMM_MID_LIMIT
-#define KGAT_SPMM_MID_LIMIT 16384
-#endif
-constexpr int64_t kMidRunTileLimit = KGAT_SPMM_MID_LIMIT;
+constexpr int kSpmmMidLimit = 16384;
+constexpr int64_t kMidRunTileLimit = kSpmmMidLimit;
 
 template <int LPR, int C>
 static int64_t merge_tiles_c(int64_t n_edges) {
@@ -1100,9 +983,6 @@ static int launch_merge_c(const SpmmArgs& a) {
   int64_t nz_blocks = (a.n_rows + kThreads - 1) / kThreads;  // one lane per row
   if (nz_blocks > 2048) nz_blocks = 2048;
   if (nz_blocks < 1) nz_blocks = 1;
-#if KGAT_SPMM_TIMING_SKIP_FINISH  // timing probe only (scripts/micro/step_ab.py): rows cut by tiles stay unwritten
-  if (DO == 0) return KGAT_OK;
-#endif
   // KGAT_SPMM_DEFER_FINISH: the consumer (kgat_bi_interaction_mul_deferred_f32) forms the tiles' first / last rows
   // from the partials in the workspace, and the rows without in-edges, itself
   if (DO == 0 && (a.flags & KGAT_SPMM_DEFER_FINISH)) return KGAT_OK;
@@ -1119,10 +999,8 @@ static int launch_merge_c(const SpmmArgs& a) {
 // the run length at D = 64 - 512-edge tiles hold half the rows and leave LDS for a 56-row buffer at five
 // workgroups per CU; measured slower, profiles/r04_fused_bi_ab.txt: the per-tile phases around the edge loop
 // (stage, partials, combine, the dense tail) do not shrink with the tile.)
-#ifndef KGAT_FUSED_HALF_RUNS
-#define KGAT_FUSED_HALF_RUNS 0
-#endif
-constexpr int fused_run_len(int lpr) { return (KGAT_FUSED_HALF_RUNS && lpr >= 16) ? run_len(lpr) / 2 : run_len(lpr); }
+constexpr int kFusedHalfRuns = 0;
+constexpr int fused_run_len(int lpr) { return (kFusedHalfRuns && lpr >= 16) ? run_len(lpr) / 2 : run_len(lpr); }
 
 template <int LPR, bool MUL_SELF, bool HAS_EID, int DO = 0>
 static int launch_merge(const SpmmArgs& a) {

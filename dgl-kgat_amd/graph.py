@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .options import options
 from .function import BuiltinMessage, BuiltinReduce
 from .lazy import LazyEdgeWeights, pending_csr_weights
 
@@ -320,7 +321,7 @@ class _Structure:
 def _f32_products():
     """``KGAT_ATT_F32_PRODUCTS=1``: the attention kernels' two products on the fp32 MFMA (the C
     ABI's KGAT_ATT_F32_PRODUCTS flag) instead of the default bf16-piece products."""
-    return os.environ.get("KGAT_ATT_F32_PRODUCTS", "") not in ("", "0")
+    return options.att_f32_products
 
 
 def _fused_statics(groups):
@@ -631,7 +632,7 @@ class DGLGraph:
         # do the whole relation-space product per group and a d-length dot per edge (one launch
         # with the per-group vectors in LDS / two launches with a table); "split" keeps the
         # reference's contraction order (bit-identical to "one")
-        grouped_out = os.environ.get("KGAT_ATT_SCATTER_CSR", "") in ("", "0")
+        grouped_out = not options.att_scatter_csr
 
         def run(form):
             if form == "fused":
@@ -660,7 +661,7 @@ class DGLGraph:
             return ops.att_score(st.n_nodes, groups.rel_ptr, groups.perm, groups.src_g, groups.dst_g,
                                  ent_c, W_c, rel_c, pos_g=groups.pos_g, algo="auto" if form == "one" else form)[1]
 
-        form = os.environ.get("KGAT_ATT_FORM", "auto") if algo == "auto" else algo
+        form = options.att_form if algo == "auto" else algo
         race = form == "race"
         if form in ("auto", "race"):
             form = groups.g_tab.get(("form", d, k))

@@ -14,7 +14,6 @@ Two ways through every step:
   and the SpMM with the ``h * h_N`` product in its epilogue.  Same results, fewer passes.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -22,6 +21,7 @@ import torch.nn.functional as F
 
 from . import function as fn
 from .autograd import edge_softmax, u_mul_e_sum
+from .options import options
 
 
 def ops_transr_supported(model, h):
@@ -193,7 +193,7 @@ class KGATPropagation(nn.Module):
             # (the gradient of a layer's input is needed in full only where that input is a replicated parameter -
             # the embedding table under layer 0; deeper layers reduce it to the rows' owners)
             h = shard_conv(g.partition, g, h, layer.res_fc_2.weight, 0.01, p, seed + li,
-                           owner_only_grad=li > 0 and os.environ.get("KGAT_SHARD_GRAD_ALLREDUCE", "") in ("", "0"))
+                           owner_only_grad=li > 0 and not options.shard_grad_allreduce)
             cache.append(F.normalize(h, p=2, dim=1))
         return torch.cat(cache, 1)
 
@@ -239,17 +239,17 @@ class KGATPropagation(nn.Module):
         # 0.481 ms on the benchmark graph (the copy launch was 18 us; the aggregation grows by 3.5 us, and
         # the attention launch of the next step by 3.5 us because the pass no longer ends on the embedding
         # table).  KGAT_GNN_COPY_SELF=0 restores the separate copy.
-        copy_self = os.environ.get("KGAT_GNN_COPY_SELF", "1") not in ("", "0") and widths[0] % 4 == 0
+        copy_self = options.gnn_copy_self and widths[0] % 4 == 0
         # KGAT_FUSE_BI=1: aggregation and dense part of a layer in ONE launch where the widths allow
         # (kgat_spmm_bi_fused_f32: the rows h * h_N stay with the workgroup that completed them; same bits as the
         # two launches).  Off by default: measured 3-4 % SLOWER per layer than the two launches on the benchmark
         # graph (119.7 vs 116.4 us at 64 -> 64, profiles/r04_fused_bi_ab.txt) - the dense tail
         # keeps a workgroup's gather slots idle, which costs the latency-bound aggregation more than the 82 MB
         # round trip of h * h_N costs the separate launch.
-        fuse_bi = os.environ.get("KGAT_FUSE_BI", "0") not in ("", "0")
+        fuse_bi = options.fuse_bi
         # KGAT_GNN_MUL_IN_SPMM=1: rounds 1-3's split - h * h_N in the aggregation's epilogue (A/B)
-        mul_in_spmm = os.environ.get("KGAT_GNN_MUL_IN_SPMM", "0") not in ("", "0")
-        defer = os.environ.get("KGAT_GNN_DEFER_FINISH", "1") not in ("", "0")
+        mul_in_spmm = options.gnn_mul_in_spmm
+        defer = options.gnn_defer_finish
         st = g._st
         scratch = None
         for li, layer in enumerate(self.layers):

@@ -152,10 +152,10 @@ def enable(flag=True):
 
 def enabled():
     """Whether kgat_attention hands back LazyEdgeWeights by default (see the module docstring)."""
-    import os
-    if os.environ.get("KGAT_EAGER_EDGE_WEIGHTS"):
+    from .options import options
+    if options.eager_edge_weights:
         return False
-    if _enabled is None and os.environ.get("KGAT_LAZY_EDGE_WEIGHTS", "") not in ("", "0"):
+    if _enabled is None and options.lazy_edge_weights:
         enable(True)
     return bool(_enabled)
 

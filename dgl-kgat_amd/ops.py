@@ -13,7 +13,7 @@ from ._lib import KGATLibraryError, check
 SPMM_MUL_SELF = 1
 SPMM_DEFER_FINISH = 2
 SPMM_ALGO = {"auto": 0, "merge": 1, "rows": 2, "generic": 3, "merge1": 4}
-ATT_ALGO = dict({"auto": 0, "mfma": 1, "generic": 2}, **{"mfma_v%d" % v: 16 + v for v in range(16)})
+ATT_ALGO = {"auto": 0, "mfma": 1, "generic": 2, "mfma_chunk": 3}
 
 
 def _stream(t):
@@ -272,10 +272,9 @@ FOLD_TILE_COST_128 = (64, 12, 700)
 def fold_tile_cost(d, f32_products=False):
     """The split cost that goes with the product form att_score_fused takes at width d
     (``KGAT_FOLD_TILE_COST="tile,chunk,relation"`` overrides it: A/B runs of the whole step)."""
-    import os
-    env = os.environ.get("KGAT_FOLD_TILE_COST")
-    if env:
-        return tuple(int(x) for x in env.split(","))
+    from .options import options
+    if options.fold_tile_cost:
+        return options.fold_tile_cost
     if d == 128:
         return FOLD_TILE_COST_128
     return FOLD_TILE_COST if (d % 32 == 0 and not f32_products) else FOLD_TILE_COST_F32

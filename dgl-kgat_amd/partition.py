@@ -18,6 +18,8 @@ import os
 
 import numpy as np
 import torch
+
+from .options import options
 import torch.distributed as dist
 
 from . import ops
@@ -33,7 +35,7 @@ ROW_WEIGHT = 8
 
 def _row_weight(row_weight):
     if row_weight is None:
-        row_weight = int(os.environ.get("KGAT_PARTITION_ROW_WEIGHT", ROW_WEIGHT))
+        row_weight = options.partition_row_weight if options.partition_row_weight is not None else ROW_WEIGHT
     return max(int(row_weight), 0)
 
 
@@ -96,16 +98,16 @@ class Partition:
     def __init__(self, rank, world, bounds, n_nodes, group=None, mode=None, force_collectives=None):
         self.rank, self.world, self.bounds, self.n_nodes, self.group = rank, world, list(bounds), n_nodes, group
         if force_collectives is None:
-            force_collectives = os.environ.get("KGAT_FORCE_COLLECTIVES", "") not in ("", "0")
+            force_collectives = options.force_collectives
         self.force_collectives = bool(force_collectives)
         self.lo, self.hi = bounds[rank], bounds[rank + 1]
-        self.mode = mode or os.environ.get("KGAT_EXCHANGE", "allreduce")
+        self.mode = mode or options.exchange
         if self.mode not in EXCHANGE_MODES:
             raise ValueError("exchange mode %r is not one of %s" % (self.mode, EXCHANGE_MODES))
         self.exchange_enabled = True  # False: the collective is skipped (local-time probes on one GPU)
         self._bufs = {}
         self._chunks = {}
-        self.n_chunks = int(os.environ.get("KGAT_EXCHANGE_CHUNKS", "1"))  # > 1: propagate_fused overlaps the exchange
+        self.n_chunks = options.exchange_chunks  # > 1: propagate_fused overlaps the exchange
 
     @property
     def collectives_on(self):
@@ -284,7 +286,7 @@ class Partition:
         h_c = h.detach().contiguous()
         # (the aggregation's second launch left to the dense kernel where the widths allow, as in the unsharded layer:
         # kgat_layer._gnn_fused; KGAT_GNN_DEFER_FINISH=0 restores it)
-        defer = (os.environ.get("KGAT_GNN_DEFER_FINISH", "1") not in ("", "0") and self.hi > self.lo and
+        defer = (options.gnn_defer_finish and self.hi > self.lo and
                  ops.bi_interaction_deferral_supported(h_c.shape[1], weight.shape[0]))
         hn = ops.spmm(csr.indptr, csr.col, csr.row_of, h_c, w_csr, rows=(self.lo, self.hi - self.lo),
                       e_range=(0, st.n_edges), defer_finish=defer)

@@ -140,14 +140,14 @@ def main():
         for p in model.parameters():   # one source of truth for the initial parameters, whatever the ranks' RNG drew
             dist.broadcast(p.data, src=0)
         replicas_agree("after the initial broadcast")
-    # one Adam over all parameters (kgat.py:85); torch's single-kernel implementation of the same update
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr, fused=dev.type == "cuda")
+    # one Adam over all parameters (kgat.py:85): the same update, bit for bit, as one launch per step (optim.FusedAdam)
+    opt = K.FusedAdam(model.parameters(), lr=args.lr)
     train_g, test_g = ds.train_graph(dev), ds.test_graph(dev)
     if world > 1:
         from dgl_kgat_amd import partition
         train_g, test_g = partition.shard_graph(train_g, rank, world)[0], partition.shard_graph(test_g, rank, world)[0]
-    trip = torch.as_tensor(ds.train_KG_triplet.astype(np.int64), device=dev)
-    pairs = torch.as_tensor(ds.train_pairs.astype(np.int64), device=dev)
+    trip = torch.as_tensor(ds.train_KG_triplet.astype(np.int32), device=dev)   # int32 ids go to the kernels as they are
+    pairs = torch.as_tensor(ds.train_pairs.astype(np.int32), device=dev)
     off = ds.n_users
     train_dict = user_dict(ds.train_pairs, off)
     valid_dict, test_dict = user_dict(ds.valid_pairs, off), user_dict(ds.test_pairs, off)
@@ -164,11 +164,9 @@ def main():
         for _ in range(n_it):
             idx = torch.randint(0, len(trip), (min(args.batch_size_kg, len(trip)),), device=dev)
             h, r, pos_t = trip[idx, 0], trip[idx, 1], trip[idx, 2]
-            neg_t = torch.randint(0, ds.n_KG_entity, h.shape, device=dev)
-            loss = model.transR(h, r, pos_t, neg_t)
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
+            neg_t = torch.randint(0, ds.n_KG_entity, h.shape, device=dev, dtype=torch.int32)
+            # transR -> backward -> step -> zero_grad of kgat.py:127-131 as two library calls (same bits)
+            loss = model.kg_step(h.contiguous(), r.contiguous(), pos_t.contiguous(), neg_t, opt)
             total += loss.item()
         say("Epoch %04d | KGE %.1fs loss %.4f" % (epoch, time.time() - t0, total / n_it))
         # ---- attention refresh (kgat.py:139-145)
@@ -183,7 +181,7 @@ def main():
         for _ in range(n_it):
             idx = torch.randint(0, len(pairs), (min(args.batch_size, len(pairs)),), device=dev)
             users, pos_items = pairs[idx, 0], pairs[idx, 1]
-            neg_items = torch.randint(off, off + ds.n_items, users.shape, device=dev)
+            neg_items = torch.randint(off, off + ds.n_items, users.shape, device=dev, dtype=torch.int32)
             emb = model.gnn(train_g, train_g.ndata["id"])
             loss = model.get_loss(emb, users, pos_items, neg_items)
             loss.backward()

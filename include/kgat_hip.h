@@ -56,10 +56,9 @@ enum {
   KGAT_ATT_ALGO_AUTO = 0,
   KGAT_ATT_ALGO_MFMA = 1,   /* v_mfma_f32_16x16x4_f32; d == k in {16,32,64,128} */
   KGAT_ATT_ALGO_GENERIC = 2, /* VALU, any (d,k) with d*k*4 <= 64 KiB */
-  /* MFMA tuning variants for A/B runs: BASE + bits (1: one 16-edge tile per wave step of the
-   * chunk kernel, 2: device-library tanhf instead of the exp2/rcp form, 4: workgroup-chunk
-   * kernel instead of the persistent-wavefront kernel, 8: one persistent wave per SIMD) */
-  KGAT_ATT_ALGO_VARIANT_BASE = 16
+  KGAT_ATT_ALGO_MFMA_CHUNK = 3 /* the workgroup-chunk MFMA kernel (W_r in LDS) that AUTO takes at d = 128, beyond
+                                * 4,096 relations and for tables of 4 GiB and more - selectable so that tests reach it
+                                * on small inputs */
 };
 
 /* flags for kgat_att_score_fused_f32 and kgat_att_score_folded_f32 */

@@ -1,5 +1,6 @@
 # Developer tool: the three bench lines of the driver's config (plain, 50 steps, under rocprofv3 kernel stats).  usage: bench_lines.sh <tag>
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-lines}; mkdir -p $O; cd $GRAFT_REPO_ROOT
+python3 -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo "build failed"; exit 1; }   # never build under the profiler
 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-hbm-leg > $O/bench_line_50steps.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 """Kernel micro-benchmarks on the benchmark graph (developer tool; not part of the product
 path or of bench.py's contract).  Interleaved rounds in one process, HIP events per launch.
 
-  python scripts/kbench.py att   [--algos mfma_v0,mfma_v1,...] [--dim 64]
+  python scripts/kbench.py att   [--algos mfma,mfma_chunk,generic] [--dim 64]
   python scripts/kbench.py spmm  [--algos merge,rows,rows_ordered] [--dim 64]
   python scripts/kbench.py softmax
 """
@@ -67,7 +67,7 @@ def main():
         ent = torch.randn(n, D, generator=g).to(dev)
         W = ((torch.rand(R, D, D, generator=g) - 0.5) * (2 * 1.414 * (6 / (D * D + R * D)) ** 0.5)).to(dev)
         rel = torch.randn(R, D, generator=g).to(dev)
-        algos = (args.algos or "mfma_v0,mfma_v2,mfma_v4,mfma_v5,mfma_v8").split(",")
+        algos = (args.algos or "mfma,mfma_chunk").split(",")
         fns = {a: (lambda a=a: ops.att_score(n, rel_ptr, perm, sg, dg, ent, W, rel, pos_g=pos, algo=a)) for a in algos}
         # split form: head projections once per (head, relation) group
         et_csr = ops.gather(eid, et)

@@ -1,7 +1,11 @@
 # Developer tool: issue / wait counters of the step's kernels (separate --pmc passes, kernel trace off).  usage: pmc_issue.sh <tag>
+# The library is built BEFORE the first profiler line (a stale library would otherwise be rebuilt from inside the
+# profiled process - hipcc children under the profiler's preload; _lib.load() refuses that).
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_issue}; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+python3 -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo "build failed"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-leg"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-train-leg"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/p1 --output-format csv -- $B > $O/p1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/p2 --output-format csv -- $B > $O/p2.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS -d $O/p3 --output-format csv -- $B > $O/p3.log 2>&1

@@ -4,6 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
+python3 -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo "build failed"; exit 1; }   # never build under the profiler
 if [ "$2" != "notests" ]; then
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
 tail -4 $O/pytest_gpu.log

@@ -542,8 +542,7 @@ with torch.no_grad():
     for mode in partition.EXCHANGE_MODES:
         if mode in ("p2p", "allgather"):
             continue                              # gloo: device send/recv staged through the host / equal slices only (CPU test)
-        os.environ["KGAT_EXCHANGE"] = mode
-        sg, keep = partition.shard_graph(g, rank, world)
+        sg, keep = partition.shard_graph(g, rank, world, mode=mode)
         a_loc = model.compute_attention(sg)       # all in-edges of the owned rows are local: no exchange
         assert float((a_loc.reshape(-1) - g.edata["w"].reshape(-1)[torch.as_tensor(keep, device=dev)]).abs().max()) <= 2e-6
         sg.edata["w"] = a_loc
@@ -569,8 +568,7 @@ with torch.no_grad():
     # the stretches between the exchanges replayed as HIP graphs, the collectives staying eager calls between the
     # replays (round 4: the first form kept ONE "current buffer" on the Python side, which a replay finds frozen at
     # the last layer's - every exchange then assembled the wrong buffer)
-    os.environ["KGAT_EXCHANGE"] = "allreduce"
-    sg, keep = partition.shard_graph(g, rank, world)
+    sg, keep = partition.shard_graph(g, rank, world, mode="allreduce")
     sg.edata["w"] = model.compute_attention(sg)
     eager = model.gnn(sg).clone()
     gs = K.GraphedForward(model, sg)

@@ -534,11 +534,24 @@ def test_attention_product_form_switches(monkeypatch):
     assert ops.fold_tile_cost(16) == ops.FOLD_TILE_COST_F32          # no bf16-piece form below 32
     assert ops.fold_tile_cost(64, f32_products=True) == ops.FOLD_TILE_COST_F32
     assert ops.ATT_F32_PRODUCTS == 1
+    from dgl_kgat_amd import options
     for val, want in (("", False), ("0", False), ("1", True), ("yes", True)):
+        before = graph._f32_products()
         monkeypatch.setenv("KGAT_ATT_F32_PRODUCTS", val)
+        assert graph._f32_products() is before     # the environment is read once, at import ...
+        options.reload()                            # ... or when a launcher asks for it
         assert graph._f32_products() is want
     monkeypatch.delenv("KGAT_ATT_F32_PRODUCTS")
+    options.reload()
     assert graph._f32_products() is False
+    with options.override(att_f32_products=True, fuse_bi=True):
+        assert graph._f32_products() is True and options.options.fuse_bi is True
+    assert graph._f32_products() is False and options.options.fuse_bi is False
+    # no module of the package reads the environment for behaviour outside options.py (_lib: the compiler path)
+    pkg = os.path.join(ROOT, "dgl-kgat_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py") and f not in ("options.py", "_lib.py"):
+            assert "os.environ" not in open(os.path.join(pkg, f)).read(), f
     # the header and the loader agree on the flag and on the ABI version that introduced it
     hdr = open(os.path.join(ROOT, "include", "kgat_hip.h")).read()
     assert "KGAT_ATT_F32_PRODUCTS = 1" in hdr and "#define KGAT_ABI_VERSION %d" % _lib.ABI_VERSION in hdr and _lib.ABI_VERSION >= 3
