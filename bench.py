@@ -872,10 +872,13 @@ def main():
         ref_flops = e_att * (4 * D * D + 3 * D)
         form, n_groups = getattr(g._st, "last_att_form", ("one", 0))
         if form == "fused":       # as folded, in one launch; hub blocks recompute their V rows per tile
+            from dgl_kgat_amd.graph import _fused_gpt
+            gpt = _fused_gpt(n, D)
             n_fold_tiles = int(g._st.rel_groups(g.edata["type"], n_rel, dev).g_tab["tiles"][1][-1])
-            flops = n_fold_tiles * 16 * 4 * D * D + e_att * 2 * D
-            kern = "kgat_att_score_fused_f32 (att_fold_fused_kernel: per 16-group tile 2 MFMA products, V rows " \
-                   "in LDS, gather-dot over the tile's edges; %d tiles)" % n_fold_tiles
+            flops = n_fold_tiles * gpt * 4 * D * D + e_att * 2 * D
+            kern = "kgat_att_score_fused_f32 (%s: per %d-group tile 2 MFMA products, V rows " \
+                   "in LDS, gather-dot over the tile's edges; %d tiles)" % (
+                       "att_fold_fused32_kernel" if gpt == 32 else "att_fold_fused_kernel", gpt, n_fold_tiles)
         elif form == "folded":    # per group W_r^T e_h and W_r T (2 x 2dk), per edge a d-length dot
             flops = n_groups * 4 * D * D + e_att * 2 * D
             kern = "kgat_att_score_folded_f32 (att_fold_head_kernel: 2 MFMA products per (head, relation) group; " \
@@ -892,7 +895,7 @@ def main():
         # v_mfma_f32_16x16x4_f32.  The ceiling of the first is the dense bf16 peak / 6.
         from dgl_kgat_amd.graph import _f32_products
         pieces = not _f32_products() and ((form == "fused" and D % 32 == 0) or (form == "folded" and D == 128))
-        att_peak = BF16_MFMA_PEAK_TF / 6.0 if pieces else FP32_MFMA_PEAK_TF
+        att_peak = BF16_MFMA_PEAK_TF / (5.0 if (pieces and form == "fused" and D == 64) else 6.0) if pieces else FP32_MFMA_PEAK_TF
         att_traffic, att_traffic_file = None, None
         if form == "fused" and world == 1 and args.workload == "amazon-book" and args.scale == 1.0 and D == 64:
             # committed PMC measurement of the identical launch (see the SpMM's `traffic` above)

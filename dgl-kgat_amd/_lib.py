@@ -54,11 +54,11 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _i32, _p]),
     "kgat_fold_tiles_max": (_i64, [_i64, _i64, _i32, _i32]),
     "kgat_fold_tiles_workspace_bytes": (_sz, [_i64, _i32]),
-    "kgat_fold_tiles": (_i32, [_i64, _i32, _i64, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
+    "kgat_fold_tiles": (_i32, [_i64, _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "kgat_att_score_fused_supported": (_i32, [_i64, _i32, _i32, _i32]),
     "kgat_fold_tile_parts_workspace_bytes": (_sz, [_i64]),
     "kgat_fold_tile_parts": (_i32, [_i64, _i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
-    "kgat_att_pack_records": (_i32, [_i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "kgat_att_pack_records": (_i32, [_i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "kgat_att_score_fused_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
                                         _p, _p, _p, _p, _p, _p, _i32, _p]),
     "kgat_edge_softmax_workspace_bytes": (_sz, [_i64, _i64]),

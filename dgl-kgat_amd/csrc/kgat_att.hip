@@ -599,7 +599,11 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const float* ent, const float* W_R, const float* rel, float* logits,
                              float* logits_csr, float* logits_g, int flags, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
-  KGAT_CHECK_ARG((flags & ~KGAT_ATT_F32_PRODUCTS) == 0, "att_score_fused: unknown flag");
+  KGAT_CHECK_ARG((flags & ~(KGAT_ATT_F32_PRODUCTS | KGAT_ATT_TILES32)) == 0, "att_score_fused: unknown flag");
+  if ((flags & KGAT_ATT_TILES32) && (d != 64 || k != 64 || (flags & KGAT_ATT_F32_PRODUCTS))) {
+    set_error("att_score_fused: 32-group tiles exist at d = k = 64 with the piece products only");
+    return KGAT_E_UNSUPPORTED;
+  }
   if (n_edges == 0) return KGAT_OK;
   if (!kgat_att_score_fused_supported(n_nodes, d, k, n_rel)) {
     set_error("att_score_fused: needs d == k in {16,32,64,128}, 0 < R <= %d, N*d*4 < 4 GiB (d=%d k=%d R=%d)",
@@ -610,7 +614,8 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
     set_error("att_score_fused: d = 128 runs the bf16-piece products only (the folded form has KGAT_ATT_F32_PRODUCTS)");
     return KGAT_E_UNSUPPORTED;
   }
-  KGAT_CHECK_ARG(n_nodes <= (1ll << 28), "att_score_fused: packed records hold node ids below 2^28");
+  KGAT_CHECK_ARG(n_nodes <= ((flags & KGAT_ATT_TILES32) ? (1ll << 27) : (1ll << 28)),
+                 "att_score_fused: packed records hold node ids below 2^28 (2^27 with 32-group tiles)");
   KGAT_CHECK_ARG(rel_ptr && rec_g && gptr && g_node && tiles && rel_tptr && ent && W_R && rel,
                  "att_score_fused: null pointer");
   KGAT_CHECK_ARG(logits || logits_csr || logits_g, "att_score_fused: no output requested");
@@ -629,6 +634,7 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   a.n_edges = n_edges;
   a.gid = nullptr; a.gptr = gptr; a.g_node = g_node;
   a.rec_g = rec_g; a.logits_g = logits_g;
+  if (flags & KGAT_ATT_TILES32) return launch_att_fold_fused32(a, rel_tptr, tiles);
   return launch_att_fold_fused_any(d, a, rel_tptr, tiles);
 }
 

@@ -108,7 +108,8 @@ struct AttArgs {
 int launch_att_persistent_any(int d, const AttArgs& a);
 int launch_att_split_any(int d, const AttArgs& a);
 int launch_att_fold_head_any(int d, const AttArgs& a);
-int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);  // writes V (n_groups x d) into a.G_tab
+int launch_att_fold_fused_any(int d, const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);
+int launch_att_fold_fused32(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles);  // d = 64, 32-group tiles  // writes V (n_groups x d) into a.G_tab
 constexpr int kAttMaxRelLds = 4096;
 
 // Lanes that share one edge in the per-edge dot product of the folded forms (a lane holds

@@ -4,7 +4,6 @@
 // Separate translation unit because it is built with -mllvm -amdgpu-mfma-vgpr-form=1 (MFMA
 // results in VGPRs, no v_accvgpr_read copies in the epilogue), which the LDS-staged chunk
 // kernels of kgat_att.hip do not want (it costs them occupancy).
-#include <stdlib.h>
 
 #include "kgat_att_common.h"
 
@@ -1430,6 +1429,395 @@ constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step 
     }
     t = seg_end;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused folded form on 32-GROUP tiles (d = k = 64, round 5; KGAT_ATT_TILES32, opt-in).  The same algorithm as
+// att_fold_fused_kernel - per tile the V rows of its head groups from two chained products at fp32 accuracy, parked
+// in the wavefront's LDS patch, then a gather-dot over the tile's positions - re-cut to test what rounds 3-4 took for
+// that kernel's bound, the instructions a SIMD has to issue per head group (478 vector instructions against 88 MFMAs
+// per 16-group tile, the matrix pipe 40 % busy):
+//  * v_mfma_f32_32x32x16_f16 on 32 groups: half as many matrix instructions per group, half as many fragment reads
+//    of W_r's pieces per group;
+//  * BOTH products on fp16 pieces: W_r 2^shift as three (exact), the head rows as two after a power-of-two scale PER
+//    ROW that brings the row's largest magnitude to [2^13, 2^14) (the scale is folded into the converts -
+//    v_fma_mixlo/mixhi_f16 - and leaves through the per-lane factor of the tanh argument's fma: lane (group, half)
+//    holds only its own group's columns), the tanh values 2^14 as two: five piece products per product (3 x 2, the
+//    2^-33 one dropped), cuts of 5 / 4 vector instructions per pair of values instead of 11;
+//  * twice the positions per tile: fewer partly filled 64-position chunks (69.7 k on the benchmark graph against
+//    89.0 k), half as many tile descriptors, claims and waits per group.
+// An fp32 operand as h + l with fp16 pieces carries 22 bits: |x s - h - l| <= 2^-23 |x s|, one more rounding of the
+// operand at fp32's own level, of either sign - what the 16-group kernel's second product has done to the tanh values
+// since round 4; error against fp64 no larger than the fp32-MFMA form's (test_att_fused_product_forms, which runs this
+// kernel too; test_att_fused32_tiles_and_logits: rows over 70 orders of magnitude, tiny and zero rows).
+// MEASURED (profiles/r05_att32_experiments.txt): 22.5 M vector + 2.5 M matrix instructions per launch against
+// 30.2 M + 5.6 M - and the SAME run time, 126-132 us in the step against 125-133.  So the instruction count is not
+// what bounds either kernel; nor is the gather (every row from a 1,024-row cache-resident slice: -5 us), nor the
+// residency (12 wavefronts per CU without the cross-phase row prefetch: the same), nor the split over workgroups
+// (max / mean of their end times 1.14, finer static splits slower).  A wavefront spends 16 k cycles on a 32-group
+// tile of which 4.5 k issue instructions: the rest are the in-order stalls of one long dependent sequence per
+// wavefront (MFMA port / RAW 39 %, memory 28 %), two such sequences per SIMD.  Not the default: equal speed does not
+// pay for a second arithmetic statement on the path.
+constexpr int kFused32Threads = 512;
+constexpr int kF32Groups = 32;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ floatx16 mfma32_f16(const uintx4& a, const uintx4& b, const floatx16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (a s, b s) as a packed fp16 pair, round to nearest even; s a power of two: the product is exact, one rounding
+__device__ __forceinline__ unsigned cvt_scaled_pk_f16(float a, float b, float s) {
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(r) : "v"(a), "v"(b), "v"(s));
+  return r;
+}
+__device__ __forceinline__ float rem_scaled_lo(float x, float s, unsigned hh) {  // x s - float(low half of hh)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hh));
+  return r;
+}
+__device__ __forceinline__ float rem_scaled_hi(float x, float s, unsigned hh) {  // x s - float(high half of hh)
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hh));
+  return r;
+}
+__device__ __forceinline__ void split_scaled_f16x2(const float (&x)[8], float s, uintx4& h, uintx4& m) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned hh = cvt_scaled_pk_f16(x[2 * t], x[2 * t + 1], s);
+    h[t] = hh;
+    m[t] = cvt_pk_f16(rem_scaled_lo(x[2 * t], s, hh), rem_scaled_hi(x[2 * t + 1], s, hh));
+  }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(kFused32Threads) void att_fold_fused32_kernel(
+    int n_rel, int64_t n_edges, const int32_t* __restrict__ rel_ptr, const int32_t* __restrict__ rel_tptr,
+    const int4* __restrict__ tiles, const int32_t* __restrict__ gptr, const int32_t* __restrict__ g_node,
+    const int32_t* __restrict__ rec_g, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ pos_g, const float* __restrict__ ent, const float* __restrict__ W_R,
+    const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr,
+    float* __restrict__ logits_g, const int32_t* __restrict__ part_tptr) {
+  constexpr int D_ = 64, K_ = 64;
+  constexpr bool LOGITS_EID = OUT == 2;
+  constexpr int ROW_SHIFT = 8;                         // log2 of a row's bytes
+  constexpr int NW = kFused32Threads / kWave;
+  constexpr int LPE = 4, VPL = 4;                      // lanes per edge, float4 pieces of a row per lane
+  constexpr int LDV = D_ + 4;
+  constexpr int NFRAG = 2 * 4 * kWave;                 // fragments of one piece of one product: [row tile][k-step][lane]
+  // W_r 2^shift as fp16 pieces in A-fragment order, [product][piece h,m,l][row tile][k-step][lane]
+  __shared__ uintx4 s_a[2 * 3 * NFRAG];
+  __shared__ __attribute__((aligned(16))) float s_v[NW][kF32Groups * LDV];
+  __shared__ __attribute__((aligned(16))) float s_rel[K_];   // e_r 2 log2(e)
+  __shared__ int32_t s_next;                                  // next unclaimed tile of the current relation segment
+  __shared__ unsigned s_wmax;                                 // bits of max |W_r| of the current relation
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave, w = tid / kWave;
+  const int gr = lane & 31, hf = lane >> 5;                   // MFMA column (head group of the tile), k half
+  const int li = lane % LPE;
+
+  {  // relation ids outside [0, R): logit 0
+    const int64_t n_scored = rel_ptr[n_rel];
+    for (int64_t p = n_scored + (int64_t)blockIdx.x * kFused32Threads + tid; p < n_edges;
+         p += (int64_t)gridDim.x * kFused32Threads) {
+      if (LOGITS_EID) logits[perm[p]] = 0.f;
+      if (OUT >= 1 && logits_csr) logits_csr[pos_g[p]] = 0.f;
+      if (logits_g) logits_g[p] = 0.f;
+    }
+  }
+  const int32_t n_tiles = rel_tptr[n_rel];
+  const unsigned part = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
+  const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
+  float* vrow = s_v[w];
+
+  int32_t t = t_begin;
+  while (t < t_end) {  // workgroup-uniform loop over relation segments
+    int lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rel_tptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int32_t rend = gptr[r + 1];
+    int32_t seg_end = rel_tptr[r + 1];
+    seg_end = seg_end < t_end ? seg_end : t_end;
+    if (tid == 0) s_wmax = 0u;  // (every wave has read the previous segment's value by now)
+    __syncthreads();            // every wave is done with the previous relation's W_r
+    if (tid == 0) s_next = t;
+    const float* W = W_R + (size_t)r * D_ * K_;
+    {
+      float mx = 0.f;
+      for (int idx = tid * 4; idx < D_ * K_; idx += kFused32Threads * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W + idx);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+      atomicMax(&s_wmax, __float_as_uint(mx));
+      if (tid < K_) s_rel[tid] = rel[(size_t)r * K_ + tid] * kTwoLog2e;
+    }
+    __syncthreads();
+    const int w_shift = __builtin_amdgcn_readfirstlane(f16_block_shift(s_wmax));
+    for (int f = tid; f < 2 * NFRAG; f += kFused32Threads) {
+      const int prod = f / NFRAG, g = f % NFRAG;
+      const int fl = g % kWave, fs = (g / kWave) % 4, ft = g / (kWave * 4);
+      const int fr = fl & 31, fh = fl >> 5;
+      float x[8];
+      if (prod == 0) {
+        // first product, G^T = W^T E^T: A[row 32 ft + fr][k = 16 fs + 8 fh + jj] = W[k][row]
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) x[jj] = ldexpf(W[(16 * fs + 8 * fh + jj) * K_ + 32 * ft + fr], w_shift);
+      } else {
+        // second product, V^T = W T: the contraction index of k-step fs = 2 tt + u, slot (fh, jj) is the G column the
+        // lane's accumulator register 8 u + jj of row tile tt holds: 32 tt + 8 (2 u + jj / 4) + 4 fh + jj % 4
+        const int tt = fs >> 1, u = fs & 1;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          x[jj] = ldexpf(W[(32 * ft + fr) * K_ + 32 * tt + 8 * (2 * u + (jj >> 2)) + 4 * fh + (jj & 3)], w_shift);
+      }
+      uintx4 h, m, l;
+      split_f16x3(x, h, m, l);
+      s_a[(prod * 3 + 0) * NFRAG + g] = h; s_a[(prod * 3 + 1) * NFRAG + g] = m; s_a[(prod * 3 + 2) * NFRAG + g] = l;
+    }
+    __syncthreads();
+
+    auto desc_of = [&](int32_t n) -> int4 {
+      n = n < seg_end ? n : seg_end - 1;
+      return tiles[n];
+    };
+    struct CIdx { int32_t row_off, lg, oe, op; };
+    auto head_idx = [&](const int4& d) -> int32_t {
+      int32_t g = d.y + gr;
+      g = g < rend ? g : rend - 1;
+      return g_node[g];
+    };
+    auto chunk_idx = [&](const int4& d, int32_t p0) -> CIdx {
+      int32_t p = p0 + lane;
+      p = p < d.w ? p : d.w - 1;
+      CIdx c;
+      const uint32_t rec = (uint32_t)rec_g[p];
+      c.row_off = (int32_t)(rec << ROW_SHIFT);   // (node ids below 2^24: the shift drops the five slot bits)
+      c.lg = (int32_t)(rec >> 27);
+      c.oe = LOGITS_EID ? perm[p] : 0;
+      c.op = (OUT >= 1 && logits_csr) ? pos_g[p] : 0;
+      return c;
+    };
+    struct HBuf { float a[32]; };
+    // lane (group gr, half hf) takes its group's head row elements 16 s + 8 hf .. + 7 of every k-step s
+    auto load_head = [&](HBuf& f, int32_t row) {
+      const char* base = reinterpret_cast<const char*>(ent);
+      const uint32_t o = (uint32_t)row * (uint32_t)(D_ * 4) + (uint32_t)(hf * 32);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(base + o + s * 64);
+        const float4 v1 = *reinterpret_cast<const float4*>(base + o + s * 64 + 16);
+        f.a[8 * s + 0] = v0.x; f.a[8 * s + 1] = v0.y; f.a[8 * s + 2] = v0.z; f.a[8 * s + 3] = v0.w;
+        f.a[8 * s + 4] = v1.x; f.a[8 * s + 5] = v1.y; f.a[8 * s + 6] = v1.z; f.a[8 * s + 7] = v1.w;
+      }
+    };
+    struct EBuf { float4 r[LPE][VPL]; };
+    const char* eb = reinterpret_cast<const char*>(ent) + li * 16;
+    auto load_edges = [&](EBuf& e, const CIdx& c) {
+#pragma unroll
+      for (int s = 0; s < LPE; ++s) {
+        const uint32_t eo = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.row_off);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) e.r[s][v] = *reinterpret_cast<const float4*>(eb + eo + v * (LPE * 16));
+      }
+    };
+    // V rows of the tile's 32 groups into the wave's patch; `f` is free again after the first product: the next
+    // tile's head rows are requested into it there and arrive during the rest of the step
+    auto mfma_phase = [&](HBuf& f, int32_t next_row) {
+      float mx = fabsf(f.a[0]);
+#pragma unroll
+      for (int i = 1; i < 32; ++i) mx = fmaxf(mx, fabsf(f.a[i]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the other half of the row
+      const int ex = (int)(__float_as_uint(mx) >> 23);   // (mx >= 0)
+      int sh = (ex == 0 || ex == 255) ? 0 : 140 - ex;     // brings the row's largest magnitude into [2^13, 2^14)
+      sh = sh > 126 ? 126 : sh;
+      const float sc = __uint_as_float((unsigned)(sh + 127) << 23);
+      const float cl = ldexpf(kTwoLog2e, -sh - w_shift);  // G = G' 2^-(sh + w_shift); tanh argument scale 2 log2(e)
+      floatx16 acc[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.f;
+      {
+        const uintx4* fa = s_a + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float x[8];
+          uintx4 bh, bl;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = f.a[8 * s + jj];
+          split_scaled_f16x2(x, sc, bh, bl);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {  // five piece products, smallest first
+            const uintx4 ah = fa[0 * NFRAG + (tt * 4 + s) * kWave];
+            const uintx4 am = fa[1 * NFRAG + (tt * 4 + s) * kWave];
+            const uintx4 al = fa[2 * NFRAG + (tt * 4 + s) * kWave];
+            acc[tt] = mfma32_f16(al, bh, acc[tt]);
+            acc[tt] = mfma32_f16(am, bl, acc[tt]);
+            acc[tt] = mfma32_f16(am, bh, acc[tt]);
+            acc[tt] = mfma32_f16(ah, bl, acc[tt]);
+            acc[tt] = mfma32_f16(ah, bh, acc[tt]);
+          }
+        }
+      }
+      load_head(f, next_row);
+      // acc[tt][4 q + i] = G'[group gr][column 32 tt + 8 q + 4 hf + i]: tanh, scaled by 2^14 for the fp16 cut
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 rv = *reinterpret_cast<const float4*>(s_rel + 32 * tt + 8 * q + 4 * hf);
+          const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y = fmaf(acc[tt][4 * q + i], cl, rr[i]);
+            acc[tt][4 * q + i] = fmaf(-32768.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 16384.0f);
+          }
+        }
+      floatx16 v[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[tt][i] = 0.f;
+      {
+        const uintx4* fa = s_a + 3 * NFRAG + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // k-step s = 2 tt + u: registers 8 u .. 8 u + 7 of row tile tt
+          float x[8];
+          uintx4 bh, bl;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = acc[s >> 1][8 * (s & 1) + jj];
+          split_f16x2(x, bh, bl);        // |tanh| 2^14 < 16,384: inside fp16's range
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const uintx4 ah = fa[0 * NFRAG + (t2 * 4 + s) * kWave];
+            const uintx4 am = fa[1 * NFRAG + (t2 * 4 + s) * kWave];
+            const uintx4 al = fa[2 * NFRAG + (t2 * 4 + s) * kWave];
+            v[t2] = mfma32_f16(al, bh, v[t2]);
+            v[t2] = mfma32_f16(am, bl, v[t2]);
+            v[t2] = mfma32_f16(am, bh, v[t2]);
+            v[t2] = mfma32_f16(ah, bl, v[t2]);
+            v[t2] = mfma32_f16(ah, bh, v[t2]);
+          }
+        }
+      }
+      // v[t2][4 q + i] = V'[group gr][32 t2 + 8 q + 4 hf + i] -> the wave's LDS patch, row = group
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous tile's reads are done
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 o;
+          o.x = v[t2][4 * q + 0]; o.y = v[t2][4 * q + 1]; o.z = v[t2][4 * q + 2]; o.w = v[t2][4 * q + 3];
+          *reinterpret_cast<float4*>(vrow + gr * LDV + 32 * t2 + 8 * q + 4 * hf) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto edge_phase = [&](const EBuf& e, const CIdx& c, int32_t p0, int32_t pe) {
+      float mine = 0.f;
+#pragma unroll
+      for (int s = 0; s < LPE; ++s) {
+        const int32_t lg = __builtin_amdgcn_ds_bpermute((lane - li + s) << 2, c.lg);
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const float4 b = *reinterpret_cast<const float4*>(vrow + lg * LDV + 4 * li + v * (LPE * 4));
+          d = v == 0 ? e.r[s][v].x * b.x : fmaf(e.r[s][v].x, b.x, d);
+          d = fmaf(e.r[s][v].y, b.y, d);
+          d = fmaf(e.r[s][v].z, b.z, d);
+          d = fmaf(e.r[s][v].w, b.w, d);
+        }
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
+        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+        mine = li == s ? d : mine;
+      }
+      mine = ldexpf(mine, -w_shift - 14);  // (V rows are those of (W_r 2^w_shift) (T 2^14))
+      if (p0 + lane < pe) {
+        if (LOGITS_EID) logits[c.oe] = mine;
+        if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;
+        if (logits_g) logits_g[p0 + lane] = mine;
+      }
+    };
+
+    auto claim = [&]() -> int32_t {
+      int32_t g = 0;
+      if (lane == 0) g = atomicAdd(&s_next, 1);
+      return __builtin_amdgcn_readfirstlane(g);
+    };
+    int32_t n = claim();
+    if (n < seg_end) {
+      int32_t n1 = claim(), n2 = claim();
+      int4 d0 = desc_of(n), d1 = desc_of(n1), d2 = desc_of(n2);
+      int32_t h1 = head_idx(d1);
+      CIdx c0 = chunk_idx(d0, d0.z);
+      HBuf hb;
+      load_head(hb, head_idx(d0));
+      while (true) {
+        const int32_t n3 = claim();
+        const int4 d3 = desc_of(n3);
+        const int32_t h2 = head_idx(d2);
+        const CIdx c1 = chunk_idx(d1, d1.z);
+        // indices of the second to fourth chunk: requested before the MFMA phase, which hides their trip from HBM
+        CIdx cx = chunk_idx(d0, d0.z + kWave);
+        const CIdx cy = chunk_idx(d0, d0.z + 2 * kWave);
+        const CIdx cz = chunk_idx(d0, d0.z + 3 * kWave);
+        EBuf eb0;
+        load_edges(eb0, c0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(hb, h1);
+        __builtin_amdgcn_sched_barrier(0);
+        edge_phase(eb0, c0, d0.z, d0.w);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d0.z + kWave < d0.w) {
+          load_edges(eb0, cx);
+          edge_phase(eb0, cx, d0.z + kWave, d0.w);
+          if (d0.z + 2 * kWave < d0.w) {
+            load_edges(eb0, cy);
+            cx = chunk_idx(d0, d0.z + 4 * kWave);
+            edge_phase(eb0, cy, d0.z + 2 * kWave, d0.w);
+            if (d0.z + 3 * kWave < d0.w) {
+              load_edges(eb0, cz);
+              edge_phase(eb0, cz, d0.z + 3 * kWave, d0.w);
+              for (int32_t p0 = d0.z + 4 * kWave; p0 < d0.w; p0 += kWave) {
+                load_edges(eb0, cx);
+                const CIdx cn = chunk_idx(d0, p0 + kWave);
+                edge_phase(eb0, cx, p0, d0.w);
+                cx = cn;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        d0 = d1; d1 = d2; d2 = d3;
+        h1 = h2;
+        c0 = c1;
+        n = n1; n1 = n2; n2 = n3;
+        if (n >= seg_end) break;
+      }
+    }
+    t = seg_end;
+  }
+}
+
+template <int OUT>
+static void launch_att_fold_fused32_form(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
+  hipLaunchKernelGGL((att_fold_fused32_kernel<OUT>), dim3(grid), dim3(kFused32Threads), 0, a.st, a.n_rel, a.n_edges,
+                     a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.rec_g, a.perm,
+                     a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr);
+}
+
+int launch_att_fold_fused32(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {
+  if (a.logits) launch_att_fold_fused32_form<2>(a, rel_tptr, tiles);
+  else if (a.logits_csr) launch_att_fold_fused32_form<1>(a, rel_tptr, tiles);
+  else launch_att_fold_fused32_form<0>(a, rel_tptr, tiles);
+  KGAT_CHECK_LAUNCH("att_fold_fused32");
+  return KGAT_OK;
 }
 
 template <int D_, int OUT, bool X3>

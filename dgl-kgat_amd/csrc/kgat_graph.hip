@@ -394,9 +394,10 @@ __global__ void group_ptr_kernel(int n_rel, const int32_t* __restrict__ rel_ptr,
 // ---- packed per-position records of the fused attention kernel (kgat_att_pack_records)
 __global__ void att_pack_records_kernel(int64_t n_edges, int n_rel, const int32_t* __restrict__ rel_ptr,
                                         const int32_t* __restrict__ gptr, const int32_t* __restrict__ gid,
-                                        const int32_t* __restrict__ src_g, int32_t* __restrict__ rec_g) {
+                                        const int32_t* __restrict__ src_g, int32_t* __restrict__ rec_g, int gpt) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_edges) return;
+  const int slot_shift = gpt == 32 ? 27 : 28;   // the slot of 16 / 32 groups in the top 4 / 5 bits
   uint32_t rec = (uint32_t)src_g[p];
   if (p < rel_ptr[n_rel]) {
     int lo = 0, hi = n_rel;  // relation of position p: largest r with rel_ptr[r] <= p
@@ -404,7 +405,7 @@ __global__ void att_pack_records_kernel(int64_t n_edges, int n_rel, const int32_
       const int mid = (lo + hi) >> 1;
       if (rel_ptr[mid] <= p) lo = mid; else hi = mid;
     }
-    rec |= (uint32_t)((gid[p] - gptr[lo]) & 15) << 28;
+    rec |= (uint32_t)((gid[p] - gptr[lo]) & (gpt - 1)) << slot_shift;
   }
   rec_g[p] = (int32_t)rec;
 }
@@ -418,32 +419,32 @@ __global__ void fold_gstart_kernel(int n_rel, const int32_t* __restrict__ rel_pt
   if (p == 0) gstart[n_groups] = (int32_t)n_scored;
 }
 // one thread: base-tile prefix per relation (16 groups per base tile, relations kept apart)
-__global__ void fold_base_ptr_kernel(int n_rel, const int32_t* __restrict__ gptr, int32_t* __restrict__ bptr) {
+__global__ void fold_base_ptr_kernel(int n_rel, const int32_t* __restrict__ gptr, int32_t* __restrict__ bptr, int gpt) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int32_t run = 0;
   bptr[0] = 0;
   for (int r = 0; r < n_rel; ++r) {
-    run += (gptr[r + 1] - gptr[r] + 15) >> 4;
+    run += (gptr[r + 1] - gptr[r] + gpt - 1) / gpt;
     bptr[r + 1] = run;
   }
 }
 __device__ __forceinline__ int fold_base_tile(int n_rel, const int32_t* __restrict__ bptr,
                                               const int32_t* __restrict__ gptr,
-                                              const int32_t* __restrict__ gstart, int32_t b, int32_t& g0,
-                                              int32_t& pb, int32_t& pe) {
+                                              const int32_t* __restrict__ gstart, int32_t b, int gpt,
+                                              int32_t& g0, int32_t& pb, int32_t& pe) {
   int lo = 0, hi = n_rel;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (bptr[mid] <= b) lo = mid; else hi = mid;
   }
-  g0 = gptr[lo] + ((b - bptr[lo]) << 4);
-  const int32_t g1 = g0 + 16 < gptr[lo + 1] ? g0 + 16 : gptr[lo + 1];
+  g0 = gptr[lo] + (b - bptr[lo]) * gpt;
+  const int32_t g1 = g0 + gpt < gptr[lo + 1] ? g0 + gpt : gptr[lo + 1];
   pb = gstart[g0];
   pe = gstart[g1];
   return lo;
 }
 // cnt[b] = number of tiles base tile b becomes (0 past the last base tile); cnt has nb_max + 1 entries
-__global__ void fold_count_kernel(int n_rel, int64_t nb_max, int cap, const int32_t* __restrict__ bptr,
+__global__ void fold_count_kernel(int n_rel, int64_t nb_max, int cap, int gpt, const int32_t* __restrict__ bptr,
                                   const int32_t* __restrict__ gptr, const int32_t* __restrict__ gstart,
                                   int32_t* __restrict__ cnt) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,14 +452,14 @@ __global__ void fold_count_kernel(int n_rel, int64_t nb_max, int cap, const int3
   int32_t c = 0;
   if (b < bptr[n_rel]) {
     int32_t g0, pb, pe;
-    fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, g0, pb, pe);
+    fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, gpt, g0, pb, pe);
     c = (pe - pb + cap - 1) / cap;
     c = c > 0 ? c : 1;
   }
   cnt[b] = c;
 }
 // off = exclusive scan of cnt; writes the tiles, the tile prefix per relation and the tile count
-__global__ void fold_emit_kernel(int n_rel, int64_t nb_max, int cap, const int32_t* __restrict__ bptr,
+__global__ void fold_emit_kernel(int n_rel, int64_t nb_max, int cap, int gpt, const int32_t* __restrict__ bptr,
                                  const int32_t* __restrict__ gptr, const int32_t* __restrict__ gstart,
                                  const int32_t* __restrict__ off, int32_t* __restrict__ tiles,
                                  int32_t* __restrict__ rel_tptr) {
@@ -466,7 +467,7 @@ __global__ void fold_emit_kernel(int n_rel, int64_t nb_max, int cap, const int32
   if (b <= n_rel) rel_tptr[b] = off[bptr[b]];
   if (b >= bptr[n_rel]) return;
   int32_t g0, pb, pe;
-  const int r = fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, g0, pb, pe);
+  const int r = fold_base_tile(n_rel, bptr, gptr, gstart, (int32_t)b, gpt, g0, pb, pe);
   int32_t t = off[b];
   int32_t p = pb;
   do {
@@ -637,8 +638,10 @@ size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel) {
 }
 
 int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,
-                    const int32_t* gptr, int cap, int32_t* tiles, int32_t* rel_tptr, void* workspace,
-                    size_t workspace_bytes, kgat_stream_t stream) {
+                    const int32_t* gptr, int cap, int groups_per_tile, int32_t* tiles, int32_t* rel_tptr,
+                    void* workspace, size_t workspace_bytes, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(groups_per_tile == 16 || groups_per_tile == 32, "fold_tiles: 16 or 32 groups per tile");
+  const int gpt = groups_per_tile;
   KGAT_CHECK_ARG(n_edges >= 0 && n_edges < INT32_MAX - 1 && n_rel > 0 && n_groups >= 0 && n_groups <= n_edges,
                  "fold_tiles: bad size");
   KGAT_CHECK_ARG(cap >= 64 && cap % 64 == 0, "fold_tiles: cap must be a positive multiple of 64");
@@ -658,27 +661,29 @@ int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t*
   hipLaunchKernelGGL(fold_gstart_kernel, dim3(blocks_for(n_edges > 0 ? n_edges : 1, 256)), dim3(256), 0, st, n_rel,
                      rel_ptr, n_groups, gid, gstart);
   KGAT_CHECK_LAUNCH("fold_gstart");
-  hipLaunchKernelGGL(fold_base_ptr_kernel, dim3(1), dim3(64), 0, st, n_rel, gptr, bptr);
+  hipLaunchKernelGGL(fold_base_ptr_kernel, dim3(1), dim3(64), 0, st, n_rel, gptr, bptr, gpt);
   KGAT_CHECK_LAUNCH("fold_base_ptr");
-  hipLaunchKernelGGL(fold_count_kernel, dim3(blocks_for(nb_max + 1, 256)), dim3(256), 0, st, n_rel, nb_max, cap,
+  hipLaunchKernelGGL(fold_count_kernel, dim3(blocks_for(nb_max + 1, 256)), dim3(256), 0, st, n_rel, nb_max, cap, gpt,
                      (const int32_t*)bptr, gptr, (const int32_t*)gstart, cnt);
   KGAT_CHECK_LAUNCH("fold_count");
   const int rc = exclusive_scan_i32(cnt, nb_max + 1, scan_ws, st);
   if (rc != KGAT_OK) return rc;
   const int64_t n_thr = nb_max > n_rel + 1 ? nb_max : n_rel + 1;
-  hipLaunchKernelGGL(fold_emit_kernel, dim3(blocks_for(n_thr, 256)), dim3(256), 0, st, n_rel, nb_max, cap,
+  hipLaunchKernelGGL(fold_emit_kernel, dim3(blocks_for(n_thr, 256)), dim3(256), 0, st, n_rel, nb_max, cap, gpt,
                      (const int32_t*)bptr, gptr, (const int32_t*)gstart, (const int32_t*)cnt, tiles, rel_tptr);
   KGAT_CHECK_LAUNCH("fold_emit");
   return KGAT_OK;
 }
 
 int kgat_att_pack_records(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* gptr,
-                          const int32_t* gid, const int32_t* src_g, int32_t* rec_g, kgat_stream_t stream) {
+                          const int32_t* gid, const int32_t* src_g, int groups_per_tile, int32_t* rec_g,
+                          kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_edges >= 0 && n_edges < INT32_MAX && n_rel > 0, "att_pack_records: bad size");
+  KGAT_CHECK_ARG(groups_per_tile == 16 || groups_per_tile == 32, "att_pack_records: 16 or 32 groups per tile");
   if (n_edges == 0) return KGAT_OK;
   KGAT_CHECK_ARG(rel_ptr && gptr && gid && src_g && rec_g, "att_pack_records: null pointer");
   hipLaunchKernelGGL(att_pack_records_kernel, dim3(blocks_for(n_edges, 256)), dim3(256), 0, as_stream(stream), n_edges,
-                     n_rel, rel_ptr, gptr, gid, src_g, rec_g);
+                     n_rel, rel_ptr, gptr, gid, src_g, rec_g, groups_per_tile);
   KGAT_CHECK_LAUNCH("att_pack_records");
   return KGAT_OK;
 }

@@ -324,24 +324,39 @@ def _f32_products():
     return options.att_f32_products
 
 
-def _fused_statics(groups):
-    """Packed records + the CSR-position -> grouped-position map of the fused path (graph-static)."""
-    rec = groups.g_tab.get("rec_g")
-    if rec is None:
-        rec = groups.g_tab["rec_g"] = ops.att_pack_records(groups.rel_ptr, groups.gptr, groups.gid, groups.src_g)
+def _fused_gpt(n_nodes, d):
+    """Head groups per work tile of the fused attention kernel: 32 at d = k = 64 with the piece products (the kernel on
+    v_mfma_f32_32x32x16_f16, KGAT_ATT_TILES32; node ids below 2^27), else 16."""
+    return 32 if (d == 64 and options.att_tiles32 and not _f32_products() and n_nodes < (1 << 27)) else 16
+
+
+def _gpos_csr(groups):
+    """The CSR-position -> grouped-position map the softmax reads grouped-order logits through (graph-static)."""
+    if "gpos_csr" not in groups.g_tab:
         groups.g_tab["gpos_csr"] = ops.invert_permutation(groups.pos_g)
-    return rec, groups.g_tab["gpos_csr"]
+    return groups.g_tab["gpos_csr"]
 
 
-def _fused_tiles(groups, d):
+def _fused_statics(groups, gpt=16):
+    """Packed records of the fused path for `gpt` groups per tile + the position map (graph-static)."""
+    rec = groups.g_tab.get(("rec_g", gpt))
+    if rec is None:
+        rec = groups.g_tab[("rec_g", gpt)] = ops.att_pack_records(groups.rel_ptr, groups.gptr, groups.gid, groups.src_g,
+                                                                  groups_per_tile=gpt)
+    return rec, _gpos_csr(groups)
+
+
+def _fused_tiles(groups, d, gpt=16):
     """Work tiles of the fused attention kernel and their split over the workgroups, kept with the
     relation grouping (graph-static); the split cost goes with the product form taken at width d."""
-    cost = ops.fold_tile_cost(d, _f32_products())
+    cost = ops.fold_tile_cost(d, _f32_products(), gpt)
+    key = (cost, gpt)
     tiles = groups.g_tab.get("tiles")
-    if tiles is None or groups.g_tab.get("tiles_cost") != cost:
+    if tiles is None or groups.g_tab.get("tiles_cost") != key:
         tiles = groups.g_tab["tiles"] = ops.fold_tiles(groups.rel_ptr, groups.gid, groups.gptr, groups.n_groups,
-                                                       cost=cost)
-        groups.g_tab["tiles_cost"] = cost
+                                                       cap=ops.FOLD_TILE_CAP32 if gpt == 32 else ops.FOLD_TILE_CAP,
+                                                       cost=cost, groups_per_tile=gpt)
+        groups.g_tab["tiles_cost"] = key
     return tiles
 
 
@@ -597,9 +612,10 @@ class DGLGraph:
                         best = (ms, f)
                 form = best[1]
             else:
-                tiles = _fused_tiles(groups, d)
+                gpt = _fused_gpt(st.n_nodes, d)
+                tiles = _fused_tiles(groups, d, gpt)
                 n_tiles = int(tiles[1][-1])
-                form = "fused" if n_tiles <= 2 * ((groups.n_groups + 15) // 16) else "folded"
+                form = "fused" if n_tiles <= 2 * ((groups.n_groups + gpt - 1) // gpt) else "folded"
             groups.g_tab.pop("tiles" if form == "folded" else d, None)  # the other form's scratch
             return form
         if fused_ok:
@@ -636,8 +652,9 @@ class DGLGraph:
 
         def run(form):
             if form == "fused":
-                tiles = _fused_tiles(groups, d)  # graph-static work tiles of the fused kernel
-                rec, _ = _fused_statics(groups)
+                gpt = _fused_gpt(st.n_nodes, d)
+                tiles = _fused_tiles(groups, d, gpt)  # graph-static work tiles of the fused kernel
+                rec, _ = _fused_statics(groups, gpt)
                 # the logits leave in grouped order (coalesced stores); the softmax reads them through
                 # the inverse position map.  KGAT_ATT_SCATTER_CSR=1: the round-2 form, a 4-byte
                 # scatter into CSR order (73 MB written for 14.6 MB of logits on the benchmark graph)
@@ -645,7 +662,7 @@ class DGLGraph:
                                           groups.gid, groups.gptr, groups.g_node, tiles[0], tiles[1],
                                           ent_c, W_c, rel_c, want_eid=False, want_csr=not grouped_out,
                                           want_grouped=grouped_out, part_tptr=tiles[2],
-                                          f32_products=_f32_products(), rec_g=rec)
+                                          f32_products=_f32_products(), rec_g=rec, groups_per_tile=gpt)
                 return res[2] if grouped_out else res[1]
             if form in ("folded", "split"):
                 folded = form == "folded"
@@ -675,7 +692,7 @@ class DGLGraph:
         if form == "fused" and grouped_out:
             # grouped-order logits: the sweep gathers logits[gpos_csr[q]] for CSR position q (the map
             # takes the place of `eid` on the input side; no edge-id-ordered output is asked for)
-            _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, _fused_statics(groups)[1], logits,
+            _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, _gpos_csr(groups), logits,
                                         in_csr_order=False, want_out=False, want_csr=True)
         else:
             _, a_csr = ops.edge_softmax(csr.indptr, csr.row_of, csr.eid, logits, in_csr_order=True,

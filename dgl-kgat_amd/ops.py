@@ -197,6 +197,7 @@ def head_groups(rel_ptr, dst_g):
 
 
 ATT_F32_PRODUCTS = 1  # include/kgat_hip.h: KGAT_ATT_F32_PRODUCTS
+ATT_TILES32 = 2       # include/kgat_hip.h: KGAT_ATT_TILES32
 
 
 def att_score_split_supported(n_nodes, d, k, n_rel):
@@ -248,6 +249,7 @@ def att_score_split(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, n_g
 # small part of its workgroup's time for the eight waves to balance.  Measured on MI355X with the
 # cost-balanced split (amazon-book-shaped CKG): 128: 0.2135 ms, 256: 0.2019.
 FOLD_TILE_CAP = 256
+FOLD_TILE_CAP32 = 512   # 32-group tiles (d = 64): the same positions per head group
 # per-tile cost model of the fused kernel (kgat_fold_tile_parts; from per-workgroup clock stamps,
 # scripts/micro/att_stamps.py): a tile, a chunk of 64 positions past the first 64, a relation
 # change inside a workgroup's range.  With the bf16-piece products (d % 32 == 0) the fit is 649
@@ -269,7 +271,10 @@ FOLD_TILE_COST_F32 = (64, 12, 466)
 FOLD_TILE_COST_128 = (64, 12, 700)
 
 
-def fold_tile_cost(d, f32_products=False):
+FOLD_TILE_COST32 = (110, 38, 1051)   # 32-group tiles: a tile's MFMA phase serves twice the groups (round 5)
+
+
+def fold_tile_cost(d, f32_products=False, groups_per_tile=16):
     """The split cost that goes with the product form att_score_fused takes at width d
     (``KGAT_FOLD_TILE_COST="tile,chunk,relation"`` overrides it: A/B runs of the whole step)."""
     from .options import options
@@ -277,10 +282,12 @@ def fold_tile_cost(d, f32_products=False):
         return options.fold_tile_cost
     if d == 128:
         return FOLD_TILE_COST_128
+    if groups_per_tile == 32:
+        return FOLD_TILE_COST32
     return FOLD_TILE_COST if (d % 32 == 0 and not f32_products) else FOLD_TILE_COST_F32
 
 
-def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, cost=FOLD_TILE_COST):
+def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, cost=FOLD_TILE_COST, groups_per_tile=16):
     """Work tiles of the fused attention kernel (kgat_fold_tiles) and their cost-balanced split
     over `n_parts` workgroups (kgat_fold_tile_parts; default: one per compute unit).  Returns
     (tiles (T_max, 4) int32, rel_tptr (R+1,) int32, part_tptr (n_parts+1,) int32); rel_tptr[-1]
@@ -296,8 +303,9 @@ def fold_tiles(rel_ptr, gid, gptr, n_groups, cap=FOLD_TILE_CAP, n_parts=None, co
     tiles = torch.zeros((t_max, 4), dtype=torch.int32, device=dev)
     rel_tptr = torch.zeros(n_rel + 1, dtype=torch.int32, device=dev)
     ws = _workspace(lib.kgat_fold_tiles_workspace_bytes(int(n_groups), n_rel), dev)
-    check(lib.kgat_fold_tiles(e, n_rel, int(n_groups), _ptr(rel_ptr), _ptr(gid), _ptr(gptr), int(cap), _ptr(tiles),
-                              _ptr(rel_tptr), _ptr(ws), ws.numel(), _stream(gid)), "kgat_fold_tiles")
+    check(lib.kgat_fold_tiles(e, n_rel, int(n_groups), _ptr(rel_ptr), _ptr(gid), _ptr(gptr), int(cap),
+                              int(groups_per_tile), _ptr(tiles), _ptr(rel_tptr), _ptr(ws), ws.numel(), _stream(gid)),
+          "kgat_fold_tiles")
     if n_parts is None:
         n_parts = torch.cuda.get_device_properties(dev).multi_processor_count
     part_tptr = torch.zeros(int(n_parts) + 1, dtype=torch.int32, device=dev)
@@ -312,9 +320,9 @@ def att_score_fused_supported(n_nodes, d, k, n_rel):
     return bool(_lib.load().kgat_att_score_fused_supported(int(n_nodes), int(d), int(k), int(n_rel)))
 
 
-def att_pack_records(rel_ptr, gptr, gid, src_g):
-    """rec_g[p] = src_g[p] | (slot of p's head group in its 16-group block << 28): the one index the
-    fused attention kernel reads per grouped position (kgat_att_pack_records; graph-static)."""
+def att_pack_records(rel_ptr, gptr, gid, src_g, groups_per_tile=16):
+    """rec_g[p] = src_g[p] | (slot of p's head group in its 16-group block << 28; 32-group block << 27): the one
+    index the fused attention kernel reads per grouped position (kgat_att_pack_records; graph-static)."""
     rel_ptr = _need(rel_ptr, torch.int32, "rel_ptr")
     gptr = _need(gptr, torch.int32, "gptr", rel_ptr.shape)
     src_g = _need(src_g, torch.int32, "src_g")
@@ -322,12 +330,13 @@ def att_pack_records(rel_ptr, gptr, gid, src_g):
     gid = _need(gid, torch.int32, "gid", (e,))
     rec = torch.empty(e, dtype=torch.int32, device=src_g.device)
     check(_lib.load().kgat_att_pack_records(e, rel_ptr.numel() - 1, _ptr(rel_ptr), _ptr(gptr), _ptr(gid), _ptr(src_g),
-                                            _ptr(rec), _stream(src_g)), "kgat_att_pack_records")
+                                            int(groups_per_tile), _ptr(rec), _stream(src_g)), "kgat_att_pack_records")
     return rec
 
 
 def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
-                    want_csr=True, want_eid=True, part_tptr=None, f32_products=False, rec_g=None, want_grouped=False):
+                    want_csr=True, want_eid=True, part_tptr=None, f32_products=False, rec_g=None, want_grouped=False,
+                    groups_per_tile=16):
     """Attention logits, fused folded form (kgat_att_score_fused_f32).  The kernel reads one packed
     record per grouped position (`rec_g`, att_pack_records; built here from `src_g` / `gid` when the
     caller does not keep one).  `part_tptr`: the tile range of every workgroup (fold_tiles); None:
@@ -342,7 +351,7 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
     _need(rel_ptr, torch.int32, "rel_ptr", (n_rel + 1,))
     _need(gptr, torch.int32, "gptr", (n_rel + 1,))
     if rec_g is None:
-        rec_g = att_pack_records(rel_ptr, gptr, gid, src_g)
+        rec_g = att_pack_records(rel_ptr, gptr, gid, src_g, groups_per_tile)
     rec_g = _need(rec_g, torch.int32, "rec_g")
     e = rec_g.numel()
     if want_eid:
@@ -364,8 +373,8 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
                                                    _ptr(rec_g), _ptr(pos_g) if want_csr else None, _ptr(gptr),
                                                    _ptr(g_node), _ptr(tiles), _ptr(rel_tptr), _ptr(part_tptr), n_parts,
                                                    _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits), _ptr(logits_csr),
-                                                   _ptr(logits_g), ATT_F32_PRODUCTS if f32_products else 0,
-                                                   _stream(ent)),
+                                                   _ptr(logits_g), (ATT_F32_PRODUCTS if f32_products else 0) |
+                                                   (ATT_TILES32 if groups_per_tile == 32 else 0), _stream(ent)),
               "kgat_att_score_fused_f32")
     return (logits, logits_csr, logits_g) if want_grouped else (logits, logits_csr)
 

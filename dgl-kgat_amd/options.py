@@ -10,6 +10,7 @@ import).
 environment variable           default  meaning
 =============================  =======  =====================================================================
 KGAT_ATT_F32_PRODUCTS          0        attention products on the fp32 MFMA instead of the bf16/fp16-piece products
+KGAT_ATT_TILES32               0        fused attention at d = 64 on 32-group tiles (v_mfma_f32_32x32x16_f16; same speed)
 KGAT_ATT_SCATTER_CSR           0        fused attention writes its logits in CSR order (round-2 form) instead of grouped order
 KGAT_ATT_FORM                  auto     attention form: auto / fused / folded / split / one / race
 KGAT_FOLD_TILE_COST            -        "tile,chunk,relation" cost triple of the fused attention's tile split
@@ -36,7 +37,7 @@ def _flag(name, default):
 
 
 class Options:
-    __slots__ = ("att_f32_products", "att_scatter_csr", "att_form", "fold_tile_cost", "gnn_copy_self", "fuse_bi",
+    __slots__ = ("att_f32_products", "att_tiles32", "att_scatter_csr", "att_form", "fold_tile_cost", "gnn_copy_self", "fuse_bi",
                  "gnn_mul_in_spmm", "gnn_defer_finish", "shard_grad_allreduce", "lazy_edge_weights",
                  "eager_edge_weights", "partition_row_weight", "force_collectives", "exchange", "exchange_chunks")
 
@@ -46,6 +47,7 @@ class Options:
     def load(self):
         e = os.environ
         self.att_f32_products = _flag("KGAT_ATT_F32_PRODUCTS", False)
+        self.att_tiles32 = _flag("KGAT_ATT_TILES32", False)
         self.att_scatter_csr = _flag("KGAT_ATT_SCATTER_CSR", False)
         self.att_form = e.get("KGAT_ATT_FORM", "auto")
         cost = e.get("KGAT_FOLD_TILE_COST")

@@ -63,7 +63,7 @@ enum {
 
 /* flags for kgat_att_score_fused_f32 and kgat_att_score_folded_f32 */
 enum {
-  KGAT_ATT_F32_PRODUCTS = 1 /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead of
+  KGAT_ATT_F32_PRODUCTS = 1, /* both products as v_mfma_f32_16x16x4_f32 (the round-1 form) instead of
                              * the default where a kernel has it (fused: d % 32 == 0; folded: d = 128):
                              * every fp32 operand cut by round-to-nearest into three bf16 pieces that
                              * sum to it exactly (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|), the six piece
@@ -71,6 +71,12 @@ enum {
                              * v_mfma_f32_16x16x32_bf16; the three dropped products are together
                              * < 2^-23 of |a*b| (one fp32 ulp), of either sign; error against fp64
                              * measured no larger than the fp32 form's */
+  KGAT_ATT_TILES32 = 2      /* kgat_att_score_fused_f32 at d = k = 64: `tiles` / `rec_g` were built with 32 groups per
+                             * tile (kgat_fold_tiles / kgat_att_pack_records, groups_per_tile = 32): the kernel on
+                             * v_mfma_f32_32x32x16_f16 with both products on fp16 pieces (W_r 2^shift three, the head
+                             * rows - scaled per row to [2^13, 2^14) - and the tanh values 2^14 two: five piece products
+                             * each).  Opt-in (KGAT_ATT_TILES32=1): 25 % fewer vector and 55 % fewer matrix instructions per launch at the
+                             * same run time as the 16-group kernel (profiles/r05_att32_experiments.txt). */
 };
 
 typedef void* kgat_stream_t; /* hipStream_t */
@@ -185,8 +191,8 @@ int kgat_att_score_folded_f32(int64_t n_nodes, int64_t n_edges, int d, int k, in
 int64_t kgat_fold_tiles_max(int64_t n_edges, int64_t n_groups, int n_rel, int cap);
 size_t kgat_fold_tiles_workspace_bytes(int64_t n_groups, int n_rel);
 int kgat_fold_tiles(int64_t n_edges, int n_rel, int64_t n_groups, const int32_t* rel_ptr, const int32_t* gid,
-                    const int32_t* gptr, int cap, int32_t* tiles, int32_t* rel_tptr, void* workspace,
-                    size_t workspace_bytes, kgat_stream_t stream);
+                    const int32_t* gptr, int cap, int groups_per_tile /* 16, or 32 for KGAT_ATT_TILES32 */,
+                    int32_t* tiles, int32_t* rel_tptr, void* workspace, size_t workspace_bytes, kgat_stream_t stream);
 /* Split of the tiles over the n_parts workgroups of the fused kernel (graph-static, like the
  * tiles): part b owns the contiguous tile range [part_tptr[b], part_tptr[b+1]), chosen on the
  * prefix sum of a per-tile cost
@@ -210,7 +216,8 @@ int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel);
  * (tiles are cut out of such blocks, whatever the cap).  Needs n_nodes <= 2^28.  Positions past
  * rel_ptr[R] (never scored) get their source node and slot 0. */
 int kgat_att_pack_records(int64_t n_edges, int n_rel, const int32_t* rel_ptr, const int32_t* gptr,
-                          const int32_t* gid, const int32_t* src_g, int32_t* rec_g, kgat_stream_t stream);
+                          const int32_t* gid, const int32_t* src_g, int groups_per_tile /* 16: slot << 28; 32: the
+                          slot of the 32-group block << 27, node ids below 2^27 */, int32_t* rec_g, kgat_stream_t stream);
 /* part_tptr / n_parts: the split above (one workgroup per part); NULL / 0: one workgroup per
  * compute unit, equal tile counts.  flags: 0 or KGAT_ATT_F32_PRODUCTS.
  * Outputs (any non-empty subset): logits_g[E] in grouped order (position p of the relation-grouped

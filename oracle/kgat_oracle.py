@@ -259,9 +259,9 @@ def dense_edge_softmax(n_nodes, dst, logits, dtype=np.float64):
     return out
 
 
-def fold_tiles(rel_ptr, gid, gptr, cap):
+def fold_tiles(rel_ptr, gid, gptr, cap, groups_per_tile=16):
     """Work tiles of the fused attention kernel, restated (include/kgat_hip.h kgat_fold_tiles):
-    per relation, blocks of 16 consecutive head groups; a block spanning more than `cap` grouped
+    per relation, blocks of 16 (or 32) consecutive head groups; a block spanning more than `cap` grouped
     positions is cut into consecutive position ranges of `cap`.  Returns (tiles (T,4) int32 =
     (relation, first group, first position, end position), rel_tptr (R+1,))."""
     rel_ptr, gid, gptr = (np.asarray(x, dtype=np.int64) for x in (rel_ptr, gid, gptr))
@@ -272,8 +272,8 @@ def fold_tiles(rel_ptr, gid, gptr, cap):
         gstart[gid[first]] = first
     tiles, rel_tptr = [], [0]
     for r in range(n_rel):
-        for g0 in range(int(gptr[r]), int(gptr[r + 1]), 16):
-            g1 = min(g0 + 16, int(gptr[r + 1]))
+        for g0 in range(int(gptr[r]), int(gptr[r + 1]), groups_per_tile):
+            g1 = min(g0 + groups_per_tile, int(gptr[r + 1]))
             pb, pe = int(gstart[g0]), int(gstart[g1])
             p = pb
             while True:

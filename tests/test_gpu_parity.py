@@ -609,6 +609,64 @@ def test_att_fused_tiles_and_logits(K, dev, d, cap):
     assert rel_err_inf(fused_csr.cpu().numpy(), ref[ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))[2].cpu().numpy()]) < 1e-5
 
 
+@pytest.mark.parametrize("cap", [64, 256, 512])
+def test_att_fused32_tiles_and_logits(K, dev, cap):
+    """The fused kernel on 32-group tiles (d = 64, KGAT_ATT_TILES32; v_mfma_f32_32x32x16_f16, both products on
+    fp16 pieces): tile table and packed records bit-exact against the restatement, logits against the fp64 oracle
+    and - to fp32 rounding - against the 16-group kernel and the two-launch folded form, in every output order, for
+    any split over workgroups; rows spanning 70 orders of magnitude (the per-row scale), tiny and zero rows."""
+    from dgl_kgat_amd import ops
+    n, e, R, d = 700, 30000, 6, 64
+    src, dst = random_graph(12, n, e, hub=4000, isolated_tail=20)
+    rng = np.random.default_rng(13)
+    et = rng.integers(-1, R + 1, e).astype(np.int32)
+    et[rng.choice(e, e // 2, replace=False)] = 3
+    et[et == 1] = 2  # an empty relation in the middle
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=cap, n_parts=37, cost=(110, 38, 1051),
+                                                groups_per_tile=32)
+    o_tiles, o_tptr = orc.fold_tiles(rel_ptr.cpu().numpy(), gid.cpu().numpy(), gptr.cpu().numpy(), cap, groups_per_tile=32)
+    n_tiles = int(o_tptr[-1])
+    assert np.array_equal(rel_tptr.cpu().numpy(), o_tptr) and np.array_equal(tiles.cpu().numpy()[:n_tiles], o_tiles)
+    rec = ops.att_pack_records(rel_ptr, gptr, gid, src_g, groups_per_tile=32)
+    rec_h, n_scored = rec.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, int(rel_ptr[-1])
+    assert np.array_equal(rec_h & 0x07FFFFFF, src_g.cpu().numpy())
+    rel_of = np.searchsorted(rel_ptr.cpu().numpy(), np.arange(n_scored), side="right") - 1
+    assert np.array_equal(rec_h[:n_scored] >> 27, (gid.cpu().numpy()[:n_scored] - gptr.cpu().numpy()[rel_of]) & 31)
+    t16, tptr16, parts16 = ops.fold_tiles(rel_ptr, gid, gptr, n_groups)
+    _, _, eid, _ = ops.csr_from_coo(n, t32(src, dev), t32(dst, dev))
+    W = ((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    for case in ("normal", "wide range", "tiny", "zero rows"):
+        ent = rng.standard_normal((n, d)).astype(np.float32)
+        if case == "wide range":
+            ent *= np.exp2(rng.integers(-60, 11, (n, 1))).astype(np.float32)
+            ent *= np.exp2(-rng.integers(0, 13, (n, d))).astype(np.float32)
+        elif case == "tiny":
+            ent *= np.float32(1e-37)
+        elif case == "zero rows":
+            ent[rng.random(n) < 0.3] = 0.0
+        ref = orc.att_score(ent, W, rel, src, dst, et)
+        args = (tf(ent, dev), tf(W, dev), tf(rel, dev))
+        k16 = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, t16, tptr16, *args,
+                                  part_tptr=parts16)[0].cpu().numpy()
+        out = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, *args,
+                                  part_tptr=part_tptr, rec_g=rec, want_grouped=True, groups_per_tile=32)
+        k32 = out[0].cpu().numpy()
+        assert np.isfinite(k32).all()
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        e32, e16 = np.abs(k32 - ref).max(), np.abs(k16 - ref).max()
+        print("[att32 cap %d %-10s] max|err|/max|ref| 32-group %.3e  16-group %.3e" % (cap, case, e32 / scale, e16 / scale))
+        assert e32 <= max(2.0 * e16, 2e-7 * scale), (case, e32, e16)
+        assert np.all(k32[(et < 0) | (et >= R)] == 0)
+        assert torch.equal(out[1], out[0][eid.long()]) and torch.equal(out[2], out[1][pos_g.long()])
+        # any split over workgroups, any subset of outputs: the same bits
+        even = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, *args,
+                                   want_eid=False, want_csr=False, rec_g=rec, want_grouped=True, groups_per_tile=32)
+        assert torch.equal(even[2], out[2])
+
+
 def test_att_fused_small_and_single_relation(K, dev):
     from dgl_kgat_amd import ops
     rng = np.random.default_rng(78)
@@ -678,6 +736,23 @@ def test_att_fused_product_forms(K, dev, d):
                                           tf(W, dev), tf(rel, dev), want_csr=False, folded=True, f32_products=f32p)[0]
             got[f32p] = out.cpu().numpy()
             assert np.isfinite(got[f32p]).all()
+        if d == 64:   # the 32-group kernel (both products on fp16 pieces, head rows scaled per row): the same bar
+            t32_, tptr32, parts32 = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=ops.FOLD_TILE_CAP32, n_parts=19,
+                                                  groups_per_tile=32)
+            k32 = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, t32_, tptr32,
+                                      tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False, part_tptr=parts32,
+                                      groups_per_tile=32)[0].cpu().numpy()
+            assert np.isfinite(k32).all()
+            sc_ = max(float(np.abs(ref).max()), 1e-30)
+            e32_, ef_ = np.abs(k32 - ref).max(), np.abs(got[True] - ref).max()
+            print("[att products d=64 %-12s] 32-group tiles: max|err|/max|ref| %.3e  (fp32 products %.3e); 8c %.3e"
+                  % (case, e32_ / sc_, ef_ / sc_, rel_err(k32, ref)))
+            assert e32_ <= max(2.0 * ef_, 2e-7 * sc_), (case, e32_, ef_)
+            assert rel_err(k32, ref) <= max(1e-4, 2.0 * rel_err(got[True], ref)), case
+            if case in ("all positive", "large W"):
+                b32 = abs(float(np.mean(k32.astype(np.float64) - ref))) / sc_
+                bf_ = abs(float(np.mean(got[True].astype(np.float64) - ref))) / sc_
+                assert e32_ <= 1.0 * ef_ + 1e-7 * sc_ and b32 <= max(2.0 * bf_, 3e-8), (case, e32_, ef_, b32)
         if d == 128:   # the fused one-launch form at d = 128 has the piece products only: same bar
             out = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr,
                                       tf(ent, dev), tf(W, dev), tf(rel, dev), want_csr=False, part_tptr=part_tptr)[0]
@@ -1166,7 +1241,7 @@ def test_att_product_flag_is_validated(K, dev):
     lib = _lib.load()
     p = lambda t: t.data_ptr()  # noqa: E731
     st = torch.cuda.current_stream().cuda_stream
-    for flags, want in ((0, 0), (1, 0), (2, -1), (-1, -1)):
+    for flags, want in ((0, 0), (1, 0), (4, -1), (-1, -1)):
         rec = ops.att_pack_records(rel_ptr, gptr, gid, src_g)
         rc = lib.kgat_att_score_fused_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(rec), p(pos_g), p(gptr),
                                           p(g_node), p(tiles), p(rel_tptr), p(part_tptr), part_tptr.numel() - 1, p(ent),
@@ -1174,12 +1249,36 @@ def test_att_product_flag_is_validated(K, dev):
         assert rc == want, (flags, rc, lib.kgat_last_error())
         if want:
             assert b"unknown flag" in lib.kgat_last_error()
+    # KGAT_ATT_TILES32 (= 2): tiles and records built for 32-group blocks; not together with the fp32 products
+    tiles32, rel_tptr32, part_tptr32 = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, cap=ops.FOLD_TILE_CAP32, groups_per_tile=32)
+    rec32 = ops.att_pack_records(rel_ptr, gptr, gid, src_g, groups_per_tile=32)
+    for flags, want in ((2, 0), (3, -2)):
+        rc = lib.kgat_att_score_fused_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(rec32), p(pos_g), p(gptr),
+                                          p(g_node), p(tiles32), p(rel_tptr32), p(part_tptr32), part_tptr32.numel() - 1,
+                                          p(ent), p(W), p(rel), p(out), None, None, flags, st)
+        assert rc == want, (flags, rc, lib.kgat_last_error())
     v_tab = torch.empty(max(n_groups, 1), d, device=dev)
     for flags, want in ((0, 0), (1, 0), (4, -1)):
         rc = lib.kgat_att_score_folded_f32(n, e, d, d, R, p(rel_ptr), p(perm), p(src_g), p(pos_g), p(gid), p(gptr),
                                            p(g_node), n_groups, p(ent), p(W), p(rel), p(v_tab), p(out), None, flags, st)
         assert rc == want, (flags, rc, lib.kgat_last_error())
     torch.cuda.synchronize()
+
+
+def test_att_tiles32_switch_on_the_surface(K, dev):
+    """KGAT_ATT_TILES32 (options.att_tiles32): compute_attention through the 32-group kernel - the same weights to
+    rounding as the default 16-group kernel, through the same graph path (own tiles and packed records)."""
+    from dgl_kgat_amd import options, synth
+    n, trip, R = synth.collaborative_kg(300, 400, 300, 5, 20000, 9000, seed=3)
+    torch.manual_seed(0)
+    m = K.KGATPropagation(n, R, 64, 64, 1, 64, dropout=0.0).to(dev)
+    outs = []
+    for flag in (False, True):
+        with options.override(att_tiles32=flag):
+            g = synth.build_graph(n, trip, dev)
+            with torch.no_grad():
+                outs.append(torch.as_tensor(m.compute_attention(g)).clone())
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-6 and not torch.equal(outs[0], outs[1])
 
 
 def test_f32_products_switch_on_the_surface(K, dev, monkeypatch):
