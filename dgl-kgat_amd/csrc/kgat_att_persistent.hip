@@ -1344,7 +1344,7 @@ constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step 
           d = fmaf(e.r[s][v].w, b.w, d);
         }
         d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xF, 0xF, true));
-        d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
+        if (LPE >= 4) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xF, 0xF, true));
         if (LPE >= 8) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xF, 0xF, true));
         if (LPE >= 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xF, 0xF, true));
         mine = li == s ? d : mine;
@@ -1846,19 +1846,29 @@ static int launch_att_fold_fused(const AttArgs& a, const int32_t* rel_tptr, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused folded form at d = k = 128 (round 3): what att_fold_fused_kernel is at d <= 64, built on the
-// LDS-resident piece images of att_fold_head_lds_kernel<128, true>.  One 512-thread workgroup per
-// CU; per relation segment W_r's three bf16 piece images (96 KB) are cut into LDS; a wavefront takes
-// the tiles t + w, t + w + 8, ... of the workgroup's segment, computes the 16 V rows of a tile (two
-// chained piece products, 384 MFMAs), parks them in its own 16 x 128 LDS patch (8 KB; with the images
-// exactly the CU's 160 KB) and walks the tile's positions itself: 8 lanes per edge, tail row from
-// global memory (512 B), V row from the patch, lane l ends with position p0 + l, logits stored in
-// grouped order (coalesced).  No V table: the two-launch form wrote n_groups x 512 B and read it back
-// per edge (0.5 GB each way on the benchmark graph).  The register file is full during the MFMA phase,
-// so a chunk's rows (64 positions = 128 registers) are gathered after it, not ahead of it as at
-// d <= 64; the two waves of a SIMD run out of phase, one in its MFMA phase while the other waits for
-// rows.  e_r enters as the initial value of the first product's
-// accumulators (no registers or LDS for it).
+// Fused folded form at d = k = 128 (round 3; products re-cut in round 5): what att_fold_fused_kernel is at d <= 64.
+// One 512-thread workgroup per CU; per relation segment W_r 2^shift is cut into TWO fp16 piece images in LDS (64 KB;
+// one row-major image per piece serves both products: the first contracts over the row index and takes its A
+// fragments with ds_read_b64_tr_b16, att_fold_head_lds_kernel's layout); a wavefront takes the tiles t + w,
+// t + w + 8, ... of the workgroup's segment, computes the 16 V rows of a tile (two chained piece products), parks
+// them in its own 16 x 128 LDS patch (8 KB) and walks the tile's positions itself: 8 lanes per edge, tail row from
+// global memory (512 B), V row from the patch, lane l ends with position p0 + l, logits stored in grouped order
+// (coalesced).  No V table: the two-launch form wrote n_groups x 512 B and read it back per edge (0.5 GB each way on
+// the benchmark graph).  The register file is full during the MFMA phase, so a chunk's rows (64 positions = 128
+// registers) are gathered after it, not ahead of it as at d <= 64; the two waves of a SIMD run out of phase, one in
+// its MFMA phase while the other waits for rows.
+// PRODUCTS (round 5): every operand as h + l with fp16 pieces after a power-of-two scale (W_r per relation, the head
+// rows per row - folded into the converts, v_fma_mixlo/mixhi_f16 -, the tanh values by 2^14), and THREE of the four
+// piece products, l h, h l, h h, in the fp32 accumulator of v_mfma_f32_16x16x32_f16: 192 MFMAs per tile against the
+// 384 of three bf16 pieces x six products (rounds 3-4), cuts of 5 / 4 vector instructions per pair of values instead
+// of 11.  A two-piece operand carries 22 bits (|x s - h - l| <= 2^-23 |x s|) and the dropped l l is <= 2^-22 of its
+// term: up to ~2^-21 of a TERM, where the exact fp32 fma chain has 2^-24 of a partial SUM per step - smaller than the
+// chain's error on d-term sums (measured, test_att_fused_product_forms[128], every case incl. rows over 70 orders of
+// magnitude: max error 0.76-0.97 x and mean error 0.74-0.95 x the fp32 MFMA form's; the bar of the test is unchanged).
+// At this width the matrix pipe was the longest of the kernel's resources: 0.427 -> 0.382 ms on the amazon-book graph
+// (profiles/r05_att_bounds.txt).  At d = 64 the same cut was measured on the 32-group kernel and buys nothing
+// (126.5 vs 126.4 us: that launch is not bound by its products, below) while its rows with one dominant term came
+// out at 2.2 x the fp32 form's error, over the bar: d <= 64 keeps W_r exact in three pieces.
 constexpr int kFused128Threads = 512;
 
 template <int OUT>
@@ -1876,8 +1886,10 @@ constexpr int kF128Passes = 2;
   constexpr int NPASS = kF128Passes, HALF = LPE / NPASS;  // row-gather passes per 64-position chunk
   constexpr bool LOGITS_EID = OUT == 2;
   constexpr int ROW_SHIFT = 9;  // 512-byte rows
-  __shared__ __attribute__((aligned(16))) unsigned char s_img[3 * IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char s_img[2 * IMG];   // W_r 2^shift: fp16 pieces h, l
   __shared__ __attribute__((aligned(16))) float s_v[NW][16 * D_];
+  __shared__ __attribute__((aligned(16))) float s_rel[K_];                  // e_r 2 log2(e)
+  __shared__ unsigned s_wmax;                                               // bits of max |W_r| of the current relation
   const int tid = threadIdx.x;
   const int lane = tid % kWave, w = tid / kWave;
   const int i = lane & 15, q = lane >> 4;
@@ -1920,26 +1932,37 @@ constexpr int kF128Passes = 2;
     const int32_t rend = gptr[r + 1];
     int32_t seg_end = rel_tptr[r + 1];
     seg_end = seg_end < t_end ? seg_end : t_end;
-    __syncthreads();  // every wave is done with the previous relation's images
+    if (tid == 0) s_wmax = 0u;  // (every wave has read the previous segment's value by now)
+    __syncthreads();            // every wave is done with the previous relation's images
+    const float* W = W_R + (size_t)r * D_ * K_;
     {
-      const float* W = W_R + (size_t)r * D_ * K_;
+      float mx = 0.f;
+      for (int idx = tid * 4; idx < D_ * K_; idx += kFused128Threads * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W + idx);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+      atomicMax(&s_wmax, __float_as_uint(mx));
+      if (tid < K_) s_rel[tid] = rel[(size_t)r * K_ + tid] * kTwoLog2e;
+    }
+    __syncthreads();
+    const int w_shift = __builtin_amdgcn_readfirstlane(f16_block_shift(s_wmax));
+    {
       int u0 = tid;
       asm volatile("" : "+v"(u0));  // recompute the per-thread offsets per segment: hoisted out of the segment loop they were kept (spilled) across the whole tile loop
       for (int u = u0; u < D_ * (K_ / 8); u += kFused128Threads) {
         const int row = u / (K_ / 8), ch = u % (K_ / 8);
         const float4 w0 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch);
         const float4 w1 = *reinterpret_cast<const float4*>(W + row * K_ + 8 * ch + 4);
-        const float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        uintx4 h, m, l;
-        split_bf16x3(x, h, m, l);
+        const float x[8] = {ldexpf(w0.x, w_shift), ldexpf(w0.y, w_shift), ldexpf(w0.z, w_shift), ldexpf(w0.w, w_shift),
+                            ldexpf(w1.x, w_shift), ldexpf(w1.y, w_shift), ldexpf(w1.z, w_shift), ldexpf(w1.w, w_shift)};
+        uintx4 h, l;
+        split_f16x2(x, h, l);
         const int off = ROWB * row + 16 * (ch ^ (((row & 7) << 1) | ((row >> 3) & 1)));
         *reinterpret_cast<uintx4*>(s_img + off) = h;
-        *reinterpret_cast<uintx4*>(s_img + IMG + off) = m;
-        *reinterpret_cast<uintx4*>(s_img + 2 * IMG + off) = l;
+        *reinterpret_cast<uintx4*>(s_img + IMG + off) = l;
       }
     }
     __syncthreads();
-    const float* relr = rel + (size_t)r * K_ + 4 * q;
 
     auto desc_of = [&](int32_t n) -> int4 {  // wave-uniform: kept in scalar registers
       n = n < seg_end ? n : seg_end - 1;
@@ -1967,12 +1990,20 @@ constexpr int kF128Passes = 2;
 
     // the two chained products of one tile: V rows of the tile's 16 groups -> the wave's LDS patch
     auto mfma_phase = [&](const HBuf& f) {
+      // power-of-two scale of the lane's head row (group i): the row's largest magnitude into [2^13, 2^14)
+      float mx = fabsf(f.a[0]);
+#pragma unroll
+      for (int e = 1; e < KS; ++e) mx = fmaxf(mx, fabsf(f.a[e]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const int ex = (int)(__float_as_uint(mx) >> 23);   // (mx >= 0)
+      int sh = (ex == 0 || ex == 255) ? 0 : 140 - ex;
+      sh = sh > 126 ? 126 : sh;
+      const float sc = __uint_as_float((unsigned)(sh + 127) << 23);
+      const float cl = ldexpf(kTwoLog2e, -sh - w_shift);  // G = G' 2^-(sh + w_shift); tanh argument scale 2 log2(e)
       floatx4 acc[KT];
 #pragma unroll
-      for (int c = 0; c < KT; ++c) {  // e_r is where the accumulation starts: acc = e_r + e_h W_r
-        const float4 rv = *reinterpret_cast<const float4*>(relr + 16 * c);
-        acc[c] = (floatx4){rv.x, rv.y, rv.z, rv.w};
-      }
+      for (int c = 0; c < KT; ++c) acc[c] = (floatx4){0.f, 0.f, 0.f, 0.f};
       floatx4 v[KT];
       {
         typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -1980,24 +2011,24 @@ constexpr int kF128Passes = 2;
         const int qq = i >> 2, p = i & 3;
         const int base1 = ROWB * (4 * q + qq) + 8 * (p & 1);
         const int sw1 = ((4 * (q & 1) + qq) << 1) | (q >> 1);
-        auto frag1 = [&](int n, uintx4 (&ap)[3]) {
+        auto frag1 = [&](int n, uintx4 (&ap)[2]) {
           const int s = n / KT, c = n % KT;
           const int o = base1 + 16 * ((2 * c + (p >> 1)) ^ sw1) + ROWB * 32 * s;
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
+          for (int pc = 0; pc < 2; ++pc) {
             const shortx4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o));
             const shortx4 hi4 =
                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_shortx4*)(s_img + pc * IMG + o + ROWB * 16));
             ap[pc] = __builtin_bit_cast(uintx4, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
           }
         };
-        auto pieces1 = [&](int s, uintx4 (&b)[3]) {
+        auto pieces1 = [&](int s, uintx4 (&b)[2]) {
           float x[8];
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) x[jj] = f.a[8 * s + jj];
-          split_bf16x3(x, b[0], b[1], b[2]);
+          split_scaled_f16x2(x, sc, b[0], b[1]);
         };
-        uintx4 fa[2][3], fb[2][3];
+        uintx4 fa[2][2], fb[2][2];
         frag1(0, fa[0]);
         pieces1(0, fb[0]);
 #pragma unroll
@@ -2006,45 +2037,49 @@ constexpr int kF128Passes = 2;
           if (n + 1 < S3 * KT) frag1(n + 1, fa[(n + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
           if (c == KT - 1 && s + 1 < S3) pieces1(s + 1, fb[(s + 1) & 1]);
-          const uintx4(&ap)[3] = fa[n & 1];
-          const uintx4(&bp)[3] = fb[s & 1];
-          acc[c] = mfma_bf16(ap[2], bp[0], acc[c]);
-          acc[c] = mfma_bf16(ap[0], bp[2], acc[c]);
-          acc[c] = mfma_bf16(ap[1], bp[1], acc[c]);
-          acc[c] = mfma_bf16(ap[1], bp[0], acc[c]);
-          acc[c] = mfma_bf16(ap[0], bp[1], acc[c]);
-          acc[c] = mfma_bf16(ap[0], bp[0], acc[c]);
+          const uintx4(&ap)[2] = fa[n & 1];
+          const uintx4(&bp)[2] = fb[s & 1];
+          acc[c] = mfma_f16(ap[1], bp[0], acc[c]);   // three piece products (l h, h l, h h; l l < 2^-22 dropped)
+          acc[c] = mfma_f16(ap[0], bp[1], acc[c]);
+          acc[c] = mfma_f16(ap[0], bp[0], acc[c]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // tanh(G + e_r), leaving as T 2^14 for the fp16 cut (a small |T| keeps 22 bits in two pieces)
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+      for (int c = 0; c < KT; ++c) {
+        const float4 rv = *reinterpret_cast<const float4*>(s_rel + 16 * c + 4 * q);
+        const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = att_tanh_scaled(acc[c][j] * kTwoLog2e);
+        for (int j = 0; j < 4; ++j) {
+          const float y = fmaf(acc[c][j], cl, rr[j]);
+          acc[c][j] = fmaf(-32768.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 16384.0f);
+        }
+      }
 #pragma unroll
       for (int c2 = 0; c2 < KT; ++c2) v[c2] = (floatx4){0.f, 0.f, 0.f, 0.f};
       __builtin_amdgcn_sched_barrier(0);
       {
         const int base2 = ROWB * i + 8 * (q & 1);
         const int sw2 = ((i & 7) << 1) | (i >> 3);
-        auto frag2 = [&](int n, uintx4 (&ap)[3]) {
+        auto frag2 = [&](int n, uintx4 (&ap)[2]) {
           const int s = n / KT, c2 = n % KT;
           const int o0 = base2 + 16 * (((4 * s) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
           const int o1 = base2 + 16 * (((4 * s + 2) | (q >> 1)) ^ sw2) + ROWB * 16 * c2;
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
+          for (int pc = 0; pc < 2; ++pc) {
             const uintx2 l2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o0);
             const uintx2 h2 = *reinterpret_cast<const uintx2*>(s_img + pc * IMG + o1);
             ap[pc] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3);
           }
         };
-        auto pieces2 = [&](int s, uintx4 (&b)[3]) {
+        auto pieces2 = [&](int s, uintx4 (&b)[2]) {
           float x[8];
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) x[jj] = acc[2 * s + (jj >> 2)][jj & 3];
-          split_bf16x3(x, b[0], b[1], b[2]);
+          split_f16x2(x, b[0], b[1]);   // |T| 2^14 < 16,384: inside fp16's range
         };
-        uintx4 fa[2][3], fb[2][3];
+        uintx4 fa[2][2], fb[2][2];
         frag2(0, fa[0]);
         pieces2(0, fb[0]);
 #pragma unroll
@@ -2053,14 +2088,11 @@ constexpr int kF128Passes = 2;
           if (n + 1 < S3 * KT) frag2(n + 1, fa[(n + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
           if (c2 == KT - 1 && s + 1 < S3) pieces2(s + 1, fb[(s + 1) & 1]);
-          const uintx4(&ap)[3] = fa[n & 1];
-          const uintx4(&bp)[3] = fb[s & 1];
-          v[c2] = mfma_bf16(ap[2], bp[0], v[c2]);
-          v[c2] = mfma_bf16(ap[0], bp[2], v[c2]);
-          v[c2] = mfma_bf16(ap[1], bp[1], v[c2]);
-          v[c2] = mfma_bf16(ap[1], bp[0], v[c2]);
-          v[c2] = mfma_bf16(ap[0], bp[1], v[c2]);
-          v[c2] = mfma_bf16(ap[0], bp[0], v[c2]);
+          const uintx4(&ap)[2] = fa[n & 1];
+          const uintx4(&bp)[2] = fb[s & 1];
+          v[c2] = mfma_f16(ap[1], bp[0], v[c2]);
+          v[c2] = mfma_f16(ap[0], bp[1], v[c2]);
+          v[c2] = mfma_f16(ap[0], bp[0], v[c2]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -2112,6 +2144,7 @@ constexpr int kF128Passes = 2;
           mine = li == h * HALF + s ? d : mine;
         }
       }
+      mine = ldexpf(mine, -w_shift - 14);  // (V rows are those of (W_r 2^w_shift) (T 2^14))
       if (p0 + lane < pe) {
         if (LOGITS_EID) logits[c.oe] = mine;
         if (OUT >= 1 && logits_csr) logits_csr[c.op] = mine;
