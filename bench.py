@@ -614,6 +614,9 @@ def main():
     # setup, not warmup: the first pass over a graph builds its static structures (CSR, relation /
     # head groups, work tiles) and, for N > 1, creates the RCCL communicator - none of which belongs
     # to a step, whatever --warmup says
+    import gc
+    gc.collect()   # (the long one - every object the imports, the graph and the model created - BEFORE the setup step:
+    gc.freeze()    #  see below; done here, the device does not sit idle for 50 ms between the setup step and the warm-up)
     out, a = step()
     sync()
     def step_fast():
@@ -623,9 +626,11 @@ def main():
     # steps' worth of stall that lands in whichever timed loop is running (KGAT_BENCH_TRACE=1 prints the
     # collections: round 4 found one inside the 20 timed steps, 0.46 -> 2.3 ms per step).  Collect once now
     # and freeze the survivors: later collections only look at objects created after this point.
-    import gc
-    gc.collect()
+    t_gc = time.perf_counter()
+    gc.collect()   # (only what the setup step created: short)
     gc.freeze()
+    if os.environ.get("KGAT_BENCH_TRACE") and rank == 0:
+        print("trace: second gc.collect + freeze took %.2f ms" % ((time.perf_counter() - t_gc) * 1e3), file=sys.stderr)
     # THE HEADLINE: the driver's protocol as it stands - W warm-up steps, K timed ones - right after the setup step
     # (the first ~15 steps after an idle gap run 5-10 % slower than the steady state: clocks, caches, allocator;
     # that is part of what the driver's command measures)
