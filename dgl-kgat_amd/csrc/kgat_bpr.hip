@@ -3,10 +3,12 @@
 // (gathers, batched dot products, logsigmoid, three regularisers, an index_put with a device sort): 75 launches of
 // a few microseconds each, 0.7 ms of the 1.6 ms CF step, all of it launch latency.  Here:
 //   forward   bpr_sample_kernel (one wavefront per sample: the three rows, five dot products) + bpr_reduce_kernel
-//   backward  stable radix sort of the 3B row ids (kgat_graph.hip) + zero fill + bpr_scatter_kernel
-//             (one wavefront per distinct row sums that row's contributions in sample order: fixed order of
-//             additions, no float atomics, bitwise reproducible), scaled by the incoming gradient read from
-//             device memory (no host synchronisation, no separate multiply pass)
+//   backward  stable sort of the 3B row ids + zero fill of the dense gradient, ONE launch (bpr_sort_zero_kernel: up
+//             to 32,768 ids are sorted by one workgroup with the keys in registers, 32 per lane, while the other
+//             workgroups clear the N x F gradient; larger batches: the device radix sort of kgat_graph.hip + a
+//             memset) + bpr_scatter_kernel (one wavefront per distinct row sums that row's contributions in sample
+//             order: fixed order of additions, no float atomics, bitwise reproducible), scaled by the incoming
+//             gradient read from device memory (no host synchronisation, no separate multiply pass)
 //   loss = -mean_b logsigmoid(<s,p> - <s,n>) + lambda (mean_b |s|^2/2 + mean_b |p|^2/2 + mean_b |n|^2/2)
 #include "kgat_common.h"
 
@@ -144,6 +146,133 @@ __global__ __launch_bounds__(256) void bpr_scatter_kernel(int64_t batch, int64_t
   }
 }
 
+// ---- stable sort of the 3B row ids, role-major (i = role * B + b), beside the zero fill of the dense gradient.
+// The general device sort (kgat_graph.hip) takes four launches per digit - twelve dependent launches for 30,720
+// eighteen-bit keys, 0.10 of the CF step's 0.99 ms, all of it launch latency.  Here, up to 65,536 ids: launch one -
+// workgroup L sorts slice L (4,096 consecutive ids) in LDS: LSD radix, 8-bit digits, per-wavefront counter columns,
+// ballots for the rank inside 64 keys (equal keys keep their order: kgat_transr.hip's small sort), packed values
+// key << 17 | index; the workgroups behind the slices clear `zero` (the N x F gradient) meanwhile.  Launch two - one
+// thread per id finds its place among ALL ids: its rank in its own slice + what the earlier slices hold up to its
+// key + what the later slices hold below it (binary searches over <= 15 sorted slices): a stable merge without a
+// merge tree.  Ids outside [0, N) sort as N, behind every real row.  (One workgroup sorting all 30,720 ids from
+// registers was measured first: 180 us - 1,440 wavefront-iterations of ~100 instructions on one CU.)
+constexpr int kSliceSort = 4096;
+constexpr int kSliceSortMaxLists = 16;
+constexpr int kSliceWaves = 16;
+
+__global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int32_t n_lists, int64_t n_nodes, int key_bits,
+                                                             const int32_t* __restrict__ u, const int32_t* __restrict__ p,
+                                                             const int32_t* __restrict__ n, uint64_t* __restrict__ lists,
+                                                             float* __restrict__ zero, int64_t n_zero) {
+  if ((int32_t)blockIdx.x >= n_lists) {
+    const int64_t n4 = n_zero / 4, stride = (int64_t)(gridDim.x - n_lists) * 1024;
+    float4* z = reinterpret_cast<float4*>(zero);
+    for (int64_t i = (int64_t)(blockIdx.x - n_lists) * 1024 + threadIdx.x; i < n4; i += stride)
+      z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  __shared__ uint64_t s_buf[2][kSliceSort];
+  __shared__ int32_t s_cnt[256 * kSliceWaves];
+  __shared__ int32_t s_wsum[kSliceWaves];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t total = 3 * batch;
+  const int32_t g0 = (int32_t)blockIdx.x * kSliceSort;
+  const int32_t cnt = total - g0 < kSliceSort ? total - g0 : kSliceSort;
+  for (int32_t i = tid; i < cnt; i += 1024) {
+    const int32_t gi = g0 + i;
+    const int32_t role = gi / batch, b = gi - role * batch;
+    const int32_t id = role == 0 ? u[b] : (role == 1 ? p[b] : n[b]);
+    const uint64_t key = (uint64_t)(uint32_t)id >= (uint64_t)n_nodes ? (uint64_t)n_nodes : (uint64_t)id;
+    s_buf[0][i] = (key << 17) | (uint64_t)gi;
+  }
+  const int32_t slice = ((cnt + kSliceWaves * 64 - 1) / (kSliceWaves * 64)) * 64;  // per wavefront, a multiple of 64
+  const int32_t lo = w * slice, hi = lo + slice < cnt ? lo + slice : cnt;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const int passes = (key_bits + 7) / 8;
+  int cur = 0;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 17 + 8 * pass;
+    for (int i = tid; i < 256 * kSliceWaves; i += 1024) s_cnt[i] = 0;
+    __syncthreads();
+    for (int32_t i = lo + lane; i < hi; i += 64) atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & 255u) * kSliceWaves + w], 1);
+    __syncthreads();
+    {  // exclusive scan of the 4096 counters in (digit, wavefront) order, 4 per thread
+      int32_t c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = s_cnt[4 * tid + q];
+      const int32_t mine = c[0] + c[1] + c[2] + c[3];
+      int32_t inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+      }
+      if (lane == 63) s_wsum[w] = inc;
+      __syncthreads();
+      int32_t base = inc - mine;
+      for (int q = 0; q < w; ++q) base += s_wsum[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s_cnt[4 * tid + q] = base;
+        base += c[q];
+      }
+    }
+    __syncthreads();
+    for (int32_t i0 = lo; i0 < hi; i0 += 64) {
+      const int32_t i = i0 + lane;
+      const bool valid = i < hi;
+      const uint64_t v = valid ? s_buf[cur][i] : 0ull;
+      const uint32_t dgt = (uint32_t)((v >> shift) & 255u);
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool on = (dgt >> bit) & 1u;
+        const uint64_t bal = __ballot(on);
+        peers &= on ? bal : ~bal;
+      }
+      const int rank = __popcll(peers & lt_mask);
+      const int32_t basep = valid ? s_cnt[dgt * kSliceWaves + w] : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every lane has its base before a leader moves it
+      if (valid) {
+        s_buf[cur ^ 1][basep + rank] = v;
+        if (rank == 0) s_cnt[dgt * kSliceWaves + w] = basep + __popcll(peers);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int32_t i = tid; i < cnt; i += 1024) lists[g0 + i] = s_buf[cur][i];
+}
+
+// the place of every id among all ids (see above); thread t = position t of the concatenated sorted slices
+__global__ __launch_bounds__(256) void bpr_merge_kernel(int32_t total, int32_t n_lists, const uint64_t* __restrict__ lists,
+                                                        int32_t* __restrict__ order, int32_t* __restrict__ sorted) {
+  const int32_t t = (int32_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const uint64_t v = lists[t];
+  const uint64_t key = v >> 17;
+  const int32_t mine = t / kSliceSort;
+  int32_t pos = t - mine * kSliceSort;
+  for (int32_t L = 0; L < n_lists; ++L) {
+    if (L == mine) continue;
+    const int32_t g0 = L * kSliceSort;
+    const int32_t cnt = total - g0 < kSliceSort ? total - g0 : kSliceSort;
+    // earlier slices: ids <= key come first (upper bound); later slices: ids < key (lower bound)
+    const uint64_t bound = L < mine ? key + 1 : key;
+    int32_t lo = 0, hi = cnt;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if ((lists[g0 + mid] >> 17) < bound) lo = mid + 1; else hi = mid;
+    }
+    pos += lo;
+  }
+  order[pos] = (int32_t)(v & 0x1FFFFull);
+  sorted[pos] = (int32_t)key;
+}
+
 static int bits_for_id(int64_t max_id) {
   int b = 1;
   while (b < 31 && ((int64_t)1 << b) <= max_id) ++b;
@@ -158,9 +287,11 @@ extern "C" {
 
 size_t kgat_bpr_workspace_bytes(int64_t batch) {
   if (batch < 1) batch = 1;
-  // per-sample partials (4 B floats) | keys, order (3 B int32 each) | radix sort scratch
-  return align_up((size_t)batch * 4 * 4, 256) + 2 * align_up((size_t)batch * 3 * 4, 256) +
-         radix_sort_workspace_bytes(3 * batch) + 256;
+  // per-sample partials (4 B floats) | keys, order (3 B int32 each) | sort scratch: the device radix sort's, or the
+  // one-workgroup sort's two packed buffers + its sorted keys
+  const size_t one_wg = 3 * batch <= kSliceSort * kSliceSortMaxLists ? align_up((size_t)batch * 3 * 8, 256) + align_up((size_t)batch * 3 * 4, 256) : 0;
+  const size_t radix = radix_sort_workspace_bytes(3 * batch);
+  return align_up((size_t)batch * 4 * 4, 256) + 2 * align_up((size_t)batch * 3 * 4, 256) + (one_wg > radix ? one_wg : radix) + 256;
 }
 
 int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
@@ -205,15 +336,30 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
   int32_t* order = cv.take<int32_t>((size_t)batch * 3);
   void* sort_ws = cv.base + cv.off;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((3 * batch + 255) / 256)), dim3(256), 0, st, batch, u, p, n, keys);
-  KGAT_CHECK_LAUNCH("bpr_keys");
   const int32_t* sorted = nullptr;
-  const int rc = radix_sort_index(keys, 3 * batch, bits_for_id(n_nodes - 1), order, &sorted, sort_ws,
-                                  workspace_bytes - cv.off, st);
-  if (rc != KGAT_OK) return rc;
-  if (hipMemsetAsync(grad, 0, (size_t)n_nodes * F * sizeof(float), st) != hipSuccess) {
-    set_error("bpr_grad: memset failed");
-    return KGAT_E_HIP;
+  if (3 * batch <= kSliceSort * kSliceSortMaxLists && n_nodes < ((int64_t)1 << 30)) {
+    Carver cs(sort_ws);
+    uint64_t* lists = cs.take<uint64_t>((size_t)batch * 3);
+    int32_t* sorted_w = cs.take<int32_t>((size_t)batch * 3);
+    const int32_t total = (int32_t)(3 * batch), n_lists = (total + kSliceSort - 1) / kSliceSort;
+    const unsigned zero_blocks = 2u * (unsigned)device_cu_count();
+    hipLaunchKernelGGL(bpr_sort_zero_kernel, dim3((unsigned)n_lists + zero_blocks), dim3(1024), 0, st, (int32_t)batch, n_lists,
+                       n_nodes, bits_for_id(n_nodes), u, p, n, lists, grad, (int64_t)n_nodes * F);
+    KGAT_CHECK_LAUNCH("bpr_sort_zero");
+    hipLaunchKernelGGL(bpr_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, n_lists,
+                       (const uint64_t*)lists, order, sorted_w);
+    KGAT_CHECK_LAUNCH("bpr_merge");
+    sorted = sorted_w;
+  } else {
+    hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((3 * batch + 255) / 256)), dim3(256), 0, st, batch, u, p, n, keys);
+    KGAT_CHECK_LAUNCH("bpr_keys");
+    const int rc = radix_sort_index(keys, 3 * batch, bits_for_id(n_nodes - 1), order, &sorted, sort_ws,
+                                    workspace_bytes - cv.off, st);
+    if (rc != KGAT_OK) return rc;
+    if (hipMemsetAsync(grad, 0, (size_t)n_nodes * F * sizeof(float), st) != hipSuccess) {
+      set_error("bpr_grad: memset failed");
+      return KGAT_E_HIP;
+    }
   }
   hipLaunchKernelGGL(bpr_scatter_kernel, dim3((unsigned)((3 * batch + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F,
                      emb, emb_stride, u, p, n, coef, reg_lambda, grad_scale, sorted, (const int32_t*)order, grad);

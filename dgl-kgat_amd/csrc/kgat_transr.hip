@@ -48,15 +48,28 @@ constexpr int kSsWaves = 16;
 
 // PT: the packed (key, position) type - uint32_t for keys below 2^19 (64 KB of LDS for the two buffers), uint64_t for
 // any int32 key (128 KB: entity ids of graphs beyond 524,288 nodes, e.g. BASELINE configs[4]'s 10 M).
+struct SortJob {
+  int32_t n;
+  int key_bits;
+  const int32_t *keys, *keys_b, *keys_c;
+  int32_t *order, *sorted_keys;
+  int32_t n_keys;
+  int32_t *offsets, *chunk_ptr;
+  int2* chunks;
+};
+
 template <typename PT>
-__global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bits, const int32_t* __restrict__ keys,
-                                                          const int32_t* __restrict__ keys_b,
-                                                          const int32_t* __restrict__ keys_c,
-                                                          int32_t* __restrict__ order,
-                                                          int32_t* __restrict__ sorted_keys, int32_t n_keys,
-                                                          int32_t* __restrict__ offsets,
-                                                          int32_t* __restrict__ chunk_ptr,
-                                                          int2* __restrict__ chunks) {
+__device__ __forceinline__ void small_sort_body(const SortJob& job) {
+  const int32_t n = job.n, n_keys = job.n_keys;
+  const int key_bits = job.key_bits;
+  const int32_t* __restrict__ keys = job.keys;
+  const int32_t* __restrict__ keys_b = job.keys_b;
+  const int32_t* __restrict__ keys_c = job.keys_c;
+  int32_t* __restrict__ order = job.order;
+  int32_t* __restrict__ sorted_keys = job.sorted_keys;
+  int32_t* __restrict__ offsets = job.offsets;
+  int32_t* __restrict__ chunk_ptr = job.chunk_ptr;
+  int2* __restrict__ chunks = job.chunks;
   __shared__ PT s_buf[2][kTrSmallSort];
   __shared__ int32_t s_cnt[256 * kSsWaves];
   __shared__ int32_t s_wsum[kSsWaves];
@@ -184,6 +197,24 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(int32_t n, int key_bit
       base += c[q];
     }
   }
+}
+
+// The step's sorts are independent of everything but the batch ids, and so is the zero fill of the dense entity
+// gradient: ONE launch - workgroup 0 (and 1) sort, the others clear `zero` (n_zero floats, a multiple of 4).  (Round 4
+// ran relation sort -> ... -> memset -> id sort in stream order: two one-workgroup launches of ~18 us and a 41 MB
+// memset on an otherwise idle chip.)
+template <typename PT>
+__global__ __launch_bounds__(1024) void small_sort_kernel(SortJob a, SortJob b, int n_jobs, float* __restrict__ zero,
+                                                          int64_t n_zero) {
+  if ((int)blockIdx.x < n_jobs) {
+    small_sort_body<PT>(blockIdx.x == 0 ? a : b);
+    return;
+  }
+  const int64_t n4 = n_zero / 4;
+  const int64_t stride = (int64_t)(gridDim.x - n_jobs) * 1024;
+  float4* z = reinterpret_cast<float4*>(zero);
+  for (int64_t i = (int64_t)(blockIdx.x - n_jobs) * 1024 + threadIdx.x; i < n4; i += stride)
+    z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- per-sample kernel: projections, loss head, its backward, grad_a W_r^T
@@ -329,15 +360,15 @@ constexpr int kTrStage = 16;  // samples staged through LDS per step of the part
 
 // Thread t owns 4 x 4 blocks of the d x k outer-product sum: block index t, t + 256, ... over
 // (d/4) x (k/4) blocks, so a sample costs two 16-byte LDS reads per 16 fmas.  d, k multiples of 4.
-__global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
-    int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
+__device__ __forceinline__ void transr_wgrad_partial_body(
+    int bx, int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
     const float* __restrict__ GA, const float* __restrict__ GR, const int32_t* __restrict__ chunk_ptr,
     const int2* __restrict__ chunks, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float s_x[kTrStage][3][kTrMaxDim];
   __shared__ __attribute__((aligned(16))) float s_g[kTrStage][3][kTrMaxDim];
   __shared__ float s_r[kTrStage][kTrMaxDim];
-  if ((int32_t)blockIdx.x >= chunk_ptr[n_rel]) return;
-  const int2 ck = chunks[blockIdx.x];
+  if ((int32_t)bx >= chunk_ptr[n_rel]) return;
+  const int2 ck = chunks[bx];
   const int32_t beg = ck.y, end = beg + kTrChunk < seg[ck.x + 1] ? beg + kTrChunk : seg[ck.x + 1];
   constexpr int TV = (kTrMaxDim / 4) * (kTrMaxDim / 4) / 256;  // 4 x 4 blocks per thread at the largest size
   float acc[TV][4][4], racc = 0.f;
@@ -383,7 +414,7 @@ __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
     }
   }
   const int dk = d * k;
-  float* out = part + (size_t)blockIdx.x * (dk + k);
+  float* out = part + (size_t)bx * (dk + k);
 #pragma unroll
   for (int o = 0; o < TV; ++o) {
     if (bi[o] < 0) continue;
@@ -399,16 +430,16 @@ __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
 
 // ---- ordered reductions: block r < n_rel: dW[r] and drel[r] = sums of r's partial chunks (they are
 // consecutive); block n_rel: the loss
-__global__ __launch_bounds__(256) void transr_reduce_kernel(int32_t batch, int d, int k, int n_rel,
-                                                            const int32_t* __restrict__ chunk_ptr,
-                                                            const float* __restrict__ part,
-                                                            const float* __restrict__ losses,
-                                                            float* __restrict__ grad_W, float* __restrict__ grad_rel,
-                                                            float* __restrict__ loss,
-                                                            const float* __restrict__ grad_scale) {
-  const int r = blockIdx.x;
+__device__ __forceinline__ void transr_reduce_body(int bx, int by, int ny, int32_t batch, int d, int k, int n_rel,
+                                                   const int32_t* __restrict__ chunk_ptr,
+                                                   const float* __restrict__ part,
+                                                   const float* __restrict__ losses,
+                                                   float* __restrict__ grad_W, float* __restrict__ grad_rel,
+                                                   float* __restrict__ loss,
+                                                   const float* __restrict__ grad_scale) {
+  const int r = bx;
   if (r == n_rel) {
-    if (loss == nullptr || blockIdx.y != 0) return;
+    if (loss == nullptr || by != 0) return;
     __shared__ float s_l[256];
     float v = 0.f;
     for (int32_t s = threadIdx.x; s < batch; s += 256) v += losses[s];
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(256) void transr_reduce_kernel(int32_t batch, int d
   const int first = chunk_ptr[r], n_mine = chunk_ptr[r + 1] - first;
   const float sc = grad_scale ? grad_scale[0] : 1.f;   // the gradient arriving at the loss (device scalar)
   // gridDim.y blocks share a relation's dk + k elements (42 blocks alone left most of the chip idle: 22 us)
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < dk + k; e += 256 * gridDim.y) {
+  for (int e = by * 256 + threadIdx.x; e < dk + k; e += 256 * ny) {
     float v = 0.f;
     for (int q = 0; q < n_mine; ++q) v += part[(size_t)(first + q) * (dk + k) + e];
     if (grad_scale) v *= sc;
@@ -438,14 +469,14 @@ __global__ __launch_bounds__(256) void transr_reduce_kernel(int32_t batch, int d
 // ---- entity gradient: rows of DX added into the (zeroed) dense gradient in sorted-id order;
 // one 16-lane group per run of equal ids.  The run's length comes from 16 ids per look (one per
 // lane), its rows are then added four at a time (their loads in flight together).
-__global__ __launch_bounds__(256) void transr_scatter_kernel(int32_t n_rows, int d,
-                                                             const int32_t* __restrict__ sorted_ids,
-                                                             const int32_t* __restrict__ row_order,
-                                                             const float* __restrict__ DX,
-                                                             float* __restrict__ grad_ent,
-                                                             const float* __restrict__ grad_scale) {
+__device__ __forceinline__ void transr_scatter_body(int bx, int32_t n_rows, int d,
+                                                    const int32_t* __restrict__ sorted_ids,
+                                                    const int32_t* __restrict__ row_order,
+                                                    const float* __restrict__ DX,
+                                                    float* __restrict__ grad_ent,
+                                                    const float* __restrict__ grad_scale) {
   const int sl = threadIdx.x & 15;
-  const int32_t p = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int32_t p = bx * 16 + (threadIdx.x >> 4);
   if (p >= n_rows) return;
   const int32_t id = sorted_ids[p];
   if (p > 0 && sorted_ids[p - 1] == id) return;  // not the head of its run
@@ -486,6 +517,38 @@ __global__ __launch_bounds__(256) void transr_scatter_kernel(int32_t n_rows, int
     const int i = sl + 16 * c;
     if (i < d) grad_ent[(size_t)id * d + i] = grad_scale ? acc[c] * grad_scale[0] : acc[c];
   }
+}
+
+// The launches of the backward half.  The weight-gradient partials (or, when the forward half ran in an earlier call,
+// the ordered reductions) and the entity-gradient scatter read only what the per-sample kernel and the sorts left:
+// independent work, one launch - blocks [0, n_first) take the first job, the rest the scatter.
+struct TrScatterArgs {
+  int32_t n_rows;
+  const int32_t *sorted_ids, *row_order;
+  const float* DX;
+  float* grad_ent;
+  const float* grad_scale;
+};
+
+__global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
+    int n_first, int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
+    const float* __restrict__ GA, const float* __restrict__ GR, const int32_t* __restrict__ chunk_ptr,
+    const int2* __restrict__ chunks, float* __restrict__ part, TrScatterArgs sc) {
+  if ((int)blockIdx.x < n_first) transr_wgrad_partial_body((int)blockIdx.x, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
+  else transr_scatter_body((int)blockIdx.x - n_first, sc.n_rows, d, sc.sorted_ids, sc.row_order, sc.DX, sc.grad_ent, sc.grad_scale);
+}
+
+__global__ __launch_bounds__(256) void transr_reduce_kernel(int n_first, int ny, int32_t batch, int d, int k, int n_rel,
+                                                            const int32_t* __restrict__ chunk_ptr,
+                                                            const float* __restrict__ part,
+                                                            const float* __restrict__ losses,
+                                                            float* __restrict__ grad_W, float* __restrict__ grad_rel,
+                                                            float* __restrict__ loss,
+                                                            const float* __restrict__ grad_scale, TrScatterArgs sc) {
+  if ((int)blockIdx.x < n_first)
+    transr_reduce_body((int)blockIdx.x / ny, (int)blockIdx.x % ny, ny, batch, d, k, n_rel, chunk_ptr, part, losses, grad_W,
+                       grad_rel, loss, grad_scale);
+  else transr_scatter_body((int)blockIdx.x - n_first, sc.n_rows, d, sc.sorted_ids, sc.row_order, sc.DX, sc.grad_ent, sc.grad_scale);
 }
 
 }  // namespace kgat
@@ -558,55 +621,64 @@ static int transr_run(int stage, int64_t n_nodes, int n_rel, int d, int k, int64
   int rel_bits = 1, id_bits = 1;
   while ((1 << rel_bits) < n_rel) ++rel_bits;
   while ((1ll << id_bits) < n_nodes) ++id_bits;
-  if (stage & kTrForward) {
-    hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, B, rel_bits, r, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, order, (int32_t*)nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks);
-    KGAT_CHECK_LAUNCH("transr_sort_relations");
+  const bool fwd = (stage & kTrForward) != 0, bwd = (stage & kTrBackward) != 0 && want_grad;
+  const SortJob rel_job = {B, rel_bits, r, nullptr, nullptr, order, nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks};
+  const SortJob id_job = {3 * B, id_bits, h, pos_t, neg_t, row_order, sorted_ids, 0, nullptr, nullptr, nullptr};
+  const TrScatterArgs sc = {3 * B, sorted_ids, row_order, DX, grad_ent, grad_scale};
+  const TrScatterArgs no_sc = {0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const unsigned scatter_blocks = (unsigned)((3 * B + 15) / 16);
+  const int64_t n_zero = (int64_t)n_nodes * d;
+  // first launch: the sort(s) this call needs + the zero fill of the dense entity gradient
+  {
+    const SortJob& first = fwd ? rel_job : id_job;
+    const int n_jobs = (fwd && bwd) ? 2 : ((fwd || bwd) ? 1 : 0);
+    if (n_jobs == 0) return KGAT_OK;
+    const unsigned zero_blocks = bwd ? 2u * (unsigned)device_cu_count() : 0u;
+    if (bwd && id_bits > 19)  // entity ids beyond 2^19: the 64-bit packing (128 KB of LDS, one more radix pass per 8 id bits)
+      hipLaunchKernelGGL(small_sort_kernel<uint64_t>, dim3(n_jobs + zero_blocks), dim3(1024), 0, st, first, id_job, n_jobs,
+                         grad_ent, n_zero);
+    else
+      hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(n_jobs + zero_blocks), dim3(1024), 0, st, first, id_job, n_jobs,
+                         bwd ? grad_ent : (float*)nullptr, bwd ? n_zero : (int64_t)0);
+    KGAT_CHECK_LAUNCH("transr_sort");
+  }
+  if (fwd) {
     const unsigned sb = (unsigned)((B + 3) / 4);
     if (!want_grad) {
       hipLaunchKernelGGL(transr_sample_kernel<false>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
                          pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
       KGAT_CHECK_LAUNCH("transr_sample");
-      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
+      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, 1, 1, B, d, k, 0, (const int32_t*)chunk_ptr,
                          (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss,
-                         (const float*)nullptr);
+                         (const float*)nullptr, no_sc);
       KGAT_CHECK_LAUNCH("transr_reduce");
       return KGAT_OK;
     }
     hipLaunchKernelGGL(transr_sample_kernel<true>, dim3(sb), dim3(256), 0, st, B, d, k, (const int32_t*)order, h, r,
                        pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
     KGAT_CHECK_LAUNCH("transr_sample");
-    hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part), dim3(256), 0, st, d, k, n_rel,
-                       (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
-                       (const int32_t*)chunk_ptr, (const int2*)chunks, part);
+    // the weight-gradient partials, and beside them (whole step in one call) the entity-gradient scatter
+    hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part + (bwd ? scatter_blocks : 0u)), dim3(256), 0, st,
+                       n_part, d, k, n_rel, (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
+                       (const int32_t*)chunk_ptr, (const int2*)chunks, part, bwd ? sc : no_sc);
     KGAT_CHECK_LAUNCH("transr_wgrad_partial");
-    if (!(stage & kTrBackward)) {
-      // the loss alone now (block n_rel of the reduction); the row ids are sorted here too - graph of the batch only
-      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, B, d, k, 0, (const int32_t*)chunk_ptr,
+    if (!bwd) {  // the loss alone now (block n_rel of the reduction)
+      hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, 1, 1, B, d, k, 0, (const int32_t*)chunk_ptr,
                          (const float*)part, (const float*)losses, (float*)nullptr, (float*)nullptr, loss,
-                         (const float*)nullptr);
+                         (const float*)nullptr, no_sc);
       KGAT_CHECK_LAUNCH("transr_reduce");
+      return KGAT_OK;
     }
   }
-  if (!(stage & kTrBackward) || !want_grad) return KGAT_OK;
-  hipLaunchKernelGGL(transr_reduce_kernel, dim3((unsigned)n_rel + 1, 8), dim3(256), 0, st, B, d, k, n_rel,
-                     (const int32_t*)chunk_ptr, (const float*)part, (const float*)losses, grad_W, grad_rel,
-                     (stage & kTrForward) ? loss : (float*)nullptr, grad_scale);
+  if (!bwd) return KGAT_OK;
+  // the ordered reductions into grad_W / grad_rel (+ the loss when the forward half ran here); in a backward-only call
+  // the scatter rides along
+  constexpr int kNy = 8;
+  const unsigned red_blocks = ((unsigned)n_rel + 1) * kNy;
+  hipLaunchKernelGGL(transr_reduce_kernel, dim3(red_blocks + (fwd ? 0u : scatter_blocks)), dim3(256), 0, st, (int)red_blocks,
+                     kNy, B, d, k, n_rel, (const int32_t*)chunk_ptr, (const float*)part, (const float*)losses, grad_W,
+                     grad_rel, fwd ? loss : (float*)nullptr, grad_scale, fwd ? no_sc : sc);
   KGAT_CHECK_LAUNCH("transr_reduce");
-  if (hipMemsetAsync(grad_ent, 0, sizeof(float) * (size_t)n_nodes * d, st) != hipSuccess) {
-    set_error("transr: memset failed");
-    return KGAT_E_HIP;
-  }
-  if (id_bits <= 19)
-    hipLaunchKernelGGL(small_sort_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, 3 * B, id_bits, h, pos_t, neg_t, row_order,
-                       sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
-  else  // entity ids beyond 2^19: the 64-bit packing (128 KB of LDS, one more radix pass per 8 id bits)
-    hipLaunchKernelGGL(small_sort_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, 3 * B, id_bits, h, pos_t, neg_t, row_order,
-                       sorted_ids, (int32_t)0, (int32_t*)nullptr, (int32_t*)nullptr, (int2*)nullptr);
-  KGAT_CHECK_LAUNCH("transr_sort_ids");
-  hipLaunchKernelGGL(transr_scatter_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, st, 3 * B, d,
-                     (const int32_t*)sorted_ids, (const int32_t*)row_order, (const float*)DX, grad_ent, grad_scale);
-  KGAT_CHECK_LAUNCH("transr_scatter");
   return KGAT_OK;
 }
 

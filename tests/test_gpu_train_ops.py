@@ -21,7 +21,10 @@ def _model(n, dev, F_dims=(64, 3, 64)):
     return K.KGATPropagation(n, 4, F_dims[0], F_dims[0], F_dims[1], F_dims[2], dropout=0.0).to(dev)
 
 
-@pytest.mark.parametrize("n,F,B", [(500, 176, 1000), (97, 8, 13), (3000, 48, 10240), (64, 260, 300)])
+# (batch sizes on both sides of the gradient's sort forms: 3 B ids in one 4,096-id slice, exactly one slice, one id
+#  over, sixteen slices = the last size of the slice sort + rank merge, and the device radix sort beyond it)
+@pytest.mark.parametrize("n,F,B", [(500, 176, 1000), (97, 8, 13), (3000, 48, 10240), (64, 260, 300), (700, 16, 1365),
+                                   (700, 16, 1366), (5000, 8, 21845), (5000, 8, 21846)])
 def test_bpr_loss_and_gradient_vs_torch(dev, n, F, B):
     """Loss and d loss / d readout of the fused kernels against the torch restatement of get_loss evaluated in
     float64 (rows repeated many times inside a batch, every role; the gradient scaled by what arrives at the loss),
