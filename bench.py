@@ -413,10 +413,14 @@ def train_leg(args, dev, g, n, n_rel, E, host_triplets):
         g.edata["w"] = model.compute_attention(g)
     gen = torch.Generator(device="cpu").manual_seed(99)
     b_cf, b_kg = 10240, 2048
-    u = torch.randint(0, n_users, (b_cf,), generator=gen).int().to(dev)
-    pi = torch.randint(n_users, n_users + n_items, (b_cf,), generator=gen).int().to(dev)
-    ni = torch.randint(n_users, n_users + n_items, (b_cf,), generator=gen).int().to(dev)
     trip = host_triplets()
+    # batches as the reference's default samplers draw them (dataset.py:283-323, 234-281: pos_mode "uniform" = uniform
+    # over the interaction / KG EDGES, so popular items and hub entities recur inside a batch; negatives uniform)
+    uv = np.nonzero(trip[:, 1] == n_rel - 2)[0]          # (user, interact, item) triples of the synthetic CKG
+    pick = uv[torch.randint(0, len(uv), (b_cf,), generator=gen).numpy()]
+    u = torch.as_tensor(trip[pick, 0].astype(np.int32), device=dev)
+    pi = torch.as_tensor(trip[pick, 2].astype(np.int32), device=dev)
+    ni = torch.randint(n_users, n_users + n_items, (b_cf,), generator=gen).int().to(dev)
     idx = torch.randint(0, len(trip), (b_kg,), generator=gen).numpy()
     h = torch.as_tensor(trip[idx, 0].astype(np.int32), device=dev)
     r = torch.as_tensor(trip[idx, 1].astype(np.int32), device=dev)
@@ -482,7 +486,7 @@ def train_leg(args, dev, g, n, n_rel, E, host_triplets):
                             "formula": "kg_steps x kg_step_ms + cf_steps x cf_step_ms + attention refresh + 2 x "
                                        "(attention + gnn + eval)   (reference kgat.py:114-196; host-side batch "
                                        "sampling and the reference's per-step loss.item() are not in it)"},
-            "config": "amazon-book-shaped CKG, batch 10,240 (CF) / 2,048 (KG), dropout 0.1, lr 1e-3, dgl_kgat_amd.FusedAdam, "
+            "config": "amazon-book-shaped CKG, batch 10,240 (CF) / 2,048 (KG) drawn uniformly over the interaction / KG edges as the reference's samplers do (popular items and hub entities recur inside a batch), dropout 0.1, lr 1e-3, dgl_kgat_amd.FusedAdam, "
                       "int32 batch ids, fused TransR / BPR losses; recall@20 / ndcg@20 over %d users x %d items, "
                       "readout width %d (sample value: recall %.4f)" % (n_users, n_items, emb.shape[1], rec[0])}
 

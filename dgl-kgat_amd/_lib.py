@@ -103,7 +103,7 @@ SIGNATURES = {
     "kgat_eval_items_elems": (_i64, [_i64, _i32]),
     "kgat_eval_items_kmajor_f32": (_i32, [_i64, _i32, _p, _i64, _p, _p, _p]),
     "kgat_eval_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
-    "kgat_bpr_workspace_bytes": (_sz, [_i64]),
+    "kgat_bpr_workspace_bytes": (_sz, [_i64, _i32]),
     "kgat_bpr_loss_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
     "kgat_bpr_grad_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
     "kgat_adam_max_tensors": (_i32, []),
@@ -128,7 +128,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def source_hash():

@@ -99,48 +99,156 @@ __global__ __launch_bounds__(256) void bpr_keys_kernel(int64_t batch, const int3
   keys[i] = role == 0 ? u[b] : (role == 1 ? p[b] : n[b]);
 }
 
-// One wavefront per sorted position; the wavefront at the first position of a row id sums the row's contributions in
-// sorted (= sample, the sort is stable) order and writes the row.  scale = grad_scale[0] / batch.
-__global__ __launch_bounds__(256) void bpr_scatter_kernel(int64_t batch, int64_t n_nodes, int F,
-                                                          const float* __restrict__ emb,
-                                                          int64_t stride, const int32_t* __restrict__ u,
-                                                          const int32_t* __restrict__ p, const int32_t* __restrict__ n,
-                                                          const float* __restrict__ coef, float reg_lambda,
-                                                          const float* __restrict__ grad_scale,
-                                                          const int32_t* __restrict__ sorted,
-                                                          const int32_t* __restrict__ order, float* __restrict__ grad) {
+// The dense gradient from the sorted ids, in two launches of bounded work (the scheme of the aggregation's merge
+// tiles and finish launch).  Launch one: a wavefront per WINDOW of 32 sorted positions fetches the 32 samples' indices
+// and coefficients side by side (lanes 0-31: two dependent round trips for the window), then walks the positions in
+// order, the partner rows of eight positions in flight at a time; a row id whose contributions begin and end inside
+// the window is written at once, a first / last piece of a run that crosses the window's edge goes to the window's
+// partial slot 0 / 1.  Launch two: the wavefront of the window in which a crossing run BEGINS adds the run's partials
+// in window order and writes the row.  Every sum has a fixed order (a run inside one window: sample order, as ever;
+// a crossing run: its pieces in sample order, then the pieces in window order): bitwise reproducible, no atomics.
+// (The first form - one wavefront per run, one sample after the other, three dependent round trips each - is fine
+// for uniformly drawn ids; the reference's samplers draw interactions uniformly over EDGES, so a popular item is the
+// positive of hundreds of samples of a batch: ~1 us per sample on one wavefront, +0.9 ms on a 1.0-ms step.)
+constexpr int kBprWin = 32;
+
+struct BprSample {   // what the window's lane l knows about sorted position base + l
+  int32_t key, role, r1, r2;
+  float cv;
+  bool ok;
+};
+
+__global__ __launch_bounds__(256) void bpr_window_kernel(int64_t batch, int64_t n_nodes, int F,
+                                                         const float* __restrict__ emb, int64_t stride,
+                                                         const int32_t* __restrict__ u, const int32_t* __restrict__ p,
+                                                         const int32_t* __restrict__ n, const float* __restrict__ coef,
+                                                         float reg_lambda, const float* __restrict__ grad_scale,
+                                                         const int32_t* __restrict__ sorted,
+                                                         const int32_t* __restrict__ order, float* __restrict__ grad,
+                                                         float* __restrict__ partials) {
   const int lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t total = 3 * batch;
-  if (q >= total) return;
-  const int32_t key = sorted[q];
-  if (q > 0 && sorted[q - 1] == key) return;
-  if ((uint64_t)key >= (uint64_t)n_nodes) return;   // (the forward already turned the loss into NaN)
+  const int64_t base = w * kBprWin;
+  if (base >= total) return;
+  const int m = (int)(total - base < kBprWin ? total - base : kBprWin);
   const float scale = (grad_scale ? grad_scale[0] : 1.f) / (float)batch;
   const float lam = reg_lambda * scale;
-  const float* own = emb + (size_t)key * stride;
-  for (int c = lane * 4; c < F; c += 256) {
-    const float4 o = *reinterpret_cast<const float4*>(own + c);
+  BprSample me;
+  {
+    const int64_t pos = base + (lane < m ? lane : m - 1);
+    me.key = sorted[pos];
+    const int64_t idx = order[pos];
+    const int64_t b = idx % batch;
+    me.role = (int32_t)(idx / batch);
+    const int32_t ub = u[b], pb = p[b], nb = n[b];
+    me.ok = (uint64_t)ub < (uint64_t)n_nodes && (uint64_t)pb < (uint64_t)n_nodes && (uint64_t)nb < (uint64_t)n_nodes &&
+            (uint64_t)me.key < (uint64_t)n_nodes;
+    const float cs = coef[b] * scale;   // -dL/dx
+    // the partner rows: p and n for the source row (dL/ds = dL/dx (p - n)), the source row for p / n (dL/dp = dL/dx s,
+    // dL/dn = -dL/dx s)
+    me.r1 = me.ok ? (me.role == 0 ? pb : ub) : 0;
+    me.r2 = me.ok ? (me.role == 0 ? nb : ub) : 0;
+    me.cv = me.role == 0 ? cs : (me.role == 1 ? -cs : cs);
+    if (!me.ok) me.key = me.key < 0 || (uint64_t)me.key >= (uint64_t)n_nodes ? (int32_t)n_nodes : me.key;
+  }
+  const int32_t prev_key = base > 0 ? sorted[base - 1] : -1;
+  const int32_t next_key = base + m < total ? sorted[base + m] : -2;
+  for (int c0 = 0; c0 < F; c0 += 256) {   // (every lane stays in the loop: the samples live in lanes 0-31)
+    const bool live = c0 + lane * 4 < F;
+    const int c = live ? c0 + lane * 4 : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t j = q; j < total && sorted[j] == key; ++j) {
-      const int64_t idx = order[j];
-      const int64_t b = idx % batch;
-      const int role = (int)(idx / batch);
-      const int32_t ub = u[b], pb = p[b], nb = n[b];
-      if ((uint64_t)ub >= (uint64_t)n_nodes || (uint64_t)pb >= (uint64_t)n_nodes || (uint64_t)nb >= (uint64_t)n_nodes)
-        continue;                         // (a sample with an id outside the table: the forward made the loss NaN)
-      const float cs = coef[b] * scale;   // -dL/dx
-      float4 d;
-      if (role == 0) {   // source row: dL/ds = dL/dx (p - n)
-        const float4 x = *reinterpret_cast<const float4*>(emb + (size_t)pb * stride + c);
-        const float4 y = *reinterpret_cast<const float4*>(emb + (size_t)nb * stride + c);
-        d = make_float4(-cs * (x.x - y.x), -cs * (x.y - y.y), -cs * (x.z - y.z), -cs * (x.w - y.w));
-      } else {           // positive / negative row: dL/dp = dL/dx s, dL/dn = -dL/dx s
-        const float4 a = *reinterpret_cast<const float4*>(emb + (size_t)ub * stride + c);
-        const float sg = role == 1 ? -cs : cs;
-        d = make_float4(sg * a.x, sg * a.y, sg * a.z, sg * a.w);
+    int32_t cur = __shfl(me.key, 0, 64);
+    bool first_piece = true;
+    auto flush = [&](bool last_piece) {
+      if ((uint64_t)cur >= (uint64_t)n_nodes) return;              // ids outside the table carry nothing
+      const bool starts = !(first_piece && prev_key == cur), ends = !(last_piece && next_key == cur);
+      if (!live) return;
+      if (starts && ends) *reinterpret_cast<float4*>(grad + (size_t)cur * F + c) = acc;
+      else *reinterpret_cast<float4*>(partials + ((size_t)w * 2 + (starts ? 1 : 0)) * F + c) = acc;
+    };
+    constexpr int RB = 8;   // positions whose rows are in flight together
+    for (int t0 = 0; t0 < m; t0 += RB) {
+      float4 x[RB], y[RB], o[RB];
+      int32_t kt[RB], rl[RB];
+      float cv[RB];
+      bool okt[RB];
+#pragma unroll
+      for (int t = 0; t < RB; ++t) {
+        const int tt = t0 + t < m ? t0 + t : m - 1;
+        kt[t] = __shfl(me.key, tt, 64);
+        rl[t] = __shfl(me.role, tt, 64);
+        okt[t] = __shfl((int)me.ok, tt, 64) != 0;
+        cv[t] = __shfl(me.cv, tt, 64);
+        const int32_t a1 = __shfl(me.r1, tt, 64), a2 = __shfl(me.r2, tt, 64);
+        x[t] = *reinterpret_cast<const float4*>(emb + (size_t)a1 * stride + c);
+        y[t] = *reinterpret_cast<const float4*>(emb + (size_t)a2 * stride + c);
+        o[t] = *reinterpret_cast<const float4*>(emb + (size_t)(okt[t] ? kt[t] : 0) * stride + c);
       }
-      acc.x += d.x + lam * o.x; acc.y += d.y + lam * o.y; acc.z += d.z + lam * o.z; acc.w += d.w + lam * o.w;
+#pragma unroll
+      for (int t = 0; t < RB; ++t) {
+        if (t0 + t >= m) continue;
+        if (kt[t] != cur) {   // (wave-uniform)
+          flush(false);
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          cur = kt[t];
+          first_piece = false;
+        }
+        if (!okt[t]) continue;   // (a sample with an id outside the table: the forward made the loss NaN)
+        float4 d;
+        if (rl[t] == 0) d = make_float4(-cv[t] * (x[t].x - y[t].x), -cv[t] * (x[t].y - y[t].y), -cv[t] * (x[t].z - y[t].z),
+                                        -cv[t] * (x[t].w - y[t].w));
+        else d = make_float4(cv[t] * x[t].x, cv[t] * x[t].y, cv[t] * x[t].z, cv[t] * x[t].w);
+        acc.x += d.x + lam * o[t].x; acc.y += d.y + lam * o[t].y; acc.z += d.z + lam * o[t].z; acc.w += d.w + lam * o[t].w;
+      }
+    }
+    flush(true);
+  }
+}
+
+// the runs that cross window edges: the wavefront of the window in which such a run begins (its last piece, slot 1)
+// adds the following windows' first pieces (slot 0) in window order
+__global__ __launch_bounds__(256) void bpr_carry_kernel(int64_t batch, int64_t n_nodes, int F,
+                                                        const int32_t* __restrict__ sorted,
+                                                        const float* __restrict__ partials, float* __restrict__ grad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = 3 * batch;
+  const int64_t base = w * kBprWin;
+  if (base >= total) return;
+  const int m = (int)(total - base < kBprWin ? total - base : kBprWin);
+  if (base + m >= total) return;                      // the last window: nothing continues
+  const int32_t key = sorted[base + m - 1];
+  if (sorted[base + m] != key) return;                // its last run ends with the window
+  if ((uint64_t)key >= (uint64_t)n_nodes) return;
+  // does that run begin in this window?  (its first position is inside it, or it fills the window from its start on
+  // with another id before it)
+  if (sorted[base] == key && base > 0 && sorted[base - 1] == key) return;   // a middle window of the run
+  // the windows behind it that the run reaches: window w + j continues it iff its first id is the key; it is the last
+  // one iff the run ends inside it (or at its end)
+  int64_t n_follow = 0;
+  while (true) {   // 64 windows per look
+    const int64_t wj = w + 1 + n_follow + lane;
+    const bool cont = wj * kBprWin < total && sorted[wj * kBprWin] == key;
+    const unsigned long long mk = __ballot(cont);
+    if (mk == ~0ull) { n_follow += 64; continue; }
+    n_follow += __builtin_ctzll(~mk);
+    break;
+  }
+  for (int c0 = 0; c0 < F; c0 += 256) {
+    const int c = c0 + lane * 4;
+    if (c >= F) continue;
+    float4 acc = *reinterpret_cast<const float4*>(partials + ((size_t)w * 2 + 1) * F + c);
+    for (int64_t j0 = 0; j0 < n_follow; j0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int64_t wj = w + 1 + (j0 + t < n_follow ? j0 + t : n_follow - 1);
+        v[t] = *reinterpret_cast<const float4*>(partials + ((size_t)wj * 2 + 0) * F + c);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (j0 + t < n_follow) { acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w; }
     }
     *reinterpret_cast<float4*>(grad + (size_t)key * F + c) = acc;
   }
@@ -285,13 +393,16 @@ using namespace kgat;
 
 extern "C" {
 
-size_t kgat_bpr_workspace_bytes(int64_t batch) {
+size_t kgat_bpr_workspace_bytes(int64_t batch, int F) {
   if (batch < 1) batch = 1;
+  if (F < 4) F = 4;
   // per-sample partials (4 B floats) | keys, order (3 B int32 each) | sort scratch: the device radix sort's, or the
   // one-workgroup sort's two packed buffers + its sorted keys
   const size_t one_wg = 3 * batch <= kSliceSort * kSliceSortMaxLists ? align_up((size_t)batch * 3 * 8, 256) + align_up((size_t)batch * 3 * 4, 256) : 0;
   const size_t radix = radix_sort_workspace_bytes(3 * batch);
-  return align_up((size_t)batch * 4 * 4, 256) + 2 * align_up((size_t)batch * 3 * 4, 256) + (one_wg > radix ? one_wg : radix) + 256;
+  // + the window partials of the gradient (two rows of F floats per 32 sorted positions)
+  const size_t win = align_up((size_t)((3 * batch + kBprWin - 1) / kBprWin) * 2 * (size_t)F * 4, 256);
+  return align_up((size_t)batch * 4 * 4, 256) + 2 * align_up((size_t)batch * 3 * 4, 256) + win + (one_wg > radix ? one_wg : radix) + 256;
 }
 
 int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
@@ -302,7 +413,7 @@ int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
   KGAT_CHECK_ARG(batch < ((int64_t)1 << 29), "bpr_loss: batch too large");
   KGAT_CHECK_ARG(emb && u && p && n && loss && coef && workspace, "bpr_loss: null pointer");
   KGAT_CHECK_ARG((reinterpret_cast<uintptr_t>(emb) & 15) == 0, "bpr_loss: emb must be 16-byte aligned");
-  if (workspace_bytes < kgat_bpr_workspace_bytes(batch)) {
+  if (workspace_bytes < kgat_bpr_workspace_bytes(batch, F)) {
     set_error("bpr_loss: workspace too small");
     return KGAT_E_WORKSPACE;
   }
@@ -326,7 +437,7 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
   KGAT_CHECK_ARG(emb && u && p && n && coef && grad && workspace, "bpr_grad: null pointer");
   KGAT_CHECK_ARG(((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0,
                  "bpr_grad: emb and grad must be 16-byte aligned");
-  if (workspace_bytes < kgat_bpr_workspace_bytes(batch)) {
+  if (workspace_bytes < kgat_bpr_workspace_bytes(batch, F)) {
     set_error("bpr_grad: workspace too small");
     return KGAT_E_WORKSPACE;
   }
@@ -334,6 +445,7 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
   cv.take<float>((size_t)batch * 4);
   int32_t* keys = cv.take<int32_t>((size_t)batch * 3);
   int32_t* order = cv.take<int32_t>((size_t)batch * 3);
+  float* win_part = cv.take<float>((size_t)((3 * batch + kBprWin - 1) / kBprWin) * 2 * (size_t)F);
   void* sort_ws = cv.base + cv.off;
   hipStream_t st = as_stream(stream);
   const int32_t* sorted = nullptr;
@@ -361,9 +473,15 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
       return KGAT_E_HIP;
     }
   }
-  hipLaunchKernelGGL(bpr_scatter_kernel, dim3((unsigned)((3 * batch + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F,
-                     emb, emb_stride, u, p, n, coef, reg_lambda, grad_scale, sorted, (const int32_t*)order, grad);
-  KGAT_CHECK_LAUNCH("bpr_scatter");
+  {
+    const int64_t n_win = (3 * batch + kBprWin - 1) / kBprWin;
+    hipLaunchKernelGGL(bpr_window_kernel, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F, emb,
+                       emb_stride, u, p, n, coef, reg_lambda, grad_scale, sorted, (const int32_t*)order, grad, win_part);
+    KGAT_CHECK_LAUNCH("bpr_window");
+    hipLaunchKernelGGL(bpr_carry_kernel, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, st, batch, n_nodes, F, sorted,
+                       (const float*)win_part, grad);
+  }
+  KGAT_CHECK_LAUNCH("bpr_carry");
   return KGAT_OK;
 }
 

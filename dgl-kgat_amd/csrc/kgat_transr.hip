@@ -356,20 +356,86 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
 }
 
 // ---- W_R gradient: partial sums of x^T ga per chunk of <= 64 relation-sorted samples
-constexpr int kTrStage = 16;  // samples staged through LDS per step of the partial kernel
 
 // Thread t owns 4 x 4 blocks of the d x k outer-product sum: block index t, t + 256, ... over
 // (d/4) x (k/4) blocks, so a sample costs two 16-byte LDS reads per 16 fmas.  d, k multiples of 4.
+// The staging area of the partial kernels (dynamic LDS): `st` samples of x (3 rows of d), g (3 rows of k) and the
+// relation row (k) each, row strides sxs / sgs = the width rounded up to 32 floats + 16 (three rows apart - the four
+// sample slots of an MFMA operand - then fall 16 banks apart instead of on the same ones).
+struct TrStageGeom {
+  int st, sxs, sgs;
+};
+static TrStageGeom transr_stage_geom(int d, int k) {
+  TrStageGeom g;
+  g.sxs = (d + 31) / 32 * 32 + 16;
+  g.sgs = (k + 31) / 32 * 32 + 16;
+  const int per_sample = 3 * g.sxs + 3 * g.sgs + (k + 3) / 4 * 4;
+  int st = (150 * 1024 / 4) / per_sample;
+  st = st > kTrChunk ? kTrChunk : st;
+  g.st = st / 4 * 4;
+  return g;
+}
+static size_t transr_stage_bytes(int d, int k) {
+  const TrStageGeom g = transr_stage_geom(d, k);
+  return (size_t)g.st * (3 * g.sxs + 3 * g.sgs + (k + 3) / 4 * 4) * sizeof(float);
+}
+
+// `ns` samples from s0 on into the staging area; rows past `ns` up to `fill` read as zero.  The global side is
+// contiguous (rows of d / k floats back to back), so the block walks it 16 bytes per thread, UB loads in flight per
+// thread before the first LDS store (a load and its store inside one loop iteration made every row a round trip of its
+// own - 24 in a row, two thirds of the kernel's time; element-wise index arithmetic, three divisions by run-time widths
+// per float, was most of the rest).
+__device__ __forceinline__ void transr_stage_rows(float* __restrict__ dst, int stride, const float* __restrict__ src,
+                                                  int width, int n_rows) {
+  constexpr int UB = 6;
+  const int n4 = n_rows * width / 4;   // float4 pieces (width is a multiple of 4)
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  for (int base = threadIdx.x; base < n4; base += 256 * UB) {
+    float4 v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int f = base + 256 * u;
+      v[u] = s4[f < n4 ? f : n4 - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int f = base + 256 * u;
+      if (f < n4) {
+        const unsigned e = 4u * (unsigned)f, row = e / (unsigned)width, col = e - row * (unsigned)width;
+        *reinterpret_cast<float4*>(dst + (size_t)row * stride + col) = v[u];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void transr_stage_load(float* __restrict__ sx, float* __restrict__ sg, float* __restrict__ sr,
+                                                  const TrStageGeom& g, int d, int k, int32_t s0, int ns, int fill,
+                                                  const float* __restrict__ XS, const float* __restrict__ GA,
+                                                  const float* __restrict__ GR) {
+  const int kr = (k + 3) / 4 * 4;
+  transr_stage_rows(sx, g.sxs, XS + (size_t)3 * s0 * d, d, 3 * ns);
+  transr_stage_rows(sg, g.sgs, GA + (size_t)3 * s0 * k, k, 3 * ns);
+  transr_stage_rows(sr, kr, GR + (size_t)s0 * k, k, ns);
+  // zero rows behind the last sample (the MFMA form rounds the sample count up to a multiple of four)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int hl = lane >> 5, c4 = 4 * (lane & 31);
+  for (int rr = 3 * ns + 2 * w + hl; rr < 3 * fill; rr += 8) {
+    if (c4 < d) *reinterpret_cast<float4*>(sx + (size_t)rr * g.sxs + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < k) *reinterpret_cast<float4*>(sg + (size_t)rr * g.sgs + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 __device__ __forceinline__ void transr_wgrad_partial_body(
-    int bx, int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
-    const float* __restrict__ GA, const float* __restrict__ GR, const int32_t* __restrict__ chunk_ptr,
-    const int2* __restrict__ chunks, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float s_x[kTrStage][3][kTrMaxDim];
-  __shared__ __attribute__((aligned(16))) float s_g[kTrStage][3][kTrMaxDim];
-  __shared__ float s_r[kTrStage][kTrMaxDim];
+    float* s_dyn, const TrStageGeom g, int bx, int d, int k, int n_rel, const int32_t* __restrict__ seg,
+    const float* __restrict__ XS, const float* __restrict__ GA, const float* __restrict__ GR,
+    const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part) {
   if ((int32_t)bx >= chunk_ptr[n_rel]) return;
   const int2 ck = chunks[bx];
   const int32_t beg = ck.y, end = beg + kTrChunk < seg[ck.x + 1] ? beg + kTrChunk : seg[ck.x + 1];
+  const int kr = (k + 3) / 4 * 4;
+  float* const sx = s_dyn;
+  float* const sg = sx + (size_t)g.st * 3 * g.sxs;
+  float* const sr = sg + (size_t)g.st * 3 * g.sgs;
   constexpr int TV = (kTrMaxDim / 4) * (kTrMaxDim / 4) / 256;  // 4 x 4 blocks per thread at the largest size
   float acc[TV][4][4], racc = 0.f;
 #pragma unroll
@@ -386,14 +452,10 @@ __device__ __forceinline__ void transr_wgrad_partial_body(
     bi[o] = t < n_blk ? 4 * (t / kb) : -1;
     bj[o] = 4 * (t % kb);
   }
-  for (int32_t s0 = beg; s0 < end; s0 += kTrStage) {
-    const int ns = end - s0 < kTrStage ? end - s0 : kTrStage;
+  for (int32_t s0 = beg; s0 < end; s0 += g.st) {
+    const int ns = end - s0 < g.st ? end - s0 : g.st;
     __syncthreads();
-    for (int t = threadIdx.x; t < ns * 3 * d; t += 256)
-      s_x[t / (3 * d)][(t / d) % 3][t % d] = XS[(size_t)3 * s0 * d + t];
-    for (int t = threadIdx.x; t < ns * 3 * k; t += 256)
-      s_g[t / (3 * k)][(t / k) % 3][t % k] = GA[(size_t)3 * s0 * k + t];
-    for (int t = threadIdx.x; t < ns * k; t += 256) s_r[t / k][t % k] = GR[(size_t)s0 * k + t];
+    transr_stage_load(sx, sg, sr, g, d, k, s0, ns, ns, XS, GA, GR);
     __syncthreads();
     for (int q = 0; q < ns; ++q) {
 #pragma unroll
@@ -401,16 +463,16 @@ __device__ __forceinline__ void transr_wgrad_partial_body(
         if (bi[o] < 0) continue;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-          const float4 x = *reinterpret_cast<const float4*>(&s_x[q][v][bi[o]]);
-          const float4 g = *reinterpret_cast<const float4*>(&s_g[q][v][bj[o]]);
-          const float xs[4] = {x.x, x.y, x.z, x.w}, gs[4] = {g.x, g.y, g.z, g.w};
+          const float4 x = *reinterpret_cast<const float4*>(sx + (size_t)(3 * q + v) * g.sxs + bi[o]);
+          const float4 gg = *reinterpret_cast<const float4*>(sg + (size_t)(3 * q + v) * g.sgs + bj[o]);
+          const float xs[4] = {x.x, x.y, x.z, x.w}, gs[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[o][a][c] = fmaf(xs[a], gs[c], acc[o][a][c]);
         }
       }
-      if (threadIdx.x < k) racc += s_r[q][threadIdx.x];
+      if (threadIdx.x < k) racc += sr[(size_t)q * kr + threadIdx.x];
     }
   }
   const int dk = d * k;
@@ -424,6 +486,82 @@ __device__ __forceinline__ void transr_wgrad_partial_body(
       v4.x = acc[o][a][0]; v4.y = acc[o][a][1]; v4.z = acc[o][a][2]; v4.w = acc[o][a][3];
       *reinterpret_cast<float4*>(out + (size_t)(bi[o] + a) * k + bj[o]) = v4;
     }
+  }
+  if (threadIdx.x < k) out[dk + threadIdx.x] = racc;
+}
+
+// The same partial sums on the fp32 matrix pipe (d, k multiples of 16): the block's four wavefronts share the
+// (d/16) x (k/16) output tiles round robin; v_mfma_f32_16x16x4_f32 takes four samples of one operand kind per
+// instruction (A = x[sample][16 ti + i], B = g[sample][16 tj + j]: exact fp32 products, fp32 accumulate).  The whole
+// chunk is staged in ONE round trip where it fits (64 samples at d = k = 64: 139 KB), its tail zero-filled to a
+// multiple of 16 samples (zero rows add nothing); the operand pairs of four MFMA groups are requested from LDS together,
+// ahead of their twelve instructions.  32 us (vector form, element-wise staging of 16 samples at a time) -> ~10.  The
+// order of additions differs from the vector form's (four samples inside an instruction), fixed all the same.
+typedef float trx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void transr_wgrad_mfma_body(
+    float* s_dyn, const TrStageGeom g, int bx, int d, int k, int n_rel, const int32_t* __restrict__ seg,
+    const float* __restrict__ XS, const float* __restrict__ GA, const float* __restrict__ GR,
+    const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part) {
+  if ((int32_t)bx >= chunk_ptr[n_rel]) return;
+  const int2 ck = chunks[bx];
+  const int32_t beg = ck.y, end = beg + kTrChunk < seg[ck.x + 1] ? beg + kTrChunk : seg[ck.x + 1];
+  const int kr = (k + 3) / 4 * 4;
+  float* const sx = s_dyn;
+  float* const sg = sx + (size_t)g.st * 3 * g.sxs;
+  float* const sr = sg + (size_t)g.st * 3 * g.sgs;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int tk = k / 16, n_tiles = (d / 16) * tk;
+  constexpr int MAXT = (kTrMaxDim / 16) * (kTrMaxDim / 16) / 4;  // tiles per wavefront at the largest size
+  trx4 acc[MAXT];
+#pragma unroll
+  for (int o = 0; o < MAXT; ++o) acc[o] = (trx4){0.f, 0.f, 0.f, 0.f};
+  float racc = 0.f;
+  for (int32_t s0 = beg; s0 < end; s0 += g.st) {
+    const int ns = end - s0 < g.st ? end - s0 : g.st;
+    const int ng = (ns + 3) >> 2;                    // groups of four samples
+    const int fill = 4 * ng < g.st ? 4 * ng : g.st;  // (g.st is a multiple of 4)
+    __syncthreads();
+    transr_stage_load(sx, sg, sr, g, d, k, s0, ns, fill, XS, GA, GR);
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < MAXT; ++o) {
+      const int t = w + 4 * o;
+      if (t >= n_tiles) break;   // (wave-uniform)
+      const int ti = t / tk, tj = t - ti * tk;
+      const float* px = sx + (size_t)(3 * lq) * g.sxs + 16 * ti + li;
+      const float* pg = sg + (size_t)(3 * lq) * g.sgs + 16 * tj + li;
+      for (int gb = 0; gb < ng; gb += 4) {
+        float av[4][3], bv[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const int gq = gb + j < ng ? gb + j : ng - 1;   // (clamped: the products of a repeated group are skipped below)
+            av[j][v] = px[(size_t)(12 * gq + v) * g.sxs];
+            bv[j][v] = pg[(size_t)(12 * gq + v) * g.sgs];
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (gb + j < ng) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][v], bv[j][v], acc[o], 0, 0, 0);
+          }
+      }
+    }
+    if (threadIdx.x < k)
+      for (int q = 0; q < ns; ++q) racc += sr[(size_t)q * kr + threadIdx.x];
+  }
+  const int dk = d * k;
+  float* out = part + (size_t)bx * (dk + k);
+#pragma unroll
+  for (int o = 0; o < MAXT; ++o) {
+    const int t = w + 4 * o;
+    if (t >= n_tiles) break;
+    const int ti = t / tk, tj = t - ti * tk;
+    // acc[o][r] = sum over samples of x[16 ti + 4 lq + r] * g[16 tj + li]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + 4 * lq + r) * k + 16 * tj + li] = acc[o][r];
   }
   if (threadIdx.x < k) out[dk + threadIdx.x] = racc;
 }
@@ -478,44 +616,85 @@ __device__ __forceinline__ void transr_scatter_body(int bx, int32_t n_rows, int 
   const int sl = threadIdx.x & 15;
   const int32_t p = bx * 16 + (threadIdx.x >> 4);
   if (p >= n_rows) return;
-  const int32_t id = sorted_ids[p];
-  if (p > 0 && sorted_ids[p - 1] == id) return;  // not the head of its run
+  // ONE round trip tells the group everything about its run's first 64 positions: the id before it, the ids and the
+  // row numbers of positions p .. p + 63 (lane sl takes positions p + sl + 16 j).  (Id, then the ids behind it, then
+  // the row numbers, then the rows - four dependent round trips per look - made this a 26-us launch of 6,144 rows.)
+  constexpr int LK = 4;   // looks of sixteen positions covered by the first round trip
+  int32_t my_id[LK], my_row[LK];
+#pragma unroll
+  for (int j = 0; j < LK; ++j) {
+    const int32_t qs = p + 16 * j + sl < n_rows ? p + 16 * j + sl : n_rows - 1;
+    my_id[j] = sorted_ids[qs];
+    my_row[j] = row_order[qs];
+  }
+  const int32_t prev = p > 0 ? sorted_ids[p - 1] : -1;
   // 16-lane ballots: the group's lanes are bits [16 g, 16 g + 16) of the wavefront mask
   const int gshift = (threadIdx.x & 48);
+  const int32_t id = __shfl(my_id[0], 0, 16);
+  if (p > 0 && prev == id) return;  // not the head of its run
   int32_t len = 0;
-  while (true) {
+  bool open = true;
+#pragma unroll
+  for (int j = 0; j < LK; ++j) {
+    const unsigned m = (unsigned)((__ballot(open && p + 16 * j + sl < n_rows && my_id[j] == id) >> gshift) & 0xFFFFull);
+    if (open) {
+      if (m == 0xFFFFu) len += 16;
+      else { len += __builtin_ctz(~m); open = false; }
+    }
+  }
+  while (open) {  // a run beyond the first 64 positions: sixteen more ids per step
     const int32_t q = p + len + sl;
     const bool same = q < n_rows && sorted_ids[q] == id;
     const unsigned m = (unsigned)((__ballot(same) >> gshift) & 0xFFFFull);
     if (m == 0xFFFFu) { len += 16; continue; }
     len += __builtin_ctz(~m);
-    break;
+    open = false;
   }
-  float acc[kTrMaxDim / 16];
+  // Lane sl owns floats 4 sl .. 4 sl + 3 (and + 64 at d > 64) of the row: one 16-byte load per row and half, SIXTEEN
+  // rows in flight per look.  (Batches are drawn from the triples, so a hub entity heads dozens of samples of a batch:
+  // four rows per look made its one lane group walk 49 rows in 13 dependent round trips - the launch's 26 us.)  The
+  // rows are still added one after the other in sorted order: same bits.
+  constexpr int HV = kTrMaxDim / 64;  // 16-byte pieces per lane and row at the largest width
+  float4 acc[HV];
 #pragma unroll
-  for (int c = 0; c < kTrMaxDim / 16; ++c) acc[c] = 0.f;
-  for (int32_t q0 = 0; q0 < len; q0 += 4) {
-    int32_t rows[4];
+  for (int c = 0; c < HV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t q0 = 0; q0 < len; q0 += 16) {
+    float4 v[16][HV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rows[u] = row_order[p + (q0 + u < len ? q0 + u : len - 1)];
-    float v[4][kTrMaxDim / 16];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int c = 0; c < kTrMaxDim / 16; ++c) {
-        const int i = sl + 16 * c;
-        v[u][c] = i < d ? DX[(size_t)rows[u] * d + i] : 0.f;
+    for (int u = 0; u < 16; ++u) {
+      const int32_t qq = q0 + u < len ? q0 + u : len - 1;
+      // the first 64 row numbers are in the group's registers already
+      int32_t row;
+      if (q0 < 16 * LK) {   // (uniform over the group)
+        const int jj = q0 >> 4;
+        const int32_t mine = jj == 0 ? my_row[0] : (jj == 1 ? my_row[1] : (jj == 2 ? my_row[2] : my_row[3]));
+        row = __shfl(mine, qq & 15, 16);
+      } else {
+        row = row_order[p + qq];
       }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+      for (int c = 0; c < HV; ++c) {
+        const int i = 4 * sl + 64 * c;
+        v[u][c] = i < d ? *reinterpret_cast<const float4*>(DX + (size_t)row * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
       if (q0 + u < len)
 #pragma unroll
-        for (int c = 0; c < kTrMaxDim / 16; ++c) acc[c] += v[u][c];
+        for (int c = 0; c < HV; ++c) {
+          acc[c].x += v[u][c].x; acc[c].y += v[u][c].y; acc[c].z += v[u][c].z; acc[c].w += v[u][c].w;
+        }
   }
+  const float gs = grad_scale ? grad_scale[0] : 1.f;
 #pragma unroll
-  for (int c = 0; c < kTrMaxDim / 16; ++c) {
-    const int i = sl + 16 * c;
-    if (i < d) grad_ent[(size_t)id * d + i] = grad_scale ? acc[c] * grad_scale[0] : acc[c];
+  for (int c = 0; c < HV; ++c) {
+    const int i = 4 * sl + 64 * c;
+    if (i < d) {
+      float4 o = acc[c];
+      if (grad_scale) { o.x *= gs; o.y *= gs; o.z *= gs; o.w *= gs; }
+      *reinterpret_cast<float4*>(grad_ent + (size_t)id * d + i) = o;
+    }
   }
 }
 
@@ -533,9 +712,12 @@ struct TrScatterArgs {
 __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
     int n_first, int d, int k, int n_rel, const int32_t* __restrict__ seg, const float* __restrict__ XS,
     const float* __restrict__ GA, const float* __restrict__ GR, const int32_t* __restrict__ chunk_ptr,
-    const int2* __restrict__ chunks, float* __restrict__ part, TrScatterArgs sc) {
-  if ((int)blockIdx.x < n_first) transr_wgrad_partial_body((int)blockIdx.x, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
-  else transr_scatter_body((int)blockIdx.x - n_first, sc.n_rows, d, sc.sorted_ids, sc.row_order, sc.DX, sc.grad_ent, sc.grad_scale);
+    const int2* __restrict__ chunks, float* __restrict__ part, TrStageGeom geom, TrScatterArgs sc) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // (the scatter's blocks do not touch it)
+  if ((int)blockIdx.x < n_first) {
+    if (d % 16 == 0 && k % 16 == 0) transr_wgrad_mfma_body(s_dyn, geom, (int)blockIdx.x, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
+    else transr_wgrad_partial_body(s_dyn, geom, (int)blockIdx.x, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
+  } else transr_scatter_body((int)blockIdx.x - n_first, sc.n_rows, d, sc.sorted_ids, sc.row_order, sc.DX, sc.grad_ent, sc.grad_scale);
 }
 
 __global__ __launch_bounds__(256) void transr_reduce_kernel(int n_first, int ny, int32_t batch, int d, int k, int n_rel,
@@ -658,9 +840,21 @@ static int transr_run(int stage, int64_t n_nodes, int n_rel, int d, int k, int64
                        pos_t, neg_t, ent, W_R, rel, reg_lambda, losses, GA, GR, DX, XS);
     KGAT_CHECK_LAUNCH("transr_sample");
     // the weight-gradient partials, and beside them (whole step in one call) the entity-gradient scatter
-    hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part + (bwd ? scatter_blocks : 0u)), dim3(256), 0, st,
+    const size_t lds = transr_stage_bytes(d, k);
+    {
+      static size_t lds_set = 0;   // (the attribute is per function; raise it when a larger width comes along)
+      if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(transr_wgrad_partial_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          set_error("transr: cannot reserve %zu bytes of LDS", lds);
+          return KGAT_E_HIP;
+        }
+        lds_set = lds;
+      }
+    }
+    hipLaunchKernelGGL(transr_wgrad_partial_kernel, dim3((unsigned)n_part + (bwd ? scatter_blocks : 0u)), dim3(256), lds, st,
                        n_part, d, k, n_rel, (const int32_t*)seg, (const float*)XS, (const float*)GA, (const float*)GR,
-                       (const int32_t*)chunk_ptr, (const int2*)chunks, part, bwd ? sc : no_sc);
+                       (const int32_t*)chunk_ptr, (const int2*)chunks, part, transr_stage_geom(d, k), bwd ? sc : no_sc);
     KGAT_CHECK_LAUNCH("transr_wgrad_partial");
     if (!bwd) {  // the loss alone now (block n_rel of the reduction)
       hipLaunchKernelGGL(transr_reduce_kernel, dim3(1), dim3(256), 0, st, 1, 1, B, d, k, 0, (const int32_t*)chunk_ptr,

@@ -909,7 +909,7 @@ def bpr_loss(emb, u, p, n, reg_lambda):
     lib = _lib.load()
     loss = torch.empty((), dtype=torch.float32, device=emb.device)
     coef = torch.empty(b, dtype=torch.float32, device=emb.device)
-    ws = _workspace(lib.kgat_bpr_workspace_bytes(b), emb.device)
+    ws = _workspace(lib.kgat_bpr_workspace_bytes(b, emb.shape[1]), emb.device)
     with _timed("bpr_loss", (b, emb.shape[1])):
         check(lib.kgat_bpr_loss_f32(emb.shape[0], emb.shape[1], _ptr(emb), emb.stride(0), b, _ptr(u), _ptr(p), _ptr(n),
                                     float(reg_lambda), _ptr(loss), _ptr(coef), _ptr(ws), ws.numel(), _stream(emb)),
@@ -924,7 +924,7 @@ def bpr_grad(emb, u, p, n, coef, reg_lambda, grad_scale=None, workspace=None):
     grad = torch.empty((emb.shape[0], emb.shape[1]), dtype=torch.float32, device=emb.device)
     if grad_scale is not None:
         grad_scale = _need(grad_scale.reshape(1), torch.float32, "grad_scale")
-    ws = workspace if workspace is not None else _workspace(lib.kgat_bpr_workspace_bytes(b), emb.device)
+    ws = workspace if workspace is not None else _workspace(lib.kgat_bpr_workspace_bytes(b, emb.shape[1]), emb.device)
     with _timed("bpr_grad", (b, emb.shape[1])):
         check(lib.kgat_bpr_grad_f32(emb.shape[0], emb.shape[1], _ptr(emb), emb.stride(0), b, _ptr(u), _ptr(p), _ptr(n),
                                     _ptr(coef), float(reg_lambda), _ptr(grad_scale), _ptr(grad), _ptr(ws), ws.numel(),

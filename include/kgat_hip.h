@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 8
+#define KGAT_ABI_VERSION 9
 
 enum {
   KGAT_OK = 0,
@@ -513,9 +513,11 @@ int kgat_adam_step_f32(int n_tensors, const int64_t* sizes_host, float* const* p
  * kgat_bpr_loss_f32: loss (1 float) and coef[batch] = sigmoid(-(x_b)) for the backward.
  * kgat_bpr_grad_f32: d loss / d emb as a DENSE n_nodes x F matrix (rows outside the batch zero - what torch's
  * index backward produces), times grad_scale[0] (DEVICE scalar = the gradient arriving at the loss; NULL = 1): rows
- * that occur several times are summed in sample order after a stable sort of the 3 x batch row ids - fixed order of
- * additions, no float atomics, bitwise reproducible.  Same workspace size for both. */
-size_t kgat_bpr_workspace_bytes(int64_t batch);
+ * that occur several times are summed after a stable sort of the 3 x batch row ids: in sample order inside a window of
+ * 32 sorted positions, a row that spans several windows as its window pieces in window order - a fixed order of
+ * additions, no float atomics, bitwise reproducible, and bounded work per wavefront whatever the popularity of a row.
+ * Same workspace size for both (it depends on F since ABI version 9: the windows' partial rows). */
+size_t kgat_bpr_workspace_bytes(int64_t batch, int F);
 int kgat_bpr_loss_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stride, int64_t batch, const int32_t* u,
                       const int32_t* p, const int32_t* n, float reg_lambda, float* loss, float* coef, void* workspace,
                       size_t workspace_bytes, kgat_stream_t stream);
