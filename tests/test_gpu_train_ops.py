@@ -54,6 +54,62 @@ def test_bpr_loss_and_gradient_vs_torch(dev, n, F, B):
     assert float(l2.detach()) == float(l0)
 
 
+@pytest.mark.parametrize("B,hot", [(4000, 1500), (300, 299), (10240, 40)])
+def test_bpr_gradient_hot_rows(dev, B, hot):
+    """Batches as an edge-uniform sampler draws them: one item is the positive of `hot` samples (its contributions span
+    many 32-position windows of the sorted ids: window pieces + carry launch), one user the source of 70, one row
+    appears in all three roles; against the float64 torch restatement, and bit for bit the same on a second call."""
+    torch.manual_seed(B)
+    n, F = 2000, 176
+    m = _model(n, dev)
+    emb = torch.randn(n, F, device=dev)
+    u = torch.randint(0, n, (B,), device=dev)
+    p = torch.randint(0, n, (B,), device=dev)
+    q = torch.randint(0, n, (B,), device=dev)
+    p[torch.randperm(B, device=dev)[:hot]] = 1234
+    u[torch.randperm(B, device=dev)[:min(70, B)]] = 77
+    q[:3] = 1234
+    u[3:6] = 1234
+    outs = []
+    for fused, dt in ((True, torch.float32), (True, torch.float32), (False, torch.float64)):
+        e = emb.to(dt).clone().requires_grad_(True)
+        loss = m.get_loss(e, u, p, q, fused=fused)
+        loss.backward()
+        outs.append(e.grad.double().cpu().numpy())
+    g0, g1, gr = outs
+    assert np.array_equal(g0, g1)
+    scale = np.abs(gr).max()
+    assert np.abs(g0 - gr).max() <= 3e-6 * scale, np.abs(g0 - gr).max() / scale
+    assert not (gr == 0).any() or np.abs(g0[gr == 0]).max() == 0
+
+
+def test_transr_hub_batch(dev):
+    """A KG batch in which one entity heads 300 of 1,024 samples and is the tail of 100 more (its gradient row is the
+    sum of 400 rows: the scatter's looks of sixteen rows, beyond its first 64 positions): kg_step against the autograd
+    path, same bits; gradients against the torch restatement."""
+    import dgl_kgat_amd as K
+    torch.manual_seed(11)
+    n, R, B = 3000, 7, 1024
+    m = K.KGATPropagation(n, R, 64, 64, 2, 32, dropout=0.0).to(dev)
+    h = torch.randint(0, n, (B,), device=dev); r = torch.randint(0, R, (B,), device=dev)
+    pt = torch.randint(0, n, (B,), device=dev); nt = torch.randint(0, n, (B,), device=dev)
+    h[:300] = 42
+    pt[300:400] = 42
+    grads = []
+    for fused in (True, False):
+        m.zero_grad()
+        m.transR(h, r, pt, nt, fused=fused).backward()
+        grads.append([x.grad.clone() for x in (m.entity_embed.weight, m.W_R, m.relation_embed.weight)])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+    g_again = []
+    m.zero_grad()
+    m.transR(h, r, pt, nt).backward()
+    g_again = [x.grad.clone() for x in (m.entity_embed.weight, m.W_R, m.relation_embed.weight)]
+    for a, b in zip(grads[0], g_again):
+        assert torch.equal(a, b)
+
+
 def test_bpr_under_the_training_stack(dev):
     """get_loss(gnn(g)) -> backward through the fused propagation stack: parameter gradients equal to those of the
     torch-operator loss."""
