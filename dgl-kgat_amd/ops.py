@@ -256,7 +256,7 @@ FOLD_TILE_CAP32 = 512   # 32-group tiles (d = 64): the same positions per head g
 # ticks of workgroup time per tile, 389 per later chunk, 10,661 per relation change; with the fp32
 # products 1,459 / 267 / 10,630.  Both in units of a 64th of a tile.  Round 3 re-scanned the triple
 # for the kernel with packed records and coalesced stores.  Stand-alone launches (variants
-# alternating, every launch with another tile split: scripts/micro/att_variants_ab.py) preferred
+# alternating, every launch with another tile split; the tool went with round 5's clean-up) preferred
 # cheaper chunks - (64,24,800) 0.145 ms against 0.151 - but INSIDE the step, where the launch starts
 # with the table and the index arrays partly evicted, the order is the opposite (KGAT_FOLD_TILE_COST
 # A/B of bench.py on one box: (64,38,1051) 142.5-144.0 us, (64,30,1051) 145.2-146.4, (64,30,800)
@@ -264,11 +264,12 @@ FOLD_TILE_CAP32 = 512   # 32-group tiles (d = 64): the same positions per head g
 # more there.  The step is what counts: the fitted triple stays.
 FOLD_TILE_COST = (64, 38, 1051)
 FOLD_TILE_COST_F32 = (64, 12, 466)
-# d = 128 (att_fold_fused128_kernel): a tile's two products are ~4.5 x the d = 64 tile's, a later chunk
-# moves twice the bytes, a relation change cuts four times the matrix.  Scanned on the amazon-book-shaped
-# CKG (scripts/micro/att_variants_ab.py): (64,20,600) 0.440 ms, (64,12,700) 0.421, (64,12,1200) 0.430,
-# (64,8,900) 0.450, (64,6,400) 0.466.
-FOLD_TILE_COST_128 = (64, 12, 700)
+# d = 128 (att_fold_fused128_kernel): scanned inside the step on the amazon-book-shaped CKG
+# (scripts/micro/att128_cost_scan.sh).  With round 5's products (two fp16 pieces per operand, three piece products:
+# half the MFMAs of rounds 3-4) a later chunk weighs more against a tile's products than it did: (64,12,700) - round
+# 3's choice - 0.385 ms, (64,18,700) 0.352, (64,24,700) 0.350, (64,32,700) 0.361, (64,24,400) 0.355, (64,24,1200) 0.351,
+# (64,40,1000) 0.376.
+FOLD_TILE_COST_128 = (64, 24, 700)
 
 
 FOLD_TILE_COST32 = (110, 38, 1051)   # 32-group tiles: a tile's MFMA phase serves twice the groups (round 5)

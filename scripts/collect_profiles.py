@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: copy the summaries of a scripts/round_runs.sh (or bench_lines.sh) output directory into
-profiles/r03_* (bench lines reduced to their JSON line, the rocprofv3 kernel-stats CSV, PMC traffic records,
+"""Developer tool: copy the summaries of a scripts/round5_runs.sh (or bench_lines.sh) output directory into
+profiles/<prefix>* (bench lines reduced to their JSON line, the rocprofv3 kernel-stats CSV, PMC traffic records,
 the text records of the experiments).
 
   python scripts/collect_profiles.py gpurun_out/r03_final [--prefix r03_]
