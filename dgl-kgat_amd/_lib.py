@@ -61,6 +61,8 @@ SIGNATURES = {
     "kgat_att_pack_records": (_i32, [_i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "kgat_att_score_fused_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
                                         _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "kgat_att_score_fused_timed_f32": (_i32, [_i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
+                                              _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "kgat_edge_softmax_workspace_bytes": (_sz, [_i64, _i64]),
     "kgat_edge_softmax_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "kgat_edge_softmax_3pass_workspace_bytes": (_sz, [_i64]),

@@ -591,13 +591,14 @@ int kgat_att_score_fused_supported(int64_t n_nodes, int d, int k, int n_rel) {
          n_nodes <= (1ll << 28) && (unsigned long long)n_nodes * (unsigned long long)d * 4ull < (1ull << 32);
 }
 
-int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
-                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
-                             const int32_t* pos_g, const int32_t* gptr,
-                             const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
-                             const int32_t* part_tptr, int n_parts,
-                             const float* ent, const float* W_R, const float* rel, float* logits,
-                             float* logits_csr, float* logits_g, int flags, kgat_stream_t stream) {
+static int att_score_fused_run(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                               const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                               const int32_t* pos_g, const int32_t* gptr,
+                               const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                               const int32_t* part_tptr, int n_parts,
+                               const float* ent, const float* W_R, const float* rel, float* logits,
+                               float* logits_csr, float* logits_g, int flags, long long* part_clocks,
+                               kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < INT32_MAX, "att_score_fused: bad size");
   KGAT_CHECK_ARG((flags & ~(KGAT_ATT_F32_PRODUCTS | KGAT_ATT_TILES32)) == 0, "att_score_fused: unknown flag");
   if ((flags & KGAT_ATT_TILES32) && (d != 64 || k != 64 || (flags & KGAT_ATT_F32_PRODUCTS))) {
@@ -634,8 +635,37 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
   a.n_edges = n_edges;
   a.gid = nullptr; a.gptr = gptr; a.g_node = g_node;
   a.rec_g = rec_g; a.logits_g = logits_g;
-  if (flags & KGAT_ATT_TILES32) return launch_att_fold_fused32(a, rel_tptr, tiles);
+  a.part_clocks = part_clocks;
+  if (flags & KGAT_ATT_TILES32) {
+    KGAT_CHECK_ARG(part_clocks == nullptr, "att_score_fused_timed: not with 32-group tiles");
+    return launch_att_fold_fused32(a, rel_tptr, tiles);
+  }
   return launch_att_fold_fused_any(d, a, rel_tptr, tiles);
+}
+
+int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                             const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                             const int32_t* pos_g, const int32_t* gptr,
+                             const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                             const int32_t* part_tptr, int n_parts,
+                             const float* ent, const float* W_R, const float* rel, float* logits,
+                             float* logits_csr, float* logits_g, int flags, kgat_stream_t stream) {
+  return att_score_fused_run(n_nodes, n_edges, d, k, n_rel, rel_ptr, perm, rec_g, pos_g, gptr, g_node, tiles, rel_tptr,
+                             part_tptr, n_parts, ent, W_R, rel, logits, logits_csr, logits_g, flags, nullptr, stream);
+}
+
+int kgat_att_score_fused_timed_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                                   const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                                   const int32_t* pos_g, const int32_t* gptr,
+                                   const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                                   const int32_t* part_tptr, int n_parts,
+                                   const float* ent, const float* W_R, const float* rel, float* logits,
+                                   float* logits_csr, float* logits_g, int flags, long long* part_clocks,
+                                   kgat_stream_t stream) {
+  KGAT_CHECK_ARG(part_clocks != nullptr && part_tptr != nullptr && n_parts > 0,
+                 "att_score_fused_timed: needs part_tptr and 2 * n_parts clock slots");
+  return att_score_fused_run(n_nodes, n_edges, d, k, n_rel, rel_ptr, perm, rec_g, pos_g, gptr, g_node, tiles, rel_tptr,
+                             part_tptr, n_parts, ent, W_R, rel, logits, logits_csr, logits_g, flags, part_clocks, stream);
 }
 
 }  // extern "C"

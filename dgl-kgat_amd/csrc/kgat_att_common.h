@@ -100,6 +100,7 @@ struct AttArgs {
   const int32_t* rec_g = nullptr;      // fused form: packed (source node | group slot << 28) per grouped position
   float* logits_g = nullptr;           // fused form: logits in grouped order
   bool f32_products = false;           // fused / folded forms: fp32 MFMA products instead of the bf16-piece products
+  long long* part_clocks = nullptr;    // fused form, measurement aid: s_memrealtime at every workgroup's start and end
 };
 
 

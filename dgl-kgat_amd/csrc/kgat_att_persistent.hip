@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(kFusedThreads) void att_fold_fused_kernel(
     const int32_t* __restrict__ rec_g, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ pos_g, const float* __restrict__ ent, const float* __restrict__ W_R,
     const float* __restrict__ rel, float* __restrict__ logits, float* __restrict__ logits_csr,
-    float* __restrict__ logits_g, const int32_t* __restrict__ part_tptr) {
+    float* __restrict__ logits_g, const int32_t* __restrict__ part_tptr, long long* __restrict__ clocks) {
   constexpr bool LOGITS_EID = OUT == 2;
   constexpr int ROW_SHIFT = D_ == 64 ? 8 : (D_ == 32 ? 7 : 6);  // log2 of a row's bytes
   static_assert((D_ * 4) == (1 << ROW_SHIFT), "row bytes");
@@ -1094,6 +1094,8 @@ constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step 
   const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
   const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
+  // measurement aid (kgat_att_score_fused_timed_f32): when this workgroup started and ended, in 100 MHz ticks
+  if (clocks && tid == 0) clocks[2 * part] = (long long)__builtin_amdgcn_s_memrealtime();
 
   int32_t t = t_begin;
   while (t < t_end) {  // workgroup-uniform loop over relation segments
@@ -1428,6 +1430,10 @@ constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step 
 #undef KGAT_FUSED_STEP
     }
     t = seg_end;
+  }
+  if (clocks) {
+    __syncthreads();
+    if (tid == 0) clocks[2 * part + 1] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1825,7 +1831,7 @@ static void launch_att_fold_fused_form(const AttArgs& a, const int32_t* rel_tptr
   const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
   hipLaunchKernelGGL((att_fold_fused_kernel<D_, OUT, X3>), dim3(grid), dim3(kFusedThreads), 0, a.st, a.n_rel,
                      a.n_edges, a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.rec_g,
-                     a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr);
+                     a.perm, a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr, a.part_clocks);
 }
 
 template <int D_, bool X3>
@@ -1878,7 +1884,7 @@ __global__ __launch_bounds__(kFused128Threads) void att_fold_fused128_kernel(
     const int32_t* __restrict__ rec_g, const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_g,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel,
     float* __restrict__ logits, float* __restrict__ logits_csr, float* __restrict__ logits_g,
-    const int32_t* __restrict__ part_tptr) {
+    const int32_t* __restrict__ part_tptr, long long* __restrict__ clocks) {
   constexpr int D_ = 128, K_ = 128, KS = D_ / 4, KT = K_ / 16, NW = kFused128Threads / kWave;
   constexpr int S3 = D_ / 32, ROWB = D_ * 2, IMG = D_ * ROWB;
   constexpr int LPE = 8, VPL = D_ / (4 * LPE);
@@ -1909,6 +1915,7 @@ constexpr int kF128Passes = 2;
   const int32_t t_begin = part_tptr ? part_tptr[part] : (int32_t)((int64_t)n_tiles * part / gridDim.x);
   const int32_t t_end = part_tptr ? part_tptr[part + 1] : (int32_t)((int64_t)n_tiles * (part + 1) / gridDim.x);
   float* vrow = s_v[w];
+  if (clocks && tid == 0) clocks[2 * part] = (long long)__builtin_amdgcn_s_memrealtime();   // (measurement aid)
 
   struct HBuf { float a[KS]; };
   auto load_head = [&](HBuf& f, int32_t row) {
@@ -2185,6 +2192,10 @@ constexpr int kF128Passes = 2;
     }
     t = seg_end;
   }
+  if (clocks) {
+    __syncthreads();
+    if (tid == 0) clocks[2 * part + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // Round 3's wave-role experiments (producer / consumer waves; measured, not adopted - notes in the file)
@@ -2194,7 +2205,7 @@ static void launch_att_fold_fused128_form(const AttArgs& a, const int32_t* rel_t
   const unsigned grid = a.part_tptr ? a.grid : (unsigned)device_cu_count();
   hipLaunchKernelGGL((att_fold_fused128_kernel<OUT>), dim3(grid), dim3(kFused128Threads), 0, a.st, a.n_rel, a.n_edges,
                      a.rel_ptr, rel_tptr, reinterpret_cast<const int4*>(tiles), a.gptr, a.g_node, a.rec_g, a.perm,
-                     a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr);
+                     a.pos_g, a.ent, a.W_R, a.rel, a.logits, a.logits_csr, a.logits_g, a.part_tptr, a.part_clocks);
 }
 
 static int launch_att_fold_fused128(const AttArgs& a, const int32_t* rel_tptr, const int32_t* tiles) {

@@ -337,14 +337,15 @@ def att_pack_records(rel_ptr, gptr, gid, src_g, groups_per_tile=16):
 
 def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W_R, rel,
                     want_csr=True, want_eid=True, part_tptr=None, f32_products=False, rec_g=None, want_grouped=False,
-                    groups_per_tile=16):
+                    groups_per_tile=16, part_clocks=None):
     """Attention logits, fused folded form (kgat_att_score_fused_f32).  The kernel reads one packed
     record per grouped position (`rec_g`, att_pack_records; built here from `src_g` / `gid` when the
     caller does not keep one).  `part_tptr`: the tile range of every workgroup (fold_tiles); None:
     equal tile counts, one workgroup per compute unit.  `f32_products`: the two products on the fp32
     MFMA (KGAT_ATT_F32_PRODUCTS) instead of the three-bf16-piece products the kernel takes by
-    default when d % 32 == 0.  Returns (logits edge-id order, logits CSR order) - unrequested ones
-    None - and, with want_grouped, a third item: the logits in grouped order."""
+    default when d % 32 == 0.  `part_clocks` (int64, 2 x n_parts): measurement aid
+    (kgat_att_score_fused_timed_f32) - every workgroup's start / end time in 100 MHz ticks.  Returns (logits edge-id
+    order, logits CSR order) - unrequested ones None - and, with want_grouped, a third item: the logits in grouped order."""
     ent = _need(ent, torch.float32, "ent")
     n_rel, d, k = W_R.shape
     W_R = _need(W_R, torch.float32, "W_R")
@@ -369,14 +370,17 @@ def att_score_fused(n_nodes, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, til
     logits = torch.empty(e, dtype=torch.float32, device=ent.device) if want_eid else None
     logits_csr = torch.empty(e, dtype=torch.float32, device=ent.device) if want_csr else None
     logits_g = torch.empty(e, dtype=torch.float32, device=ent.device) if want_grouped else None
+    flags = (ATT_F32_PRODUCTS if f32_products else 0) | (ATT_TILES32 if groups_per_tile == 32 else 0)
+    args = (n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm) if want_eid else None, _ptr(rec_g),
+            _ptr(pos_g) if want_csr else None, _ptr(gptr), _ptr(g_node), _ptr(tiles), _ptr(rel_tptr), _ptr(part_tptr), n_parts,
+            _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits), _ptr(logits_csr), _ptr(logits_g), flags)
     with _timed("att_score", (e, d, k)):
-        check(_lib.load().kgat_att_score_fused_f32(n_nodes, e, d, k, n_rel, _ptr(rel_ptr), _ptr(perm) if want_eid else None,
-                                                   _ptr(rec_g), _ptr(pos_g) if want_csr else None, _ptr(gptr),
-                                                   _ptr(g_node), _ptr(tiles), _ptr(rel_tptr), _ptr(part_tptr), n_parts,
-                                                   _ptr(ent), _ptr(W_R), _ptr(rel), _ptr(logits), _ptr(logits_csr),
-                                                   _ptr(logits_g), (ATT_F32_PRODUCTS if f32_products else 0) |
-                                                   (ATT_TILES32 if groups_per_tile == 32 else 0), _stream(ent)),
-              "kgat_att_score_fused_f32")
+        if part_clocks is None:
+            check(_lib.load().kgat_att_score_fused_f32(*args, _stream(ent)), "kgat_att_score_fused_f32")
+        else:
+            part_clocks = _need(part_clocks, torch.int64, "part_clocks", (2 * n_parts,))
+            check(_lib.load().kgat_att_score_fused_timed_f32(*args, _ptr(part_clocks), _stream(ent)),
+                  "kgat_att_score_fused_timed_f32")
     return (logits, logits_csr, logits_g) if want_grouped else (logits, logits_csr)
 
 

@@ -231,6 +231,20 @@ int kgat_att_score_fused_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int
                              const int32_t* part_tptr, int n_parts,
                              const float* ent, const float* W_R, const float* rel, float* logits,
                              float* logits_csr, float* logits_g, int flags, kgat_stream_t stream);
+/* Measurement aid: the same launch with every workgroup's start and end time written to part_clocks[2 b], [2 b + 1]
+ * (100 MHz ticks of s_memrealtime; part b = workgroup b's tile range).  Same results; needs part_tptr; not with
+ * KGAT_ATT_TILES32.  (What it showed, scripts/micro/att_rebalance_probe.py: the cost model of kgat_fold_tile_parts
+ * leaves the workgroups' end times 8-9 % apart and the pattern repeats - correlation 0.98 run to run -, so ranges
+ * re-cut from measured times take 7-9 % off the launch where the calibration and the use share their surroundings;
+ * calibrated on the caller's first launches inside the benchmark step the gain was 1.5 %: not adopted.) */
+int kgat_att_score_fused_timed_f32(int64_t n_nodes, int64_t n_edges, int d, int k, int n_rel,
+                                   const int32_t* rel_ptr, const int32_t* perm, const int32_t* rec_g,
+                                   const int32_t* pos_g, const int32_t* gptr,
+                                   const int32_t* g_node, const int32_t* tiles, const int32_t* rel_tptr,
+                                   const int32_t* part_tptr, int n_parts,
+                                   const float* ent, const float* W_R, const float* rel, float* logits,
+                                   float* logits_csr, float* logits_g, int flags, long long* part_clocks,
+                                   kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- edge softmax (A3)
  * Replaces dgl.nn.pytorch.softmax.edge_softmax (call site reference models.py:153):
