@@ -781,6 +781,35 @@ def test_att_fused_product_forms(K, dev, d):
             assert e_new <= 1.0 * e_f32 + 1e-7 * scale and bias <= max(2.0 * bias32, 3e-8), (case, e_new, e_f32, bias)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_att_fused_timed_entry(K, dev, d):
+    """kgat_att_score_fused_timed_f32 (measurement aid): the bits of the plain launch, and for every workgroup with a
+    tile range a start tick before its end tick inside one launch-long window."""
+    from dgl_kgat_amd import ops
+    rng = np.random.default_rng(5 + d)
+    n, e, R = 2000, 50000, 6
+    src, dst = random_graph(77, n, e, hub=2500, isolated_tail=5)
+    et = rng.integers(0, R, e).astype(np.int32)
+    rel_ptr, perm, src_g, dst_g, pos_g = _grouped_by_relation_and_destination(ops, n, src, dst, et, R, dev)
+    gid, gptr, g_node, n_groups = ops.head_groups(rel_ptr, dst_g)
+    tiles, rel_tptr, part_tptr = ops.fold_tiles(rel_ptr, gid, gptr, n_groups, n_parts=37, cost=ops.fold_tile_cost(d))
+    ent = tf(rng.standard_normal((n, d)).astype(np.float32), dev)
+    W = tf(((rng.random((R, d, d)) - 0.5) * (2.0 / np.sqrt(d))).astype(np.float32), dev)
+    rel = tf(rng.standard_normal((R, d)).astype(np.float32), dev)
+    plain = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W, rel,
+                                part_tptr=part_tptr)
+    clocks = torch.zeros(2 * 37, dtype=torch.int64, device=dev)
+    timed = ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W, rel,
+                                part_tptr=part_tptr, part_clocks=clocks)
+    assert torch.equal(plain[0], timed[0]) and torch.equal(plain[1], timed[1])
+    c = clocks.cpu().numpy().reshape(-1, 2)
+    assert (c[:, 0] > 0).all() and (c[:, 1] >= c[:, 0]).all()
+    assert c[:, 1].max() - c[:, 0].min() < 100 * 1000 * 50      # all inside 50 ms of 100 MHz ticks
+    with pytest.raises(Exception):
+        ops.att_score_fused(n, rel_ptr, perm, src_g, pos_g, gid, gptr, g_node, tiles, rel_tptr, ent, W, rel,
+                            part_tptr=None, part_clocks=clocks)
+
+
 def test_att_folded_d128(K, dev):
     """d = k = 128: W_r (64 KB) lives in LDS, 32 floats per lane in the per-edge dot."""
     from dgl_kgat_amd import ops
