@@ -3,12 +3,14 @@
 // (gathers, batched dot products, logsigmoid, three regularisers, an index_put with a device sort): 75 launches of
 // a few microseconds each, 0.7 ms of the 1.6 ms CF step, all of it launch latency.  Here:
 //   forward   bpr_sample_kernel (one wavefront per sample: the three rows, five dot products) + bpr_reduce_kernel
-//   backward  stable sort of the 3B row ids + zero fill of the dense gradient, ONE launch (bpr_sort_zero_kernel: up
-//             to 32,768 ids are sorted by one workgroup with the keys in registers, 32 per lane, while the other
-//             workgroups clear the N x F gradient; larger batches: the device radix sort of kgat_graph.hip + a
-//             memset) + bpr_scatter_kernel (one wavefront per distinct row sums that row's contributions in sample
-//             order: fixed order of additions, no float atomics, bitwise reproducible), scaled by the incoming
-//             gradient read from device memory (no host synchronisation, no separate multiply pass)
+//   backward  four launches of bounded work: bpr_sort_zero_kernel (slices of 4,096 row ids sorted in LDS beside the
+//             zero fill of the N x F gradient) + bpr_merge_kernel (every id's place among all ids: a stable merge by
+//             binary searches; up to 65,536 ids - beyond: the device radix sort of kgat_graph.hip + a memset) +
+//             bpr_window_kernel (a wavefront per 32 sorted positions adds their contributions in order; rows inside
+//             the window are written, pieces of rows that cross its edges left as partials) + bpr_carry_kernel (the
+//             crossing rows' pieces in window order): fixed order of additions, no float atomics, bitwise
+//             reproducible; scaled by the incoming gradient read from device memory (no host synchronisation, no
+//             separate multiply pass)
 //   loss = -mean_b logsigmoid(<s,p> - <s,n>) + lambda (mean_b |s|^2/2 + mean_b |p|^2/2 + mean_b |n|^2/2)
 #include "kgat_common.h"
 
