@@ -35,9 +35,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- one-workgroup stable sort of n <= 8192 keys (< 2^19), payload = position in the input,
-// packed as key << 13 | position.  LSD radix sort, 8-bit digits, both buffers and the counters in
-// LDS: each of the 16 wavefronts owns a contiguous slice of the current order and its own column
-// of the 256 x 16 counter table, counts its digits (LDS atomics - counts do not depend on order),
+// packed as key << 13 | position.  LSD radix sort, 9-bit digits (8 with the 64-bit packing), both buffers and the
+// counters in LDS: each of the 16 wavefronts owns a contiguous slice of the current order and its own column
+// of the 512 x 16 counter table, counts its digits (LDS atomics - counts do not depend on order),
 // a block scan turns the table into offsets in (digit, wavefront) order, and the wavefront walks
 // its slice 64 keys at a time ranking equal digits by lane with ballots - so equal keys keep
 // their order.  Also emits, for keys in [0, n_keys], offsets[v] = first sorted position whose key
@@ -70,8 +70,12 @@ __device__ __forceinline__ void small_sort_body(const SortJob& job) {
   int32_t* __restrict__ offsets = job.offsets;
   int32_t* __restrict__ chunk_ptr = job.chunk_ptr;
   int2* __restrict__ chunks = job.chunks;
+  // digits of 9 bits with the 32-bit packing (eighteen-bit entity ids: two passes instead of three), 8 with the
+  // 64-bit one (its buffers leave 32 KB of LDS: 256 x 16 counters)
+  constexpr int DB = sizeof(PT) == 4 ? 9 : 8;
+  constexpr int NDIG = 1 << DB, CPT = NDIG * kSsWaves / 1024;   // counters per thread in the scan
   __shared__ PT s_buf[2][kTrSmallSort];
-  __shared__ int32_t s_cnt[256 * kSsWaves];
+  __shared__ int32_t s_cnt[NDIG * kSsWaves];
   __shared__ int32_t s_wsum[kSsWaves];
   const int tid = threadIdx.x, lane = tid % kWave, w = tid / kWave;
   for (int32_t i = tid; i < n; i += 1024) {
@@ -88,18 +92,18 @@ __device__ __forceinline__ void small_sort_body(const SortJob& job) {
   const int32_t lo = w * slice, hi = lo + slice < n ? lo + slice : n;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   int cur = 0;
-  const int passes = (key_bits + 7) / 8 > 0 ? (key_bits + 7) / 8 : 1;
+  const int passes = (key_bits + DB - 1) / DB > 0 ? (key_bits + DB - 1) / DB : 1;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = 13 + 8 * pass;
-    for (int i = tid; i < 256 * kSsWaves; i += 1024) s_cnt[i] = 0;
+    const int shift = 13 + DB * pass;
+    for (int i = tid; i < NDIG * kSsWaves; i += 1024) s_cnt[i] = 0;
     __syncthreads();
-    for (int32_t i = lo + lane; i < hi; i += kWave) atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & 255u) * kSsWaves + w], 1);
+    for (int32_t i = lo + lane; i < hi; i += kWave) atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & (PT)(NDIG - 1)) * kSsWaves + w], 1);
     __syncthreads();
-    {  // exclusive scan of the 4096 counters, 4 per thread
-      int32_t c[4];
+    {  // exclusive scan of the counters in (digit, wavefront) order, CPT per thread
+      int32_t c[CPT];
+      int32_t mine = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] = s_cnt[4 * tid + q];
-      const int32_t mine = c[0] + c[1] + c[2] + c[3];
+      for (int q = 0; q < CPT; ++q) { c[q] = s_cnt[CPT * tid + q]; mine += c[q]; }
       int32_t inc = mine;
 #pragma unroll
       for (int d = 1; d < kWave; d <<= 1) {
@@ -111,8 +115,8 @@ __device__ __forceinline__ void small_sort_body(const SortJob& job) {
       int32_t base = inc - mine;
       for (int q = 0; q < w; ++q) base += s_wsum[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s_cnt[4 * tid + q] = base;
+      for (int q = 0; q < CPT; ++q) {
+        s_cnt[CPT * tid + q] = base;
         base += c[q];
       }
     }
@@ -121,10 +125,10 @@ __device__ __forceinline__ void small_sort_body(const SortJob& job) {
       const int32_t i = i0 + lane;
       const bool valid = i < hi;
       const PT v = valid ? s_buf[cur][i] : (PT)0;
-      const uint32_t dgt = (uint32_t)((v >> shift) & 255u);
+      const uint32_t dgt = (uint32_t)((v >> shift) & (PT)(NDIG - 1));
       uint64_t peers = __ballot(valid);
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
+      for (int bit = 0; bit < DB; ++bit) {
         const bool on = (dgt >> bit) & 1u;
         const uint64_t bal = __ballot(on);
         peers &= on ? bal : ~bal;
