@@ -9,69 +9,88 @@ scores come out of the fp32 MFMA tile by tile and go straight into a running top
 no (users x items) score matrix, no sort of 24,915 scores per user.  Equal scores rank by item
 position (what the reference's stable CPU ``th.sort`` gives: among the masked zeros the lower
 index first).  ``calc_recall_ndcg_sorted`` is the batched matmul + full stable sort of rounds
-1-4, kept as an independent check of the kernel (tests) and for K > 32.
+1-4, kept as an independent check of the kernel (tests); nothing dispatches to it.
 """
 import numpy as np
 import torch
 
 
+_EMPTY = np.zeros(0, dtype=np.int64)
+
+
 class EvalPlan:
     """The static part of an evaluation: test users, item node ids and the users' train / test item lists as CSR
-    arrays on the device (positions ascending per user).  Build once per (train, test) split."""
+    arrays on the device (positions ascending per user).  Build once per (train, test) split and pass it as
+    ``plan=``; the dicts are read when the plan is built, never again.
+
+    Train lists are de-duplicated (the reference masks ``score[train_items] = 0.0`` - an item listed twice is masked
+    once, ``metric.py:50``); test lists keep their duplicates (``len(pos_item_l)`` counts them, ``metric.py:24``).
+    Built with array operations over the concatenated lists: one dict lookup per user is the only per-user Python
+    step (70,679 users x 2 dicts: ~0.1 s; the per-user ``np.sort`` loops of round 5 took seconds)."""
 
     def __init__(self, train_user_dict, test_user_dict, all_item_id_range, device):
         users = list(test_user_dict.keys())
         self.n_users = len(users)
-
-        def csr(d):
-            lists = [np.sort(np.asarray(d.get(u, ()), dtype=np.int64)) for u in users]
-            ptr = np.zeros(len(users) + 1, dtype=np.int64)
-            if lists:
-                np.cumsum([len(x) for x in lists], out=ptr[1:])
-            flat = np.concatenate(lists) if lists and ptr[-1] > 0 else np.zeros(0, dtype=np.int64)
-            if ptr[-1] >= 2 ** 31:
-                raise ValueError("more than 2^31 (user, item) pairs")
-            return (torch.as_tensor(ptr.astype(np.int32), device=device),
-                    torch.as_tensor(flat.astype(np.int32), device=device))
-
-        items = np.asarray(all_item_id_range, dtype=np.int64)
+        items = np.asarray(all_item_id_range, dtype=np.int64).reshape(-1)
         self.n_items = len(items)
-        for name, d in (("train", train_user_dict), ("test", test_user_dict)):
-            for u in users:
-                x = np.asarray(d.get(u, ()), dtype=np.int64)
-                if x.size and (x.min() < 0 or x.max() >= self.n_items):
-                    # (the reference would index `score` out of range, metric.py:50)
-                    raise IndexError("%s items of user %r outside [0, %d)" % (name, u, self.n_items))
-        self.user_ids = torch.as_tensor(np.asarray(users, dtype=np.int64).astype(np.int32), device=device)
+        n_items = max(self.n_items, 1)
+
+        def csr(d, name, unique):
+            lists = [d.get(u, _EMPTY) for u in users]
+            lens = np.fromiter((len(x) for x in lists), dtype=np.int64, count=len(lists))
+            total = int(lens.sum())
+            if total >= 2 ** 31:
+                raise ValueError("more than 2^31 (user, item) pairs")
+            if total == 0:
+                return (torch.zeros(len(users) + 1, dtype=torch.int32, device=device),
+                        torch.zeros(0, dtype=torch.int32, device=device))
+            flat = np.concatenate([np.asarray(x).reshape(-1) for x in lists if len(x)]).astype(np.int64, copy=False)
+            owner = np.repeat(np.arange(len(users), dtype=np.int64), lens)
+            bad = (flat < 0) | (flat >= self.n_items)
+            if bad.any():
+                # (the reference would index `score` out of range, metric.py:50)
+                raise IndexError("%s items of user %r outside [0, %d)" % (name, users[int(owner[np.argmax(bad)])],
+                                                                          self.n_items))
+            key = owner * n_items + flat                  # one sort orders users and, within a user, positions
+            key = np.unique(key) if unique else np.sort(key)
+            owner = key // n_items
+            ptr = np.zeros(len(users) + 1, dtype=np.int64)
+            np.cumsum(np.bincount(owner, minlength=len(users)), out=ptr[1:])
+            return (torch.as_tensor(ptr.astype(np.int32), device=device),
+                    torch.as_tensor((key - owner * n_items).astype(np.int32), device=device))
+
+        u = np.asarray(users, dtype=np.int64).reshape(-1)
+        if u.size and (u.min() < 0 or u.max() >= 2 ** 31 or (items.size and (items.min() < 0 or items.max() >= 2 ** 31))):
+            raise IndexError("user / item node ids must lie in [0, 2^31)")
+        self.max_node_id = int(max(u.max() if u.size else -1, items.max() if items.size else -1))
+        self.user_ids = torch.as_tensor(u.astype(np.int32), device=device)
         self.item_ids = torch.as_tensor(items.astype(np.int32), device=device)
-        self.train_ptr, self.train_items = csr(train_user_dict)
-        self.test_ptr, self.test_items = csr(test_user_dict)
-        self.key = (id(train_user_dict), id(test_user_dict), len(train_user_dict), len(test_user_dict),
-                    self.n_items, str(device))
-
-
-_last_plan = None
-
-
-def _plan_for(train_user_dict, test_user_dict, all_item_id_range, device):
-    global _last_plan
-    key = (id(train_user_dict), id(test_user_dict), len(train_user_dict), len(test_user_dict),
-           len(all_item_id_range), str(device))
-    if _last_plan is None or _last_plan.key != key:
-        _last_plan = EvalPlan(train_user_dict, test_user_dict, all_item_id_range, device)
-    return _last_plan
+        self.train_ptr, self.train_items = csr(train_user_dict, "train", True)
+        self.test_ptr, self.test_items = csr(test_user_dict, "test", False)
 
 
 def calc_recall_ndcg(embedding, train_user_dict, test_user_dict, all_item_id_range, K=20, plan=None,
                      return_per_user=False):
     """``embedding`` (N, F) node embeddings on the HIP device; the dicts map a user id to the array of its (raw,
-    un-shifted) item ids; ``all_item_id_range`` the node ids of the items.  ``plan``: a prebuilt ``EvalPlan`` (the
-    last one built is reused while the same dict objects are passed)."""
+    un-shifted) item ids; ``all_item_id_range`` the node ids of the items.  As the reference does
+    (``metric.py:36-68``), the dicts are read on EVERY call - nothing is cached between calls; a caller that
+    evaluates the same split repeatedly builds an ``EvalPlan`` once and passes it as ``plan=`` (the dicts are then
+    ignored).
+
+    Restrictions (no CPU / PyTorch fallback, by design): ``embedding`` must live on the HIP device
+    (``KGATLibraryError`` otherwise), K <= 32; a float64 embedding is ranked in float32 - the kernel's
+    arithmetic, and what the reference's fp32 model produces - so near-ties of a float64 input can rank
+    differently than a float64 sort would rank them.  ``calc_recall_ndcg_sorted`` (torch operators) takes any K,
+    dtype and device."""
     from . import ops
     if plan is None:
-        plan = _plan_for(train_user_dict, test_user_dict, all_item_id_range, embedding.device)
+        plan = EvalPlan(train_user_dict, test_user_dict, all_item_id_range, embedding.device)
     if plan.n_users == 0:
         raise ZeroDivisionError("no test users")   # (metric.py:65 divides by len(test_user_dict))
+    if plan.max_node_id >= embedding.shape[0]:
+        # (the reference's embedding[user_id] / embedding[all_item_id_range] raises IndexError, metric.py:44-46)
+        raise IndexError("user / item node id %d outside the embedding's %d rows" % (plan.max_node_id,
+                                                                                    embedding.shape[0]))
     emb = embedding.detach()
     if emb.dtype != torch.float32:
         emb = emb.float()

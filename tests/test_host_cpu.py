@@ -672,3 +672,34 @@ def test_accelerated_attention_uses_node_ids_and_deep_stacks_fall_back():
     src = inspect.getsource(kgat_layer.KGATPropagation.compute_attention)
     assert "_node_embeddings(g)" in src
     assert "len(blocks) <= 8" in inspect.getsource(kgat_layer.KGATPropagation._gnn_fused_sharded)
+
+
+def test_eval_plan_matches_per_user_construction():
+    """metrics.EvalPlan's array construction against the per-user definition (reference metric.py:36-68 reads
+    train_user_dict[u] / test_user_dict[u] per user): users in the test dict's key order, train lists sorted and
+    de-duplicated (score[train] = 0.0 masks an item once), test lists sorted with their duplicates (len() counts them),
+    users without a train list, empty lists, out-of-range items -> IndexError, and no state kept between calls."""
+    import torch
+    from dgl_kgat_amd import metrics
+    rng = np.random.default_rng(3)
+    n_i = 50
+    users = [7, 3, 11, 0, 5]
+    test = {u: rng.integers(0, n_i, rng.integers(0, 6)) for u in users}
+    train = {u: rng.integers(0, n_i, rng.integers(0, 30)) for u in users if u != 11}
+    train[99] = np.array([1, 2])                                      # a train-only user is ignored
+    test[3] = np.array([4, 4, 9])
+    plan = metrics.EvalPlan(train, test, np.arange(100, 100 + n_i), torch.device("cpu"))
+    assert plan.user_ids.tolist() == users and plan.item_ids.tolist() == list(range(100, 150))
+    for k, u in enumerate(users):
+        tr = plan.train_items[plan.train_ptr[k]:plan.train_ptr[k + 1]].numpy()
+        te = plan.test_items[plan.test_ptr[k]:plan.test_ptr[k + 1]].numpy()
+        assert np.array_equal(tr, np.unique(train.get(u, np.zeros(0, np.int64))))
+        assert np.array_equal(te, np.sort(test[u]))
+    assert plan.max_node_id == 149
+    with pytest.raises(IndexError):
+        metrics.EvalPlan({7: np.array([n_i])}, test, np.arange(100, 100 + n_i), torch.device("cpu"))
+    # the same dict object edited in place gives a different plan (round 5 cached on id() + len(): ADVICE round 5)
+    test[3][:] = [1, 2, 3]
+    plan2 = metrics.EvalPlan(train, test, np.arange(100, 100 + n_i), torch.device("cpu"))
+    assert plan2.test_items[plan2.test_ptr[1]:plan2.test_ptr[2]].tolist() == [1, 2, 3]
+    assert not hasattr(metrics, "_last_plan")
