@@ -108,6 +108,12 @@ SIGNATURES = {
     "kgat_bpr_workspace_bytes": (_sz, [_i64, _i32]),
     "kgat_bpr_loss_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
     "kgat_bpr_grad_f32": (_i32, [_i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, C.c_float, _p, _p, _p, _sz, _p]),
+    "kgat_transr_sorted_bytes": (_sz, [_i64, _i32]),
+    "kgat_transr_presort_f32": (_i32, [_i64, _i32, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "kgat_transr_step_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "kgat_transr_adam_step_f32": (_i32, [_i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, _p, _p, C.c_uint64,
+                                         _p, _sz, _p]),
     "kgat_adam_max_tensors": (_i32, []),
     "kgat_adam_step_f32": (_i32, [_i32, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _p]),
     "kgat_eval_recall_ndcg_f32": (_i32, [_i64, _p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _sz, _p,
@@ -130,7 +136,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_DIR = os.path.join(_HERE, "build")
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def source_hash():

@@ -10,7 +10,7 @@
 //   v  <- v beta2 + (1 - beta2) g g                  (mul_, addcmul_)
 //   p  <- p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
 // with the step-dependent scalars formed in double on the host exactly as torch forms them.
-#include "kgat_common.h"
+#include "kgat_adam_common.h"
 
 namespace kgat {
 
@@ -28,23 +28,6 @@ struct AdamArgs {
   float bc2_sqrt[kAdamMaxTensors];    // sqrt(1 - beta2^t)
   int count;
 };
-
-// One element, rounding where torch's multi-tensor Adam rounds (each _foreach_* call is a kernel of its own, so its
-// result is rounded to fp32 before the next one reads it; inside lerp / addcmul / addcdiv the compiler contracts
-// `a + s * x` into one fma): contraction is switched off here and the fmas are written out.
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float w1, float beta2, float w2,
-                                         float step_size, float bc2_sqrt, float eps) {
-#pragma clang fp contract(off)
-  m = fmaf(w1, g - m, m);             // _foreach_lerp_(exp_avg, grad, 1 - beta1): self + weight * (end - self)
-  const float t = v * beta2;          // _foreach_mul_(exp_avg_sq, beta2)
-  const float gg = g * g;
-  v = fmaf(w2, gg, t);                // _foreach_addcmul_(exp_avg_sq, grad, grad, 1 - beta2)
-  float d = sqrtf(v);                 // _foreach_sqrt
-  d = d / bc2_sqrt;                   // _foreach_div_(.., sqrt(1 - beta2^t))
-  d = d + eps;                        // _foreach_add_(.., eps)
-  const float q = m / d;
-  p = fmaf(-step_size, q, p);         // _foreach_addcdiv_(param, exp_avg, denom, -lr / (1 - beta1^t))
-}
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, float w1, float beta2, float w2, float eps,
                                                    int zero_grads) {

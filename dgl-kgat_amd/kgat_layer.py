@@ -336,7 +336,9 @@ class KGATPropagation(nn.Module):
         dense gradients into buffers kept with the model, they become the parameters' ``.grad``, ``optimizer.step()``
         runs (any torch optimiser; FusedAdam makes the whole iteration two library calls), the gradients are dropped.
         The same kernels on the same data as ``transR(...).backward()``: the same bits.  int32 index tensors are used
-        as they are.  Returns the loss (a 0-dim device tensor; reading it synchronises, as loss.item() does)."""
+        as they are.  Returns the loss (a 0-dim device tensor; reading it synchronises, as loss.item() does).
+        NOTE: like the reference's step - which ends in optimizer.zero_grad() - this leaves EVERY parameter's ``.grad``
+        None, including gradients another phase accumulated and has not applied yet: call it between complete steps."""
         from . import ops
         ent, W_R, rel = self.entity_embed.weight, self.W_R, self.relation_embed.weight
         if not (ent.is_cuda and ent.dtype == torch.float32 and ops_transr_supported(self, h)):
@@ -364,6 +366,55 @@ class KGATPropagation(nn.Module):
         optimizer.step()
         ent.grad = W_R.grad = rel.grad = None
         return out[0]
+
+    def kg_phase(self, h, r, pos_t, neg_t, optimizer, reg_lambda_kg=0.01):
+        """The KG phase of an epoch (reference kgat.py:116-136) over batches drawn up front: h, r, pos_t, neg_t are
+        (n_iterations, batch) id tensors; iteration i is transR(h[i], ...) -> backward -> optimizer.step -> zero_grad.
+        Returns the n_iterations losses as a device tensor (no host round trip per iteration; the reference reads
+        loss.item() every step).
+
+        With ``FusedAdam`` on the GPU: one launch sorts every batch (kgat_transr_presort_f32), then an iteration is ONE
+        library call of three launches (kgat_transr_adam_step_f32: per-sample kernel, weight-gradient partials +
+        gradient rows + loss, Adam on ent / W_R / rel without a dense gradient) - the bits of ``kg_step`` and of the
+        reference's autograd + torch.optim.Adam sequence.  Any other optimiser / size: a loop over ``kg_step``.
+        As in ``kg_step``, parameters the KG loss does not reach get no update and their ``.grad`` is left alone."""
+        from . import ops
+        from .optim import FusedAdam
+        ent, W_R, rel = self.entity_embed.weight, self.W_R, self.relation_embed.weight
+        if h.dim() != 2 or r.shape != h.shape or pos_t.shape != h.shape or neg_t.shape != h.shape:
+            raise ValueError("kg_phase: h, r, pos_t, neg_t must share one (n_iterations, batch) shape")
+        n_it, b = h.shape
+        hyper = optimizer.kg_state((ent, W_R, rel)) if isinstance(optimizer, FusedAdam) else None
+        fused = (hyper is not None and n_it > 0 and ent.is_cuda and ent.dtype == torch.float32 and
+                 ops.transr_supported(ent.shape[0], W_R.shape[1], W_R.shape[2], W_R.shape[0], b) and
+                 all(t.data_ptr() % 16 == 0 for t in (ent, W_R, rel)))
+        if not fused:
+            if n_it == 0:
+                return torch.zeros(0, dtype=torch.float32, device=ent.device)
+            # (kg_step hands back its persistent loss buffer: copy it before the next iteration overwrites it)
+            return torch.stack([self.kg_step(h[i], r[i], pos_t[i], neg_t[i], optimizer, reg_lambda_kg).clone() for i in range(n_it)])
+        import ctypes as C
+        ids = [t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous() for t in (h, r, pos_t, neg_t)]
+        st = getattr(self, "_kg_phase_state", None)
+        key = (ent.shape[0], W_R.shape[1], W_R.shape[2], W_R.shape[0], b, str(ent.device))
+        if st is None or st.key != key:
+            st = self._kg_phase_state = ops.TransRAdamState(*key[:5], ent.device)
+        losses = torch.empty(n_it, dtype=torch.float32, device=ent.device)
+        with torch.no_grad():
+            sorted_all, stride = ops.transr_presort(*ids, ent.shape[0], W_R.shape[0])
+            states = [optimizer.state[p] for p in (ent, W_R, rel)]
+            arr_m = (C.c_void_p * 3)(*[s_["exp_avg"].data_ptr() for s_ in states])
+            arr_v = (C.c_void_p * 3)(*[s_["exp_avg_sq"].data_ptr() for s_ in states])
+            steps = [int(s_["step"]) for s_ in states]
+            e_, w_, r_ = ent.detach(), W_R.detach(), rel.detach()
+            lr, b1, b2, eps = hyper
+            for i in range(n_it):
+                steps = [t + 1 for t in steps]
+                ops.transr_adam_step(ids[0][i], ids[1][i], ids[2][i], ids[3][i], sorted_all[i * stride:(i + 1) * stride],
+                                     e_, w_, r_, arr_m, arr_v, steps, lr, b1, b2, eps, reg_lambda_kg, losses[i:i + 1], st)
+            for s_, t in zip(states, steps):
+                s_["step"].fill_(float(t))
+        return losses
 
     def _gnn_fused_sharded(self, g):
         """No-grad path on a destination-range shard: per layer the local aggregation, the

@@ -427,6 +427,56 @@ def transr_loss_grad(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda, want_grad=Tr
     return loss, g_ent, g_w, g_rel
 
 
+def transr_presort(h, r, pos_t, neg_t, n_nodes, n_rel):
+    """The sorts of a whole KG phase's batches in one launch (kgat_transr_presort_f32): h, r, pos_t, neg_t are
+    (n_batches, batch) int32 tensors; returns (sorted, stride) - batch b's block is sorted[b * stride:(b + 1) * stride]."""
+    h = _need(h, torch.int32, "h")
+    if h.dim() != 2:
+        raise ValueError("h must be (n_batches, batch)")
+    for name, t in (("r", r), ("pos_t", pos_t), ("neg_t", neg_t)):
+        _need(t, torch.int32, name, h.shape)
+    lib = _lib.load()
+    nb, b = h.shape
+    stride = int(lib.kgat_transr_sorted_bytes(b, n_rel))
+    out = torch.empty(max(nb * stride, 256), dtype=torch.uint8, device=h.device)
+    with _timed("transr_presort", (nb, b)):
+        check(lib.kgat_transr_presort_f32(int(n_nodes), int(n_rel), nb, b, _ptr(h), _ptr(r), _ptr(pos_t), _ptr(neg_t),
+                                          _ptr(out), out.numel(), _stream(h)), "kgat_transr_presort_f32")
+    return out, stride
+
+
+class TransRAdamState:
+    """What a sequence of kgat_transr_adam_step_f32 calls keeps between calls: the step workspace, the row_slot words
+    (zero once, never cleared: a word is valid for the call whose tag it carries) and the tag counter."""
+
+    def __init__(self, n_nodes, d, k, n_rel, batch, device):
+        lib = _lib.load()
+        self.key = (int(n_nodes), int(d), int(k), int(n_rel), int(batch), str(device))
+        self.workspace = _workspace(lib.kgat_transr_step_workspace_bytes(batch, d, k, n_rel), device)
+        self.row_slot = torch.zeros(int(n_nodes), dtype=torch.int64, device=device)
+        self.tag = 0
+
+
+def transr_adam_step(h, r, pos_t, neg_t, sorted_block, ent, W_R, rel, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps,
+                     reg_lambda, loss_out, state):
+    """One KG iteration (kgat_transr_adam_step_f32): TransR loss of the batch into `loss_out` (a 1-element fp32 view)
+    and the Adam step on ent / W_R / rel in place.  exp_avg / exp_avg_sq: ctypes arrays of the three moment pointers
+    (built once per phase by the caller); steps: the three step counts after this step.  Shapes and dtypes are the
+    caller's responsibility here (KGATPropagation.kg_phase validates them once per phase): this is the per-iteration
+    call of a 1,641-iteration loop."""
+    import ctypes as C
+    n_rel, d, k = W_R.shape
+    state.tag += 1
+    arr_t = (C.c_int64 * 3)(*steps)
+    check(_lib.load().kgat_transr_adam_step_f32(ent.shape[0], n_rel, d, k, h.numel(), h.data_ptr(), r.data_ptr(),
+                                                pos_t.data_ptr(), neg_t.data_ptr(), sorted_block.data_ptr(), ent.data_ptr(),
+                                                W_R.data_ptr(), rel.data_ptr(), exp_avg, exp_avg_sq, arr_t, float(lr),
+                                                float(beta1), float(beta2), float(eps), float(reg_lambda),
+                                                loss_out.data_ptr(), state.row_slot.data_ptr(), state.tag,
+                                                state.workspace.data_ptr(), state.workspace.numel(), _stream(ent)),
+          "kgat_transr_adam_step_f32")
+
+
 def transr_forward(h, r, pos_t, neg_t, ent, W_R, rel, reg_lambda):
     """TransR loss with the per-sample rows left in the returned workspace for transr_backward
     (kgat_transr_forward_f32)."""
@@ -853,7 +903,7 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "transr_presort", "transr_adam_step", "TransRAdamState", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]
 

@@ -43,8 +43,12 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            for lo in range(0, len(ps), cap):
-                chunk = ps[lo:lo + cap]
+            # one launch per device and per `cap` tensors (a launch runs on ONE device's current stream: ADVICE round 5)
+            by_dev = {}
+            for p in ps:
+                by_dev.setdefault(p.device, []).append(p)
+            chunks = [(dv, lst[lo:lo + cap]) for dv, lst in by_dev.items() for lo in range(0, len(lst), cap)]
+            for dv, chunk in chunks:
                 n = len(chunk)
                 steps = []
                 for p in chunk:
@@ -59,8 +63,30 @@ class FusedAdam(torch.optim.Optimizer):
                 arr_n = (C.c_int64 * n)(*[p.numel() for p in chunk])
                 arr_t = (C.c_int64 * n)(*steps)
                 zero = self._zero_grads and all(g is p.grad for g, p in zip(grads, chunk))
-                check(lib.kgat_adam_step_f32(n, arr_n, arr_p, arr_g, arr_m, arr_v, arr_t, float(group["lr"]),
-                                             float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
-                                             int(zero), torch.cuda.current_stream(chunk[0].device).cuda_stream),
-                      "kgat_adam_step_f32")
+                with torch.cuda.device(dv):
+                    check(lib.kgat_adam_step_f32(n, arr_n, arr_p, arr_g, arr_m, arr_v, arr_t, float(group["lr"]),
+                                                 float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                                                 int(zero), torch.cuda.current_stream(dv).cuda_stream),
+                          "kgat_adam_step_f32")
         return loss
+
+    def kg_state(self, params):
+        """For KGATPropagation.kg_phase: the Adam state of `params` (created as step() creates it), and the hyper-parameters
+        they share - None when they sit in groups with different hyper-parameters."""
+        hyper = None
+        for p in params:
+            grp = next((g for g in self.param_groups if any(q is p for q in g["params"])), None)
+            if grp is None:
+                return None
+            h = (float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]))
+            if hyper is not None and h != hyper:
+                return None
+            hyper = h
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                return None
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return hyper

@@ -219,7 +219,6 @@ def main(argv=None):
                 rec[name + "_recall"], rec[name + "_ndcg"] = metrics.calc_recall_ndcg(
                     emb, seen, held, ds.item_id_range, K=20, plan=plans[name])
                 say("           | %s recall@20 %.5f ndcg@20 %.5f" % (name, rec[name + "_recall"], rec[name + "_ndcg"]))
-            train_g.edata["w"] = model.compute_attention(train_g)
         rec["eval_s"] = clock() - t0
         say("           | eval %.4fs" % rec["eval_s"])
 
@@ -240,10 +239,9 @@ def main(argv=None):
         idx = torch.randint(0, n_trip, (n_it, bs), device=dev)
         h_all, r_all, t_all = trip_cols[0][idx], trip_cols[1][idx], trip_cols[2][idx]
         neg_all = torch.randint(0, ds.n_KG_entity, (n_it, bs), device=dev, dtype=torch.int32)
-        total = torch.zeros((), dtype=torch.float32, device=dev)
-        for i in range(n_it):
-            # transR -> backward -> step -> zero_grad of kgat.py:127-131 as two library calls (same bits)
-            total += model.kg_step(h_all[i], r_all[i], t_all[i], neg_all[i], opt)
+        # every iteration = transR -> backward -> step -> zero_grad of kgat.py:127-131: one launch sorts all batches,
+        # then one library call (three launches) per iteration; the losses stay on the device (kg_phase)
+        total = model.kg_phase(h_all, r_all, t_all, neg_all, opt).sum()
         rec["kg_s"], rec["kg_iters"] = clock() - t0, n_it
         rec["kg_loss"] = float(total) / n_it
         say("Epoch %04d | KGE %.4fs (%d it, %.4f ms/it) loss %.4f" % (epoch, rec["kg_s"], n_it, 1e3 * rec["kg_s"] / n_it,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGAT_ABI_VERSION 9
+#define KGAT_ABI_VERSION 10
 
 enum {
   KGAT_OK = 0,
@@ -479,6 +479,37 @@ int kgat_transr_backward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t b
                              const int32_t* pos_t, const int32_t* neg_t, const float* grad_scale, float* grad_ent,
                              float* grad_W, float* grad_rel, void* workspace, size_t workspace_bytes,
                              kgat_stream_t stream);
+
+/* The KG phase of an epoch as three-launch iterations (round 6; reference kgat.py:116-136: for every sampled batch
+ * transR -> backward -> optimizer.step -> zero_grad; 1,641 iterations per epoch on the amazon-book shape).
+ *
+ * kgat_transr_presort_f32: the sorts an iteration needs depend only on the batch's ids, so the batches of a whole
+ * phase - h, r, pos_t, neg_t as n_batches x batch row-major arrays - are sorted by ONE launch (samples by relation
+ * with the chunk table of the weight-gradient partials; the 3 x batch entity ids).  Batch b's result is the block of
+ * kgat_transr_sorted_bytes(batch, n_rel) bytes at sorted + b * that.
+ *
+ * kgat_transr_adam_step_f32: one iteration on batch arrays h .. neg_t (batch ids each) and that batch's `sorted`
+ * block: the loss (1 float at `loss`) and the step of torch.optim.Adam on the three parameters the loss reaches -
+ * ent (n_nodes x d), W_R (n_rel x d x k), rel (n_rel x k), updated IN PLACE with their moments (`exp_avg_host`,
+ * `exp_avg_sq_host`: HOST arrays of three device pointers in that order; `steps_host`: the three step counts AFTER
+ * this step).  Dense semantics as kgat_adam_step_f32 (every row of the table moves), without a dense gradient: the
+ * <= 3 x batch summed gradient rows go to a compact buffer and are found again through `row_slot`, n_nodes 64-bit
+ * words owned by the caller - zero before the first call, never to be cleared - in which a word is valid for the call
+ * whose `tag` it carries: pass a tag in [1, 2^50) that differs from every earlier call's on the same row_slot (a
+ * counter).  The bits of kgat_transr_loss_grad_f32 followed by kgat_adam_step_f32, i.e. of the reference's
+ * loss.backward(); optimizer.step().  All pointers 16-byte aligned.  Launches: per-sample kernel, weight-gradient
+ * partials + gradient rows + loss, Adam. */
+size_t kgat_transr_sorted_bytes(int64_t batch, int n_rel);
+int kgat_transr_presort_f32(int64_t n_nodes, int n_rel, int64_t n_batches, int64_t batch, const int32_t* h,
+                            const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, void* sorted,
+                            size_t sorted_bytes, kgat_stream_t stream);
+size_t kgat_transr_step_workspace_bytes(int64_t batch, int d, int k, int n_rel);
+int kgat_transr_adam_step_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t batch, const int32_t* h, const int32_t* r,
+                              const int32_t* pos_t, const int32_t* neg_t, const void* sorted, float* ent, float* W_R,
+                              float* rel, float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                              const int64_t* steps_host, double lr, double beta1, double beta2, double eps,
+                              float reg_lambda, float* loss, uint64_t* row_slot, uint64_t tag, void* workspace,
+                              size_t workspace_bytes, kgat_stream_t stream);
 
 /* ---------------------------------------------------------------- evaluation
  * recall@K / ndcg@K of reference metric.py:36-68 (calc_recall_ndcg with one_recall_at_k :5-7, one_dcg_at_k :8-22

@@ -284,3 +284,100 @@ def test_planted_structure_recall_rises(dev, capsys):
     assert rec[3] > 3.0 * rec[0] and rec[3] > rec[2] > rec[1]
     assert val[3] > 3.0 * val[0]
     assert hist[3]["cf_loss"] < hist[1]["cf_loss"] and hist[3]["kg_loss"] < hist[1]["kg_loss"]
+
+
+@pytest.mark.parametrize("n,R,B,d,k", [(4000, 7, 1500, 64, 64), (900, 3, 700, 20, 12), (3000, 41, 2048, 32, 64),
+                                       (600000, 5, 512, 8, 8)])
+def test_kg_phase_same_bits_as_kg_step_and_the_autograd_path(dev, n, R, B, d, k):
+    """KGATPropagation.kg_phase (every batch sorted by one launch, then one three-launch library call per iteration:
+    no dense entity gradient, the weight-gradient partials summed inside the Adam launch) against (a) a loop over
+    kg_step with FusedAdam and (b) the reference's sequence transR(...).backward(); torch.optim.Adam.step(): the same
+    parameters, moments, step counts and losses BIT FOR BIT after several iterations - hub entities (one node heads 300
+    samples of a batch), widths off the MFMA form (20 x 12), 41 relations, node ids beyond 2^19 (the 64-bit sort), and a
+    CF-style step of the same optimiser over all parameters afterwards (ent has then stepped more often than W_R)."""
+    import dgl_kgat_amd as K
+    gen = torch.Generator(device="cpu").manual_seed(n + B)
+    n_it = 4
+    ids = [torch.randint(0, hi, (n_it, B), generator=gen) for hi in (n, R, n, n)]
+    ids[0][1, :min(300, B // 2)] = 42
+    ids[2][1, B // 2:B // 2 + 100] = 42
+    ids = [t.to(dev) for t in ids]
+    results = []
+    for mode in ("phase", "steps", "autograd"):
+        torch.manual_seed(3)
+        m = K.KGATPropagation(n, R, d, k, 2, 16, dropout=0.0).to(dev)
+        opt = (torch.optim.Adam if mode == "autograd" else K.FusedAdam)(m.parameters(), lr=0.01)
+        if mode == "phase":
+            losses = m.kg_phase(ids[0].int(), ids[1].int(), ids[2].int(), ids[3].int(), opt, reg_lambda_kg=1e-3)
+            assert all(p.grad is None for p in m.parameters())
+            losses = losses.tolist()
+        elif mode == "steps":
+            losses = [float(m.kg_step(ids[0][i], ids[1][i], ids[2][i], ids[3][i], opt, reg_lambda_kg=1e-3)) for i in range(n_it)]
+        else:
+            losses = []
+            for i in range(n_it):
+                loss = m.transR(ids[0][i], ids[1][i], ids[2][i], ids[3][i], reg_lambda_kg=1e-3)
+                loss.backward(); opt.step(); opt.zero_grad()
+                losses.append(float(loss.detach()))
+        kg_params = (m.entity_embed.weight, m.W_R, m.relation_embed.weight)
+        state = [(float(opt.state[p]["step"]), opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in kg_params]
+        # one more step of the SAME optimiser with a dense gradient on the table only (what a CF step does to the counts)
+        m.entity_embed.weight.grad = torch.full_like(m.entity_embed.weight, 1e-3)
+        opt.step(); opt.zero_grad()
+        if mode != "autograd":
+            more = m.kg_phase(ids[0][:1].int(), ids[1][:1].int(), ids[2][:1].int(), ids[3][:1].int(), opt, reg_lambda_kg=1e-3) \
+                if mode == "phase" else m.kg_step(ids[0][0], ids[1][0], ids[2][0], ids[3][0], opt, reg_lambda_kg=1e-3).reshape(1)
+        else:
+            loss = m.transR(ids[0][0], ids[1][0], ids[2][0], ids[3][0], reg_lambda_kg=1e-3)
+            loss.backward(); opt.step(); opt.zero_grad()
+            more = loss.detach().reshape(1)
+        results.append(([p.detach().clone() for p in m.parameters()], losses + more.tolist(), state,
+                        [float(opt.state[p]["step"]) for p in kg_params]))
+    ref = results[2]
+    for got in results[:2]:
+        assert got[1] == ref[1], (got[1], ref[1])
+        for a, b in zip(got[0], ref[0]):
+            assert torch.equal(a, b)
+        for (sa, ma, va), (sb, mb, vb) in zip(got[2], ref[2]):
+            assert sa == sb == n_it and torch.equal(ma, mb) and torch.equal(va, vb)
+        assert got[3] == ref[3] == [n_it + 2, n_it + 1, n_it + 1]
+    assert ref[1][-1] < ref[1][0]          # batch 0 again, after the updates
+
+
+def test_kg_phase_falls_back_to_kg_step(dev):
+    """torch.optim.Adam (not FusedAdam), an empty phase, mismatched shapes."""
+    import dgl_kgat_amd as K
+    torch.manual_seed(0)
+    n, R, B = 500, 4, 256
+    ids = [torch.randint(0, hi, (3, B), device=dev) for hi in (n, R, n, n)]
+    outs = []
+    for via_phase in (True, False):
+        torch.manual_seed(1)
+        m = K.KGATPropagation(n, R, 16, 16, 1, 16, dropout=0.0).to(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=0.01)
+        if via_phase:
+            ls = m.kg_phase(*ids, opt).tolist()
+        else:
+            ls = [float(m.kg_step(ids[0][i], ids[1][i], ids[2][i], ids[3][i], opt)) for i in range(3)]
+        outs.append((ls, [p.detach().clone() for p in m.parameters()]))
+    assert outs[0][0] == outs[1][0] and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    m = K.KGATPropagation(n, R, 16, 16, 1, 16, dropout=0.0).to(dev)
+    opt = K.FusedAdam(m.parameters(), lr=0.01)
+    assert m.kg_phase(*[t[:0] for t in ids], opt).shape == (0,)
+    with pytest.raises(ValueError):
+        m.kg_phase(ids[0], ids[1][:2], ids[2], ids[3], opt)
+
+
+@pytest.mark.parametrize("beta1", [0.3, 0.5, 0.0])
+def test_fused_adam_small_beta1_matches_torch(dev, beta1):
+    """torch's lerp switches formula at weight 0.5, i.e. for beta1 <= 0.5: the kernel follows it."""
+    import dgl_kgat_amd as K
+    torch.manual_seed(4)
+    a = torch.nn.Parameter(torch.randn(3000, 16, device=dev))
+    b = torch.nn.Parameter(a.detach().clone())
+    ref, ours = torch.optim.Adam([a], lr=0.01, betas=(beta1, 0.99)), K.FusedAdam([b], lr=0.01, betas=(beta1, 0.99))
+    for it in range(6):
+        g = torch.randn_like(a) * 10.0 ** (it % 3 - 2)
+        a.grad, b.grad = g.clone(), g.clone()
+        ref.step(); ours.step()
+        assert _ulp_diff(a, b) == 0 and _ulp_diff(ref.state[a]["exp_avg"], ours.state[b]["exp_avg"]) == 0, (beta1, it)
