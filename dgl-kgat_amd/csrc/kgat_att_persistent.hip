@@ -1460,10 +1460,13 @@ constexpr int kAttF16Second = 1;  // default since round 4 (-3.3 us in the step 
 // 30.2 M + 5.6 M - and the SAME run time, 126-132 us in the step against 125-133.  So the instruction count is not
 // what bounds either kernel; nor is the gather (every row from a 1,024-row cache-resident slice: -5 us), nor the
 // residency (12 wavefronts per CU without the cross-phase row prefetch: the same), nor the split over workgroups
-// (max / mean of their end times 1.14, finer static splits slower).  A wavefront spends 16 k cycles on a 32-group
-// tile of which 4.5 k issue instructions: the rest are the in-order stalls of one long dependent sequence per
-// wavefront (MFMA port / RAW 39 %, memory 28 %), two such sequences per SIMD.  Not the default: equal speed does not
-// pay for a second arithmetic statement on the path.
+// (max / mean of their end times 1.14, finer static splits slower).  What does bound both kernels was found by ablation
+// afterwards (profiles/r05_att_bounds.txt): with BOTH products and the tanh removed the launch takes
+// 124.9 of 127.9 us, with the edge phases removed 86.3 - the launch is its gather-dot side (the tail row of every edge
+// against the group's V row), which runs at 1.36-1.39 x the bare gather of the same rows; the products hide behind it.
+// (The "478 vector instructions per tile / pipe 40 % busy => issue-bound" reading of rounds 3-4, quoted above as the
+// hypothesis this kernel was built to test, is refuted by this kernel's own timing.)  Not the default: equal speed does
+// not pay for a second arithmetic statement on the path.
 constexpr int kFused32Threads = 512;
 constexpr int kF32Groups = 32;
 typedef float floatx16 __attribute__((ext_vector_type(16)));

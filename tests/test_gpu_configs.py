@@ -795,3 +795,123 @@ def test_graphed_forward_replays_the_same_bits(dev):
             model.layers[0].res_fc_2.weight.add_(0.01)
         ref2 = eager(graph)
         assert not torch.equal(ref2, ref) and torch.equal(gs(), ref2)
+
+
+_MULTI_GPU_WORKER = r"""
+import os, sys, hashlib, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import dgl_kgat_amd as K
+from dgl_kgat_amd import partition, synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ["KGAT_TEST_BACKEND"]
+one_gpu = os.environ.get("KGAT_TEST_ONE_GPU") == "1"          # rehearsal: every rank on cuda:0 over gloo
+dev = torch.device("cuda", 0 if one_gpu else rank)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+assert dist.get_world_size() == world and dist.get_backend() == backend
+modes = [m for m in partition.EXCHANGE_MODES if backend == "nccl" or m not in ("p2p", "allgather")]
+n, trip, R = synth.amazon_book_ckg(scale=0.05)
+torch.manual_seed(11)
+model = K.KGATPropagation(n, R, 64, 64, 3, 64, dropout=0.0).to(dev)
+for p_ in model.parameters():                                  # one source of truth, whatever each rank's RNG drew
+    dist.broadcast(p_.data, src=0)
+g = synth.build_graph(n, trip, dev)
+
+def same_on_all_ranks(t, what):
+    got = [None] * world
+    dist.all_gather_object(got, hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest())
+    assert len(set(got)) == 1, what + ": ranks disagree"
+    return got[0]
+
+with torch.no_grad():
+    g.edata["w"] = model.compute_attention(g)
+    ref = model.gnn(g)                                         # the one-GPU result, computed on every rank's own device
+    same_on_all_ranks(ref, "unsharded readout")
+    digests = {}
+    for mode in modes:
+        for chunks in (1, 3):                                  # 3: the exchange in row blocks, overlapped with compute
+            sg, keep = partition.shard_graph(g, rank, world, mode=mode)
+            assert sg.partition.collectives_on and sg.partition.hi > sg.partition.lo
+            sg.partition.n_chunks = chunks
+            a_loc = model.compute_attention(sg)
+            assert float((a_loc.reshape(-1) - g.edata["w"].reshape(-1)[torch.as_tensor(keep, device=dev)]).abs().max()) <= 2e-6
+            sg.edata["w"] = a_loc
+            out = model.gnn(sg)
+            err = float((out - ref).abs().max()) / float(ref.abs().max())
+            assert err <= 2e-6, (mode, chunks, err)
+            assert torch.equal(out, model.gnn(sg)), (mode, chunks, "second pass differs")
+            digests[(mode, chunks)] = same_on_all_ranks(out, "sharded readout %%s x%%d" %% (mode, chunks))
+    for chunks in (1, 3):                                      # every exchange form moves the same bits
+        assert len({digests[(m, chunks)] for m in modes}) == 1, digests
+print("rank", rank, "forward ok:", modes, flush=True)
+
+# backward: the CF step on shards (local reversed-CSR aggregation + gradient reductions) against the one-GPU stack
+for drop in (0.0, 0.1):
+    for li, layer in enumerate(model.layers):
+        layer.mess_drop.p = drop
+    model.train()
+    users = torch.arange(0, 4000, device=dev) %% n
+    pos, neg = (users * 7 + 3) %% n, (users * 13 + 5) %% n
+    def grads(graph):
+        model.zero_grad()
+        torch.manual_seed(5)
+        loss = model.get_loss(model.gnn(graph), users, pos, neg)
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    loss1, g1 = grads(g)
+    sg, keep = partition.shard_graph(g, rank, world)
+    with torch.no_grad():
+        sg.edata["w"] = model.compute_attention(sg)
+    lossP, gP = grads(sg)
+    assert abs(loss1 - lossP) <= 1e-5 * abs(loss1), (drop, loss1, lossP)
+    assert set(g1) == set(gP) and "entity_embed.weight" in g1 and "layers.0.res_fc_2.weight" in g1
+    for k in g1:
+        scale = float(g1[k].abs().max())
+        err = float((g1[k] - gP[k]).abs().max())
+        assert scale > 0 and err <= 1e-5 * scale, (drop, k, err, scale)
+        same_on_all_ranks(gP[k], "gradient " + k)
+print("rank", rank, "backward ok", flush=True)
+if backend == "nccl":
+    with open("/proc/self/maps") as fh:
+        libs = sorted({ln.split()[-1] for ln in fh if "rccl" in ln or "nccl" in ln})
+    assert libs, "no RCCL library mapped into the process"
+    print("rank", rank, "device", torch.cuda.get_device_name(dev), "rccl:", libs, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_multi_gpu_worker_rehearsal_two_ranks_gloo_one_gpu(dev, tmp_path):
+    """The worker of the multi-GPU RCCL tests below, rehearsed where it can run today: two ranks on cuda:0 over
+    gloo (all-reduce and broadcast forms, plain and in row blocks; backward with and without dropout)."""
+    from conftest import ROOT
+    script = tmp_path / "multi_gpu_worker.py"
+    script.write_text(_MULTI_GPU_WORKER % ROOT)
+    outs = _run_ranks(script, 2, tmp_path, extra_env={"KGAT_TEST_BACKEND": "gloo", "KGAT_TEST_ONE_GPU": "1"})
+    assert all("forward ok" in o and "backward ok" in o for o in outs)
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()     # (counting devices does not initialise the GPU runtime)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="first contact with >= 2 RCCL ranks needs a box with >= 2 GPUs "
+                                          "(VERDICT round 5, task 7: prepared, runs the day such a box appears)")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_sharded_forward_and_backward_match_one_gpu(world, tmp_path):
+    """SURVEY 8e on real links: `world` processes, one per GPU, `nccl` (= RCCL over xGMI) process group - the sharded
+    forward in EVERY exchange form (all-reduce of the zero-padded buffer = north star; all-gather of unequal slices;
+    per-owner broadcast; grouped send / recv), plain and overlapped in three row blocks, must equal the one-GPU
+    readout to 2e-6 and carry the same bits on every rank and in every form; the sharded CF backward must give the
+    one-GPU gradients (1e-5 of each tensor's scale) on every rank, with and without dropout."""
+    if _n_gpus() < world:
+        pytest.skip("%d GPUs visible" % _n_gpus())
+    from conftest import ROOT
+    script = tmp_path / "multi_gpu_worker.py"
+    script.write_text(_MULTI_GPU_WORKER % ROOT)
+    outs = _run_ranks(script, world, tmp_path, extra_env={"KGAT_TEST_BACKEND": "nccl"}, timeout=900)
+    for o in outs:
+        assert "forward ok" in o and "backward ok" in o and "rccl" in o.lower(), o[-2000:]
+    print(outs[0][-800:])

@@ -297,8 +297,10 @@ def test_kg_phase_same_bits_as_kg_step_and_the_autograd_path(dev, n, R, B, d, k)
     CF-style step of the same optimiser over all parameters afterwards (ent has then stepped more often than W_R)."""
     import dgl_kgat_amd as K
     gen = torch.Generator(device="cpu").manual_seed(n + B)
-    n_it = 4
+    n_it = 5
     ids = [torch.randint(0, hi, (n_it, B), generator=gen) for hi in (n, R, n, n)]
+    ids[0][2] = ids[0][1]                  # consecutive batches that share most of their rows
+    ids[2][3, :B // 2] = ids[2][2, :B // 2]
     ids[0][1, :min(300, B // 2)] = 42
     ids[2][1, B // 2:B // 2 + 100] = 42
     ids = [t.to(dev) for t in ids]
