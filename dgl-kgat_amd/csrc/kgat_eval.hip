@@ -88,14 +88,25 @@ __device__ __forceinline__ bool in_sorted(const int32_t* __restrict__ a, int32_t
 }
 
 struct EvalLds {
-  // per wavefront: cand_s / cand_i [32 users][kEvalCap], kept [32]; then the users' rows [FP2][64]
-  static __host__ __device__ size_t per_wave_bytes(int FP2) {
-    return (size_t)32 * kEvalCap * 8 + 32 * 4 * 2 + (size_t)FP2 * 64 * 4;
+  // per wavefront: cand_s / cand_i [32 users][kEvalCap], kept [32]; then (LDS form only) the users' rows [FP2][64]
+  static __host__ __device__ size_t per_wave_bytes(int FP2, bool rows_in_registers = false) {
+    return (size_t)32 * kEvalCap * 8 + 32 * 4 * 2 + (rows_in_registers ? (size_t)0 : (size_t)FP2 * 64 * 4);
   }
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
+// KG > 0 (round 6): the users' rows - the B operand of every MFMA of the sweep - live in REGISTERS (KG groups of 8
+// k pairs = 8 KG values per lane: 88 at the reference readout's 176 columns) instead of LDS.  The LDS form spends
+// 22.5 KB per wavefront on them, so a CU holds ONE workgroup = one wavefront per SIMD, and that wavefront's candidate
+// handling (vector ALU) leaves the matrix pipe idle: the sweep ran at 0.57 of the fp32-MFMA peak, the launch at 0.30.
+// With the rows in registers a wavefront needs 16.6 KB, two workgroups of four fit a CU, and a second wavefront per
+// SIMD issues MFMAs while the first one filters; no ds_read per MFMA either.  The arithmetic is the same fmaf chain
+// in the same k order: same score bits.  KG = 0: the LDS form (any width).
+constexpr int kEvalRegKG = 11;    // F in (160, 176]: the 64 + 64 + 32 + 16 readout of the reference's default model
+
+// (two wavefronts per SIMD at most - the LDS allows no more in either form - so the allocator may use 256 registers:
+// left to its default budget it kept 150 and spilled the users' rows to scratch)
+template <int NW, int KG>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(248))) void eval_topk_kernel(
     int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t tile_lo,
     int64_t tile_hi, int n_lists, int list0, int use_tau0, const float* __restrict__ emb, int64_t emb_stride,
     const float* __restrict__ itemT, const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items,
@@ -103,7 +114,8 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ul = lane & 31, half = lane >> 5;
-  char* base = s_raw + (size_t)w * EvalLds::per_wave_bytes(FP2);
+  constexpr bool REG = KG > 0;
+  char* base = s_raw + (size_t)w * EvalLds::per_wave_bytes(FP2, REG);
   float* cand_s = reinterpret_cast<float*>(base);
   int32_t* cand_i = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 4);
   int32_t* kept = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 8);  // entries known not to be training items
@@ -116,11 +128,20 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
   const bool u_ok = up < n_users;
   const int64_t up_c = u_ok ? up : n_users - 1;
   // B fragments: lane (user ul, half) holds the user's elements k = 2s + half
+  float breg[REG ? KG * 8 : 1];
   {
     const float* row = emb + (size_t)user_ids[up_c] * emb_stride;
-    for (int s = 0; s < FP2; ++s) {
-      const int k = 2 * s + half;
-      ub[s * 64 + lane] = (u_ok && k < F) ? row[k] : 0.f;
+    if constexpr (REG) {
+#pragma unroll
+      for (int s = 0; s < KG * 8; ++s) {
+        const int k = 2 * s + half;
+        breg[s] = (u_ok && k < F) ? row[k < F ? k : 0] : 0.f;
+      }
+    } else {
+      for (int s = 0; s < FP2; ++s) {
+        const int k = 2 * s + half;
+        ub[s * 64 + lane] = (u_ok && k < F) ? row[k] : 0.f;
+      }
     }
   }
   if (lane < 32) kept[lane] = 0;
@@ -181,9 +202,9 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
   // the loop unrolled by two so that no buffer is copied).
   constexpr int U = 8;
   const float* a_base = itemT + lane;
-  const int KG = FP2 / U;                                      // k groups per tile group (FP2 is a multiple of U)
+  const int KGR = FP2 / U;                                     // k groups per tile group (FP2 is a multiple of U)
   struct Pos { int64_t t0; int g; };
-  auto advance = [&](Pos& p) { if (++p.g == KG) { p.g = 0; p.t0 += kEvalNT; } };
+  auto advance = [&](Pos& p) { if (++p.g == KGR) { p.g = 0; p.t0 += kEvalNT; } };
   auto issue = [&](float (&a)[U][kEvalNT], const Pos& p) {
     // (unconditional: a load under a branch makes the compiler's counted vmcnt waits conservative - it then waited
     // for the NEXT step's loads before this step's MFMAs; past the end the clamped tile is loaded again, unused)
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
 #pragma unroll
       for (int t = 0; t < kEvalNT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
-    if (p.g == KG - 1) {
+    if (p.g == KGR - 1) {
       check(p.t0);
 #pragma unroll
       for (int t = 0; t < kEvalNT; ++t)
@@ -275,7 +296,44 @@ __global__ __launch_bounds__(NW * 64) void eval_topk_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;   // (here, behind the check's branch: not a select per step)
     }
   };
-  {
+  if constexpr (REG) {
+    // Two tile groups per loop iteration: 2 KG steps (tile group, k group) with compile-time k groups - the register
+    // index of the B operand - and compile-time buffer parity (KG is odd: the parity flips from one tile group to the
+    // next).  Step j's loads were issued during step j - 1; a group past the end re-reads the clamped last tile and
+    // is skipped by compute_r.
+    static_assert(KG == 11, "the step list below is written out for 2 x 11 steps");
+    // Two tile groups per loop iteration = 22 steps (tile group, k group) with compile-time k groups - the register
+    // index of the B operand - and compile-time buffer parity (KG is odd: the parity flips from one tile group to the
+    // next).  Step j's loads are issued during step j - 1 (a ring of three buffers, two steps ahead, measured the same:
+    // 9.51 vs 9.40 ms); a group past the end re-reads the clamped last tile and is skipped.
+    // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
+    //  per step - the index as an integral_constant - sent every captured array to scratch)
+    float a0[U][kEvalNT], a1[U][kEvalNT];
+    issue(a0, Pos{t_lo, 0});
+#define KGAT_EVAL_STEP(J, CUR, NXT)                                                                       \
+    {                                                                                                     \
+      constexpr int j = J, g = j % KG, gn = (j + 1) % KG;                                                 \
+      const int64_t tt = t0 + (j / KG) * kEvalNT, tn = t0 + ((j + 1) / KG) * kEvalNT;                     \
+      issue(NXT, Pos{tn, gn});                                                                            \
+      if (tt < t_hi) { /* wave-uniform */                                                                 \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                     \
+          _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[u][t], breg[g * U + u], acc[t], 0, 0, 0);   \
+        if (g == KG - 1) {                                                                                \
+          check(tt);                                                                                      \
+          _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                               \
+        }                                                                                                 \
+      }                                                                                                   \
+    }
+#define KGAT_EVAL_STEP2(J) KGAT_EVAL_STEP(J, a0, a1) KGAT_EVAL_STEP(J + 1, a1, a0)
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * kEvalNT) {
+      KGAT_EVAL_STEP2(0) KGAT_EVAL_STEP2(2) KGAT_EVAL_STEP2(4) KGAT_EVAL_STEP2(6) KGAT_EVAL_STEP2(8) KGAT_EVAL_STEP2(10)
+      KGAT_EVAL_STEP2(12) KGAT_EVAL_STEP2(14) KGAT_EVAL_STEP2(16) KGAT_EVAL_STEP2(18) KGAT_EVAL_STEP2(20)
+    }
+#undef KGAT_EVAL_STEP2
+#undef KGAT_EVAL_STEP
+  } else {
     float a0[U][kEvalNT], a1[U][kEvalNT];
     Pos p0{t_lo, 0}, p1{t_lo, 0};
     advance(p1);
@@ -344,7 +402,10 @@ __global__ __launch_bounds__(256) void eval_merge_kernel(
 // k pairs of a row, padded with zeros to the unroll of the MFMA loop
 static int eval_fp2(int F) { return ((F + 1) / 2 + 7) / 8 * 8; }
 
+static bool eval_rows_in_registers(int FP2) { return FP2 == kEvalRegKG * 8; }
+
 static int eval_waves_per_block(int FP2) {
+  if (eval_rows_in_registers(FP2)) return 4;
   // the largest workgroup whose wavefronts' LDS (candidates + the users' rows) fits a CU
   for (int nw = 4; nw >= 1; nw >>= 1)
     if (EvalLds::per_wave_bytes(FP2) * nw <= (size_t)160 * 1024) return nw;
@@ -366,7 +427,8 @@ static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   const int64_t rest = n_tiles - p.sample_tiles;
   const int nw = p.nw > 0 ? p.nw : 1;
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
-  const int64_t want = (int64_t)device_cu_count() * 4;       // ~4 workgroups per CU
+  // ~4 workgroups per CU (8 with the users' rows in registers: two are resident per CU there)
+  const int64_t want = (int64_t)device_cu_count() * (eval_rows_in_registers(eval_fp2(F)) ? 8 : 4);
   int64_t seg = (want + blocks - 1) / (blocks > 0 ? blocks : 1);
   const int64_t max_seg = rest / 16 > 0 ? rest / 16 : 1;     // at least 16 tiles (512 items) per segment
   if (seg > max_seg) seg = max_seg;
@@ -442,25 +504,27 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   Carver cv(workspace);
   float* part_s = cv.take<float>((size_t)n_users * pl.n_lists * K);
   int32_t* part_i = cv.take<int32_t>((size_t)n_users * pl.n_lists * K);
-  const size_t lds = EvalLds::per_wave_bytes(FP2) * nw;
+  const bool reg = eval_rows_in_registers(FP2);
+  const size_t lds = EvalLds::per_wave_bytes(FP2, reg) * nw;
   const unsigned gx = (unsigned)((n_users + 32 * nw - 1) / (32 * nw));
   hipStream_t st = as_stream(stream);
-#define KGAT_EVAL_LAUNCH(NW, GY, TLO, THI, LIST0, TAU0)                                                               \
+#define KGAT_EVAL_LAUNCH(NW, KG_, GY, TLO, THI, LIST0, TAU0)                                                          \
   do {                                                                                                                \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(eval_topk_kernel<NW>),                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(eval_topk_kernel<NW, KG_>),                                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                    \
       set_error("eval_recall_ndcg: cannot reserve %zu bytes of LDS", lds);                                            \
       return KGAT_E_HIP;                                                                                              \
     }                                                                                                                 \
-    hipLaunchKernelGGL((eval_topk_kernel<NW>), dim3(gx, (unsigned)(GY)), dim3(NW * 64), lds, st, n_users, user_ids,   \
-                       n_items, FP2, F, (int64_t)(TLO), (int64_t)(THI), pl.n_lists, LIST0, TAU0, emb, emb_stride,    \
-                       itemT, train_ptr, train_items, K, part_s, part_i);                                            \
+    hipLaunchKernelGGL((eval_topk_kernel<NW, KG_>), dim3(gx, (unsigned)(GY)), dim3(NW * 64), lds, st, n_users,        \
+                       user_ids, n_items, FP2, F, (int64_t)(TLO), (int64_t)(THI), pl.n_lists, LIST0, TAU0, emb,      \
+                       emb_stride, itemT, train_ptr, train_items, K, part_s, part_i);                                \
   } while (0)
-#define KGAT_EVAL_LAUNCH_NW(GY, TLO, THI, LIST0, TAU0)                  \
-  do {                                                                  \
-    if (nw == 4) KGAT_EVAL_LAUNCH(4, GY, TLO, THI, LIST0, TAU0);        \
-    else if (nw == 2) KGAT_EVAL_LAUNCH(2, GY, TLO, THI, LIST0, TAU0);   \
-    else KGAT_EVAL_LAUNCH(1, GY, TLO, THI, LIST0, TAU0);                \
+#define KGAT_EVAL_LAUNCH_NW(GY, TLO, THI, LIST0, TAU0)                     \
+  do {                                                                     \
+    if (reg) KGAT_EVAL_LAUNCH(4, kEvalRegKG, GY, TLO, THI, LIST0, TAU0);   \
+    else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0, GY, TLO, THI, LIST0, TAU0);   \
+    else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0, GY, TLO, THI, LIST0, TAU0);   \
+    else KGAT_EVAL_LAUNCH(1, 0, GY, TLO, THI, LIST0, TAU0);                \
   } while (0)
   if (pl.sample_tiles) {
     KGAT_EVAL_LAUNCH_NW(1, 0, pl.sample_tiles, 0, 0);

@@ -22,8 +22,11 @@ constexpr int kSpmmThreads = 256;
 // Threads per workgroup of the kernels that are laid out in lane groups of LPR lanes.  D <= 8 (two lanes per
 // row and fewer): 128 - a 256-thread workgroup holds 128 runs there, i.e. 256 run partials to combine per
 // tile; halving the workgroup (not the run length, which was tried and lost) took the D = 8 launch on the
-// last-fm graph from 0.066 to 0.058 ms (round 3, AB_FLAG=-DKGAT_SPMM_THREADS=128).  Wider rows: no gain.
-constexpr int spmm_threads(int lpr) { return (lpr <= 2 && kSpmmThreads == 256) ? 128 : kSpmmThreads; }
+// last-fm graph from 0.066 to 0.058 ms (round 3, AB_FLAG=-DKGAT_SPMM_THREADS=128).  Round 6 re-scanned workgroup size
+// x run length for the narrow rows (scripts/micro/spmm_narrow_scan.sh, profiles/r06_spmm_narrow_scan.txt): 128 threads
+// also at D = 16 / 32 - 16 runs and 32 run partials per tile, as a D = 64 tile has - with the half-length runs:
+// D = 32 49.4 -> 47.6 us, D = 16 47.8 -> 44.7 (full-length runs 50.9 / 46.1, quarter-length 54.2 / 51.8); D >= 64 flat.
+constexpr int spmm_threads(int lpr) { return (lpr <= 8 && kSpmmThreads == 256) ? 128 : kSpmmThreads; }
 
 template <int LPR>
 struct SpmmGeom {

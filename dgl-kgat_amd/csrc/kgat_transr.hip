@@ -942,9 +942,19 @@ __global__ __launch_bounds__(256) void transr_adam_kernel(TrAdamArgs a, float w1
       const int64_t r = i / width;
       const int e = (int)(i - r * width) + (t == 1 ? 0 : a.dk);
       const int first = a.chunk_ptr[r], n_mine = a.chunk_ptr[r + 1] - first;
-      for (int q = 0; q < n_mine; ++q) {   // (transr_reduce_body's order: v = 0; v += partial, chunk after chunk)
-        const float4 x = *reinterpret_cast<const float4*>(a.part + (size_t)(first + q) * stride + e);
-        gg.x += x.x; gg.y += x.y; gg.z += x.z; gg.w += x.w;
+      // transr_reduce_body's order: v = 0; v += partial, chunk after chunk.  Four partials are requested together (a
+      // load per iteration made the sum a chain of L2 round trips - ten for the most frequent relation at 32-sample
+      // chunks - at the tail of the launch); the additions stay in chunk order.
+      for (int q = 0; q < n_mine; q += 4) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int qq = q + u < n_mine ? q + u : n_mine - 1;
+          x[u] = *reinterpret_cast<const float4*>(a.part + (size_t)(first + qq) * stride + e);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + u < n_mine) { gg.x += x[u].x; gg.y += x[u].y; gg.z += x[u].z; gg.w += x[u].w; }
       }
     }
     float4 pp = *reinterpret_cast<const float4*>(p + i);
