@@ -91,9 +91,14 @@ def _check_step(tag, dev, n, trip, n_rel, d, layers, hidden, expect_form=None):
         parity_8c("%s readout block %d" % (tag, bi), x, c, y, factor=1.5)
         parity_8c_mean("%s readout block %d" % (tag, bi), x, c, y)
         e_inf, c_inf = rel_err_inf(x, y), rel_err_inf(c, y)
-        print("[scale] %s readout block %d gpu %.3e  c-fp32 %.3e (max|x-y| / max|y|; bar max(1e-5, c-fp32))"
-              % (tag, bi, e_inf, c_inf))
+        # which clause carries the block (say so in the log): the fixed 1e-5 of the tensor's scale,
+        # or - a normalised block whose small-norm rows amplify ANY fp32 forward - "no further from fp64 than the
+        # CPU fp32 forward"; either way inside the north star's 1e-4, asserted on its own
+        clause = "1e-5 of the tensor's scale" if e_inf <= 1e-5 else "no worse than the CPU fp32 forward (%.3e)" % c_inf
+        print("[scale] %s readout block %d gpu %.3e  c-fp32 %.3e (max|x-y| / max|y|): passes by the clause \"%s\""
+              % (tag, bi, e_inf, c_inf, clause))
         assert e_inf <= max(1e-5, c_inf), (bi, e_inf, c_inf)
+        assert e_inf <= 1e-4, (bi, e_inf)     # north star: <= 1e-4 relative fp32, unconditionally
     with torch.no_grad():
         h = model.entity_embed.weight.detach()
         for li, layer in enumerate(model.layers):
