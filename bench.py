@@ -1074,17 +1074,17 @@ def main():
             "vs_c_port_max_abs_diff": {"gnn_out_rel_to_max": float(np.max(np.abs(t_out - c_out))) / scale,
                                        "attention_abs": float(np.max(np.abs(t_a.reshape(-1) - c_a)))}}
         assert result["cpu_baseline"]["torch_restatement"]["vs_c_port_max_abs_diff"]["gnn_out_rel_to_max"] < 1e-4
-    # the committed 1/2/4/8 model (scripts/scaling_model.py -> profiles/r05_scaling_model.json: per-rank local time
+    # the committed 1/2/4/8 model (scripts/scaling_model.py -> profiles/r06_scaling_model.json: per-rank local time
     # MEASURED on one GPU with the exchange stubbed + the SURVEY 5 link model) beside this run's measurement
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_scaling_model.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r06_scaling_model.json")) as fh:
             sm = json.load(fh)
         key = {"amazon-book": "configs[2]", "power-law": "configs[4]"}.get(args.workload) if args.scale == 1.0 else None
         if args.workload == "amazon-book" and D == 128:
             key = "configs[3]"
         rows = [r for r in sm.get("rows", []) if r.get("config") == key and r.get("P") == world]
         if rows:
-            result["scaling_model"] = dict(rows[0], source="profiles/r05_scaling_model.json",
+            result["scaling_model"] = dict(rows[0], source="profiles/r06_scaling_model.json",
                                            note="every model_* field is a MODEL (measured per-rank local time on one "
                                                 "GPU + link model), not a measurement of this run")
     except (OSError, ValueError):

@@ -175,13 +175,18 @@ class _GNNTrain(torch.autograd.Function):
         w_csr = st.csr_weights(ew)
         widths = [h.shape[1]] + [w.shape[0] for w in weights]
         out = torch.empty((h.shape[0], sum(widths)), dtype=torch.float32, device=dev)
-        out[:, :widths[0]] = h
+        # the ego block (out[:, :d] = h0, models.py:159,168) is written by layer 0's dense kernel from the rows it loads
+        # anyway (self_out) where the slice allows 16-byte stores; otherwise by a copy here
+        ego_in_kernel = len(weights) > 0 and widths[0] % 4 == 0 and out.shape[1] % 4 == 0 and h.shape[0] > 0
+        if not ego_in_kernel:
+            out[:, :widths[0]] = h
         off = widths[0]
         hs, hns = [h], []
         for li, w in enumerate(weights):
             hn = ops.spmm(csr.indptr, csr.col, csr.row_of, hs[-1], w_csr)
             hs.append(ops.bi_interaction_train(hs[-1], hn, w.detach().contiguous(), slope, drop_p, seed + li,
-                                               norm_out=out[:, off:off + widths[li + 1]]))
+                                               norm_out=out[:, off:off + widths[li + 1]],
+                                               self_out=out[:, :widths[0]] if (li == 0 and ego_in_kernel) else None))
             hns.append(hn)
             off += widths[li + 1]
         ctx.g, ctx.slope, ctx.drop_p, ctx.seed, ctx.widths, ctx.ew = g, slope, drop_p, seed, widths, ew
@@ -220,8 +225,12 @@ class _GNNTrain(torch.autograd.Function):
             g_a = ops.spmm(rev.indptr, rev.col, rev.row_of, t, w_rev)
         grad_h0 = None
         if ctx.needs_input_grad[4]:
-            grad_h0 = grad_out[:, :ctx.widths[0]] + g_a
-            grad_h0 += g_b
+            g0 = grad_out[:, :ctx.widths[0]]
+            if g_a is not None and ctx.widths[0] % 4 == 0 and grad_out.shape[1] % 4 == 0 and g0.data_ptr() % 16 == 0:
+                grad_h0 = ops.add3_rows(g0, g_a, g_b)      # one pass: (g0 + g_a) + g_b, the same additions
+            else:
+                grad_h0 = g0 + g_a
+                grad_h0 += g_b
         return (None, None, None, None, grad_h0, *grad_w)
 
 

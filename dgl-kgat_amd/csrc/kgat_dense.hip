@@ -186,7 +186,7 @@ constexpr int kBiPrefetch = 2;
       }
       if constexpr (DEFER) row_offsets(t + PF, d);  // (clamped to the last row past the end)
     } else if (MODE >= 1) {
-      if (MODE == 1 && ego.out != nullptr && (t << 4) + i < n_rows) {
+      if (MODE >= 1 && ego.out != nullptr && (t << 4) + i < n_rows) {
         float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)ra * ego.stride) + q;
 #pragma unroll
         for (int m = 0; m < DI / 16; ++m) st_final4(pe + m * 4, make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]));
@@ -265,7 +265,7 @@ constexpr int kBiPrefetch = 2;
       }
     }
     if constexpr (LATE_MUL) {
-      if (MODE == 1 && ego.out != nullptr && row0 + i < n_rows) {
+      if (MODE >= 1 && ego.out != nullptr && row0 + i < n_rows) {
         float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)(row0 + i) * ego.stride) + q;
 #pragma unroll
         for (int m = 0; m < DI / 16; ++m) st_final4(pe + m * 4, make_float4(a[4 * m + 0], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]));
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void bi_interaction_small_kernel(
       a[4 * m] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
     }
     if (MODE >= 1) {
-      if (MODE == 1 && ego.out != nullptr) {
+      if (MODE >= 1 && ego.out != nullptr) {
         float4* pe = reinterpret_cast<float4*>(ego.out + (size_t)row * ego.stride);
 #pragma unroll
         for (int m = 0; m < DI / 4; ++m) pe[m] = make_float4(a[4 * m], a[4 * m + 1], a[4 * m + 2], a[4 * m + 3]);
@@ -915,7 +915,8 @@ int kgat_bi_interaction_mul_deferred_f32(int64_t n_rows, int d_in, int d_out, co
 
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
                                   const float* W2, float negative_slope, float drop_p, uint64_t seed, int64_t row0,
-                                  float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream) {
+                                  float* h_out, float* norm_out, int64_t norm_stride, float* self_out,
+                                  int64_t self_stride, kgat_stream_t stream) {
   KGAT_CHECK_ARG(n_rows >= 0 && n_rows < INT32_MAX && row0 >= 0 &&
                      (uint64_t)(row0 + n_rows) * (uint64_t)d_out < (1ull << 32),
                  "bi_interaction_train: bad row count");
@@ -927,8 +928,40 @@ int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const flo
     set_error("bi_interaction_train: unsupported widths %d -> %d", d_in, d_out);
     return KGAT_E_UNSUPPORTED;
   }
+  KGAT_CHECK_ARG(self_out == nullptr || (self_stride >= d_in && self_stride % 4 == 0 &&
+                                         (reinterpret_cast<uintptr_t>(self_out) & 15u) == 0),
+                 "bi_interaction_train: self_out must be 16-byte aligned with a row stride that is a multiple of 4 floats >= d_in");
   return bi_dispatch(n_rows, d_in, d_out, H, HN, W2, negative_slope, drop_args(drop_p, seed, row0, d_out), h_out,
-                     norm_out, norm_stride, as_stream(stream), 2);
+                     norm_out, norm_stride, as_stream(stream), 2, EgoCopy{self_out, self_stride});
+}
+
+// out = a + b + c over n_rows x d (a: rows of a_stride floats - a column slice of a wider matrix; b, c, out contiguous)
+__global__ __launch_bounds__(256) void add3_rows_kernel(int64_t n4, int d4, int64_t a_stride4, const float4* __restrict__ a,
+                                                        const float4* __restrict__ b, const float4* __restrict__ c,
+                                                        float4* __restrict__ out) {
+  for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < n4; x += (int64_t)gridDim.x * 256) {
+    const int64_t row = x / d4;
+    const float4 va = a[row * a_stride4 + (x - row * d4)], vb = b[x], vc = c[x];
+    // (a + b) + c, element by element: the order of `grad_out[:, :d] + g_a` followed by `+= g_b`
+    out[x] = make_float4((va.x + vb.x) + vc.x, (va.y + vb.y) + vc.y, (va.z + vb.z) + vc.z, (va.w + vb.w) + vc.w);
+  }
+}
+
+int kgat_add3_rows_f32(int64_t n_rows, int d, const float* a, int64_t a_stride, const float* b, const float* c, float* out,
+                       kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_rows >= 0 && d > 0 && d % 4 == 0 && a_stride >= d && a_stride % 4 == 0, "add3_rows: bad sizes");
+  if (n_rows == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(a && b && c && out, "add3_rows: null pointer");
+  KGAT_CHECK_ARG(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                   reinterpret_cast<uintptr_t>(out)) & 15u) == 0, "add3_rows: pointers must be 16-byte aligned");
+  const int64_t n4 = n_rows * (d / 4);
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add3_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n4, d / 4, a_stride / 4,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                     reinterpret_cast<const float4*>(c), reinterpret_cast<float4*>(out));
+  KGAT_CHECK_LAUNCH("add3_rows");
+  return KGAT_OK;
 }
 
 int kgat_bi_interaction_bwd_pre_f32(int64_t n_rows, int d_out, const float* h_out, const float* grad_a,

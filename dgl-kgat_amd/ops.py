@@ -738,7 +738,7 @@ def _strided_rows(t, n, d, name):
     return t.stride(0)
 
 
-def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None, row0=0):
+def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None, row0=0, self_out=None):
     """Training form: h_out = dropout_p(leaky_relu((H * HN) @ W2^T)) and its normalised copy into
     `norm_out` (kgat_bi_interaction_train_f32; the mask is a hash of (seed, element); `row0`: the
     global index of row 0 when H holds a row range of a larger matrix, so that a destination shard
@@ -752,12 +752,26 @@ def bi_interaction_train(H, HN, W2, negative_slope, drop_p, seed, norm_out=None,
         raise ValueError("W2 has shape %s, expected (*, %d)" % (tuple(W2.shape), d_in))
     h_out = torch.empty((n, d_out), dtype=torch.float32, device=H.device)
     stride = _strided_rows(norm_out, n, d_out, "norm_out") if norm_out is not None else 0
+    self_stride = _strided_rows(self_out, n, d_in, "self_out") if self_out is not None else 0   # the ego block (copy of H)
     with _timed("bi_interaction", (n, d_in, d_out)):
         check(_lib.load().kgat_bi_interaction_train_f32(n, d_in, d_out, _ptr(H), _ptr(HN), _ptr(W2),
                                                         float(negative_slope), float(drop_p), int(seed) & (2 ** 64 - 1),
-                                                        int(row0), _ptr(h_out), _ptr(norm_out), stride, _stream(H)),
+                                                        int(row0), _ptr(h_out), _ptr(norm_out), stride, _ptr(self_out),
+                                                        self_stride, _stream(H)),
               "kgat_bi_interaction_train_f32")
     return h_out
+
+
+def add3_rows(a, b, c):
+    """(a + b) + c where `a` is an (n, d) column slice of a wider fp32 matrix and b, c are contiguous (n, d)
+    (kgat_add3_rows_f32): the three gradient paths into the embedding table in one pass."""
+    b = _need(b, torch.float32, "b")
+    c = _need(c, torch.float32, "c", b.shape)
+    n, d = b.shape
+    stride = _strided_rows(a, n, d, "a")
+    out = torch.empty_like(b)
+    check(_lib.load().kgat_add3_rows_f32(n, d, _ptr(a), stride, _ptr(b), _ptr(c), _ptr(out), _stream(b)), "kgat_add3_rows_f32")
+    return out
 
 
 def bi_interaction_bwd_pre(h_out, grad_a, grad_b, grad_norm, negative_slope, drop_p, seed, row0=0):
@@ -903,7 +917,7 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "transr_presort", "transr_adam_step", "TransRAdamState", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "add3_rows", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "transr_presort", "transr_adam_step", "TransRAdamState", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]
 

@@ -417,7 +417,15 @@ int kgat_gather_i32(int64_t n, const int32_t* index, const int32_t* in, int32_t*
  * otherwise).  Widths as kgat_bi_interaction_supported. */
 int kgat_bi_interaction_train_f32(int64_t n_rows, int d_in, int d_out, const float* H, const float* HN,
                                   const float* W2, float negative_slope, float drop_p, uint64_t seed, int64_t row0,
-                                  float* h_out, float* norm_out, int64_t norm_stride, kgat_stream_t stream);
+                                  float* h_out, float* norm_out, int64_t norm_stride, float* self_out,
+                                  int64_t self_stride, kgat_stream_t stream);
+/* (self_out / self_stride as in kgat_bi_interaction_mul_f32: the rows of H copied into a column slice of the readout
+ * on the way - the ego block of reference models.py:159,168, which the training stack wrote with a separate copy pass.)
+ * kgat_add3_rows_f32: out = (a + b) + c over n_rows x d, a being a column slice (rows of a_stride floats) of a wider
+ * matrix: the gradient arriving at the embedding table through Model.gnn's three paths (the ego block of the readout's
+ * gradient, the aggregated branch, the elementwise branch of layer 0) in one pass instead of two. */
+int kgat_add3_rows_f32(int64_t n_rows, int d, const float* a, int64_t a_stride, const float* b, const float* c, float* out,
+                       kgat_stream_t stream);
 /* Backward head of the same layer: with y = h_out saved by the forward,
  *   grad_z = [grad_a + grad_b + normalize_bwd(grad_norm; y)] * mask/(1-p) * LeakyReLU'(z)
  * (grad_a, grad_b: gradients arriving at h_out from the next layer, either may be NULL;

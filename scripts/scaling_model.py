@@ -2,9 +2,9 @@
 """The 1/2/4/8-GPU curve as a MODEL (points that cannot be measured on a one-GPU box are shipped as a
 model, labelled as such): per-rank local step time MEASURED on one GPU with the exchange stubbed out - every rank
 of a P-way destination partition in turn, P = 1, 2, 4, 8 - plus the link arithmetic of SURVEY 5 for the per-layer
-exchange.  Writes profiles/r05_scaling_model.json; every predicted field is named model_*.
+exchange.  Writes profiles/r06_scaling_model.json; every predicted field is named model_*.
 
-    python scripts/scaling_model.py [--configs 2,3,4] [--scale4 1.0] [--out profiles/r05_scaling_model.json]
+    python scripts/scaling_model.py [--configs 2,3,4] [--scale4 1.0] [--out profiles/r06_scaling_model.json]
 
 Link model (MI355X node: 8 GPUs fully connected, 7 xGMI links per GPU, 153.6 GB/s per link and direction):
   all-reduce (ring, the north star's exchange): every link carries 2 (P-1)/P x S      -> S x 2 (P-1)/P / 153.6 GB/s
@@ -36,7 +36,7 @@ ap.add_argument("--scale4", type=float, default=1.0, help="scale of configs[4] (
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--graphs", type=int, default=1,
                 help="1: also measure every rank's local step replayed as HIP graphs (partition.GraphedShardForward)")
-ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_scaling_model.json"))
+ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_scaling_model.json"))
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 K.enable_lazy_edge_weights()   # as bench.py's headline steps
