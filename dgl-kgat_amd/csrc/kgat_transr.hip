@@ -27,7 +27,7 @@ constexpr int kTrMaxDim = 128;    // d, k <= 128
 constexpr int kTrChunk = 64;      // samples per partial W-gradient block
 constexpr int kTrSmallSort = 8192;
 constexpr int kTrMaxRel = 4096;   // relations (chunk table built by one workgroup, 4 keys per thread)
-constexpr int kTrSlotBits = 14;   // row_slot entry = call tag << 14 | (sorted position + 1); 3 * batch <= 8192 < 2^14
+constexpr int kTrSlotBits = 14;   // row_slot word = call tag << 14 | (first sorted position of the row's run + 1); 3 * batch <= 8192 < 2^14
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -57,6 +57,9 @@ struct SortJob {
   int32_t n_keys;
   int32_t *offsets, *chunk_ptr;
   int2* chunks;
+  // (the KG phase's presort only) inv[o] = sorted position of input position o; run_len[p] = length of the run of
+  // equal keys that STARTS at sorted position p, 0 where p is not the first of its run
+  int32_t *inv = nullptr, *run_len = nullptr;
 };
 
 template <typename PT>
@@ -153,6 +156,16 @@ __device__ __forceinline__ void small_sort_body(const SortJob& job) {
     if (p < n) {
       order[p] = (int32_t)(s[p] & 8191u);
       if (sorted_keys) sorted_keys[p] = (int32_t)(s[p] >> 13);
+      if (job.inv) job.inv[(int32_t)(s[p] & 8191u)] = p;
+      if (job.run_len) {
+        const PT key = s[p] >> 13;
+        int32_t len = 0;
+        if (p == 0 || (s[p - 1] >> 13) != key) {
+          len = 1;
+          while (p + len < n && (s[p + len] >> 13) == key) ++len;
+        }
+        job.run_len[p] = len;
+      }
     }
     if (offsets) {
       int32_t prev = p == 0 ? -1 : (int32_t)(s[p - 1] >> 13);
@@ -233,13 +246,30 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(SortJob a, SortJob b, 
 // row with a dependent global load in every step, the second read a 256-byte-strided column per lane: 64 cache lines
 // per load instruction): 22 -> ~10 us for the launch.  The arithmetic and its order are unchanged: same bits.
 constexpr int kTrWLds = 64;
+struct TrStepMarks {
+  const int32_t* inv_pos = nullptr;     // non-NULL: the KG phase's form
+  const int32_t* sorted_ids = nullptr;
+  const int32_t* run_len = nullptr;
+  unsigned long long* row_slot = nullptr;
+  unsigned long long tag = 0ull;
+  int sample_blocks = 0;
+};
 template <bool GRAD, bool WLDS>
 __global__ __launch_bounds__(256) void transr_sample_kernel(
     int32_t batch, int d, int k, const int32_t* __restrict__ order, const int32_t* __restrict__ h,
     const int32_t* __restrict__ r, const int32_t* __restrict__ pt, const int32_t* __restrict__ nt,
     const float* __restrict__ ent, const float* __restrict__ W_R, const float* __restrict__ rel, float lambda,
     float* __restrict__ losses, float* __restrict__ GA, float* __restrict__ GR, float* __restrict__ DX,
-    float* __restrict__ XS) {
+    float* __restrict__ XS, const TrStepMarks mk = TrStepMarks{}) {
+  // the KG phase's form (mk.inv_pos given): workgroups behind the samples' tag the batch's entity rows in row_slot -
+  // one thread per sorted position; the first of a run writes call tag << 14 | position + 1 - and the samples' DX rows
+  // go to their SORTED positions (a row's contributions are then consecutive: the Adam launch sums them itself)
+  if (mk.inv_pos != nullptr && (int)blockIdx.x >= mk.sample_blocks) {
+    const int32_t q = ((int)blockIdx.x - mk.sample_blocks) * 256 + (int)threadIdx.x;
+    if (q < 3 * batch && mk.run_len[q] > 0)
+      mk.row_slot[mk.sorted_ids[q]] = (mk.tag << kTrSlotBits) | (unsigned long long)(q + 1);
+    return;
+  }
   __shared__ float s_x[256 / kWave][3][kTrMaxDim];
   __shared__ __attribute__((aligned(16))) float s_w[WLDS ? 256 / kWave : 1][WLDS ? kTrWLds * (kTrWLds + 1) : 1];
   const int lane = threadIdx.x % kWave, wv = threadIdx.x / kWave;
@@ -248,6 +278,9 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
   const int32_t b = order[s];
   const int32_t rr = r[b];
   const int32_t ids[3] = {h[b], pt[b], nt[b]};
+  // rows of DX: 3 b + v, or (KG phase) the sorted position of that entry of the id list
+  int32_t dxr[3] = {3 * b, 3 * b + 1, 3 * b + 2};
+  if (mk.inv_pos != nullptr) { dxr[0] = mk.inv_pos[3 * b]; dxr[1] = mk.inv_pos[3 * b + 1]; dxr[2] = mk.inv_pos[3 * b + 2]; }
   const float* W = W_R + (size_t)rr * d * k;
   float(*sx)[kTrMaxDim] = s_x[wv];
   float* sw = s_w[wv];
@@ -410,9 +443,9 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
       }
     }
     if (lane < d) {
-      DX[((size_t)3 * b + 0) * d + lane] = x0;
-      DX[((size_t)3 * b + 1) * d + lane] = x1;
-      DX[((size_t)3 * b + 2) * d + lane] = x2;
+      DX[(size_t)dxr[0] * d + lane] = x0;
+      DX[(size_t)dxr[1] * d + lane] = x1;
+      DX[(size_t)dxr[2] * d + lane] = x2;
     }
     return;
   }
@@ -425,9 +458,9 @@ __global__ __launch_bounds__(256) void transr_sample_kernel(
       x1 = fmaf(sx[1][j], w, x1);
       x2 = fmaf(sx[2][j], w, x2);
     }
-    DX[((size_t)3 * b + 0) * d + i] = x0;
-    DX[((size_t)3 * b + 1) * d + i] = x1;
-    DX[((size_t)3 * b + 2) * d + i] = x2;
+    DX[(size_t)dxr[0] * d + i] = x0;
+    DX[(size_t)dxr[1] * d + i] = x1;
+    DX[(size_t)dxr[2] * d + i] = x2;
   }
 }
 
@@ -484,14 +517,44 @@ __device__ __forceinline__ void transr_stage_rows(float* __restrict__ dst, int s
   }
 }
 
+// columns [16 ti, 16 ti + 16) of `n_rows` rows, for the row tiles ti = ts, ts + TS, ... of a split block
+__device__ __forceinline__ void transr_stage_col_tiles(float* __restrict__ dst, int stride, const float* __restrict__ src,
+                                                       int width, int n_rows, int ts, int TS) {
+  const int n_ti = (width / 16 - ts + TS - 1) / TS;       // row tiles of this block
+  const int per_row = 4 * n_ti;                            // float4 pieces per row
+  const int n4 = n_rows * per_row;
+  constexpr int UB = 6;
+  for (int base = threadIdx.x; base < n4; base += 256 * UB) {
+    float4 v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      int f = base + 256 * u;
+      f = f < n4 ? f : n4 - 1;
+      const int row = f / per_row, pc = f - row * per_row;
+      v[u] = *reinterpret_cast<const float4*>(src + (size_t)row * width + 16 * (ts + TS * (pc >> 2)) + 4 * (pc & 3));
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int f = base + 256 * u;
+      if (f < n4) {
+        const int row = f / per_row, pc = f - row * per_row;
+        *reinterpret_cast<float4*>(dst + (size_t)row * stride + 16 * (ts + TS * (pc >> 2)) + 4 * (pc & 3)) = v[u];
+      }
+    }
+  }
+}
+
+// ts / TS: the block computes the output tiles of the row tiles ti = ts, ts + TS, ... only (MFMA form): it stages
+// those columns of x, all of g, and - split 0 alone - the relation rows
 __device__ __forceinline__ void transr_stage_load(float* __restrict__ sx, float* __restrict__ sg, float* __restrict__ sr,
                                                   const TrStageGeom& g, int d, int k, int32_t s0, int ns, int fill,
                                                   const float* __restrict__ XS, const float* __restrict__ GA,
-                                                  const float* __restrict__ GR) {
+                                                  const float* __restrict__ GR, int ts = 0, int TS = 1) {
   const int kr = (k + 3) / 4 * 4;
-  transr_stage_rows(sx, g.sxs, XS + (size_t)3 * s0 * d, d, 3 * ns);
+  if (TS > 1) transr_stage_col_tiles(sx, g.sxs, XS + (size_t)3 * s0 * d, d, 3 * ns, ts, TS);
+  else transr_stage_rows(sx, g.sxs, XS + (size_t)3 * s0 * d, d, 3 * ns);
   transr_stage_rows(sg, g.sgs, GA + (size_t)3 * s0 * k, k, 3 * ns);
-  transr_stage_rows(sr, kr, GR + (size_t)s0 * k, k, ns);
+  if (ts == 0) transr_stage_rows(sr, kr, GR + (size_t)s0 * k, k, ns);
   // zero rows behind the last sample (the MFMA form rounds the sample count up to a multiple of four)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int hl = lane >> 5, c4 = 4 * (lane & 31);
@@ -577,7 +640,8 @@ typedef float trx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void transr_wgrad_mfma_body(
     float* s_dyn, const TrStageGeom g, int bx, int d, int k, int n_rel, const int32_t* __restrict__ seg,
     const float* __restrict__ XS, const float* __restrict__ GA, const float* __restrict__ GR,
-    const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part) {
+    const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part, int ts = 0,
+    int TS = 1) {
   if ((int32_t)bx >= chunk_ptr[n_rel]) return;
   const int2 ck = chunks[bx];
   const int32_t beg = ck.y, end = beg + kTrChunk < seg[ck.x + 1] ? beg + kTrChunk : seg[ck.x + 1];
@@ -587,7 +651,8 @@ __device__ __forceinline__ void transr_wgrad_mfma_body(
   float* const sr = sg + (size_t)g.st * 3 * g.sgs;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int tk = k / 16, n_tiles = (d / 16) * tk;
+  // (a split block: the row tiles ti = ts, ts + TS, ... and every column tile)
+  const int tk = k / 16, n_tiles = ((d / 16 - ts + TS - 1) / TS) * tk;
   constexpr int MAXT = (kTrMaxDim / 16) * (kTrMaxDim / 16) / 4;  // tiles per wavefront at the largest size
   trx4 acc[MAXT];
 #pragma unroll
@@ -598,13 +663,13 @@ __device__ __forceinline__ void transr_wgrad_mfma_body(
     const int ng = (ns + 3) >> 2;                    // groups of four samples
     const int fill = 4 * ng < g.st ? 4 * ng : g.st;  // (g.st is a multiple of 4)
     __syncthreads();
-    transr_stage_load(sx, sg, sr, g, d, k, s0, ns, fill, XS, GA, GR);
+    transr_stage_load(sx, sg, sr, g, d, k, s0, ns, fill, XS, GA, GR, ts, TS);
     __syncthreads();
 #pragma unroll
     for (int o = 0; o < MAXT; ++o) {
       const int t = w + 4 * o;
       if (t >= n_tiles) break;   // (wave-uniform)
-      const int ti = t / tk, tj = t - ti * tk;
+      const int tl = t / tk, tj = t - tl * tk, ti = ts + TS * tl;
       const float* px = sx + (size_t)(3 * lq) * g.sxs + 16 * ti + li;
       const float* pg = sg + (size_t)(3 * lq) * g.sgs + 16 * tj + li;
       for (int gb = 0; gb < ng; gb += 4) {
@@ -625,7 +690,7 @@ __device__ __forceinline__ void transr_wgrad_mfma_body(
           }
       }
     }
-    if (threadIdx.x < k)
+    if (ts == 0 && threadIdx.x < k)
       for (int q = 0; q < ns; ++q) racc += sr[(size_t)q * kr + threadIdx.x];
   }
   const int dk = d * k;
@@ -634,12 +699,12 @@ __device__ __forceinline__ void transr_wgrad_mfma_body(
   for (int o = 0; o < MAXT; ++o) {
     const int t = w + 4 * o;
     if (t >= n_tiles) break;
-    const int ti = t / tk, tj = t - ti * tk;
+    const int tl = t / tk, tj = t - tl * tk, ti = ts + TS * tl;
     // acc[o][r] = sum over samples of x[16 ti + 4 lq + r] * g[16 tj + li]
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + 4 * lq + r) * k + 16 * tj + li] = acc[o][r];
   }
-  if (threadIdx.x < k) out[dk + threadIdx.x] = racc;
+  if (ts == 0 && threadIdx.x < k) out[dk + threadIdx.x] = racc;
 }
 
 // ---- ordered reductions: block r < n_rel: dW[r] and drel[r] = sums of r's partial chunks (they are
@@ -688,9 +753,7 @@ __device__ __forceinline__ void transr_scatter_body(int bx, int32_t n_rows, int 
                                                     const int32_t* __restrict__ row_order,
                                                     const float* __restrict__ DX,
                                                     float* __restrict__ grad_ent,
-                                                    const float* __restrict__ grad_scale,
-                                                    unsigned long long* __restrict__ row_slot = nullptr,
-                                                    unsigned long long tag = 0ull) {
+                                                    const float* __restrict__ grad_scale) {
   const int sl = threadIdx.x & 15;
   const int32_t p = bx * 16 + (threadIdx.x >> 4);
   if (p >= n_rows) return;
@@ -771,12 +834,9 @@ __device__ __forceinline__ void transr_scatter_body(int bx, int32_t n_rows, int 
     if (i < d) {
       float4 o = acc[c];
       if (grad_scale) { o.x *= gs; o.y *= gs; o.z *= gs; o.w *= gs; }
-      // dense form: row `id` of the (zeroed) N x d gradient; compact form (row_slot given): row p of a 3B x d
-      // buffer - p = the run's first sorted position - found again through row_slot[id]
-      *reinterpret_cast<float4*>(grad_ent + (size_t)(row_slot ? p : id) * d + i) = o;
+      *reinterpret_cast<float4*>(grad_ent + (size_t)id * d + i) = o;
     }
   }
-  if (row_slot && sl == 0) row_slot[id] = (tag << kTrSlotBits) | (unsigned long long)(p + 1);
 }
 
 // The launches of the backward half.  The weight-gradient partials (or, when the forward half ran in an earlier call,
@@ -788,8 +848,6 @@ struct TrScatterArgs {
   const float* DX;
   float* grad_ent;
   const float* grad_scale;
-  unsigned long long* row_slot;   // non-NULL: compact rows (see transr_scatter_body)
-  unsigned long long tag;
 };
 
 __global__ __launch_bounds__(256) void transr_wgrad_partial_kernel(
@@ -826,19 +884,24 @@ __global__ __launch_bounds__(256) void transr_reduce_kernel(int n_first, int ny,
 //    front (the samplers are edge-uniform draws, dataset.py:234-323), so ALL of them are sorted by ONE launch
 //    (transr_presort_kernel: two workgroups per batch, 3,282 of them on 256 CUs) instead of 13-18 us on an idle chip
 //    in front of every iteration;
-//  * no dense entity gradient.  The reference's optimiser is torch's dense Adam - every row of the table moves in
-//    every step - but at most 3 B of the N rows have a non-zero gradient.  The sorted scatter writes the <= 3 B summed
-//    rows into a compact buffer and marks them in `row_slot` (one 64-bit word per node: call tag << 14 | position + 1;
-//    stale words carry an older tag, so nothing is ever cleared); the Adam launch streams p, m, v of every row and
-//    takes g = 0 unless the row's word carries this call's tag.  Gone: the 41 MB zero fill, the 41 MB gradient read.
+//  * no dense entity gradient, and no scatter launch.  The reference's optimiser is torch's dense Adam - every row of
+//    the table moves in every step - but at most 3 B of the N rows have a non-zero gradient.  The per-sample kernel
+//    writes its three gradient rows at their SORTED positions (the presort also emits the inverse permutation and the
+//    run lengths), so the contributions of one entity are consecutive rows; workgroups riding in the same launch tag the
+//    batch's entities in `row_slot` (one 64-bit word per node: call tag << 14 | first sorted position + 1; stale words
+//    carry an older tag, so nothing is ever cleared).  The Adam launch streams p, m, v of every row and takes g = 0
+//    unless the row's word carries this call's tag - then g = the sum of the run's rows, in sorted order (the order of
+//    transr_scatter_body: same bits).  Gone: the 41 MB zero fill, the 41 MB gradient read, and the sorted-scatter
+//    workgroups, which were the critical path of the middle launch (32 of its 33 us: 128 registers of rows in flight per
+//    lane = one wavefront per SIMD; profiles/r06_kg_wgrad_ablation.txt).
 //    Same arithmetic on the same values: the bits of torch.optim.Adam on the dense gradient;
 //  * the ordered reduction of the weight-gradient partials happens where the sum is consumed: the Adam blocks of W_R
 //    and of the relation table add a relation's partials in chunk order (the reduction launch's order) on the way.
-// Launches per iteration: per-sample kernel -> weight-gradient partials + scatter + loss -> Adam.
+// Launches per iteration: per-sample kernel (+ row tags) -> weight-gradient partials + loss -> Adam (+ gradient-row sums).
 
 // per-batch block of the presort's output (offsets in bytes, 256-byte aligned)
 struct TrSortedLayout {
-  size_t order, seg, chunk_ptr, chunks, sorted_ids, row_order, bytes;
+  size_t order, seg, chunk_ptr, chunks, sorted_ids, row_order, inv_pos, run_len, bytes;
 };
 static TrSortedLayout transr_sorted_layout(int64_t batch, int n_rel) {
   const size_t b = (size_t)(batch > 0 ? batch : 1);
@@ -851,6 +914,8 @@ static TrSortedLayout transr_sorted_layout(int64_t batch, int n_rel) {
   l.chunks = w; w += align_up(n_part * 8, 256);
   l.sorted_ids = w; w += align_up(3 * b * 4, 256);
   l.row_order = w; w += align_up(3 * b * 4, 256);
+  l.inv_pos = w; w += align_up(3 * b * 4, 256);
+  l.run_len = w; w += align_up(3 * b * 4, 256);
   l.bytes = w;
   return l;
 }
@@ -877,25 +942,28 @@ __global__ __launch_bounds__(1024) void transr_presort_kernel(TrPresortArgs a) {
   } else {                       // the 3 B entity ids (head, positive tail, negative tail of every sample)
     job = SortJob{3 * a.batch, a.id_bits, a.h + o, a.pos_t + o, a.neg_t + o,
                   reinterpret_cast<int32_t*>(blk + a.lay.row_order), reinterpret_cast<int32_t*>(blk + a.lay.sorted_ids), 0,
-                  nullptr, nullptr, nullptr};
+                  nullptr, nullptr, nullptr,
+                  reinterpret_cast<int32_t*>(blk + a.lay.inv_pos), reinterpret_cast<int32_t*>(blk + a.lay.run_len)};
   }
   small_sort_body<PT>(job);
 }
 
-// second launch of an iteration: blocks [0, n_part) the weight-gradient partials, the next scatter_blocks the compact
-// entity-gradient rows, the last one the loss
+// second launch of an iteration: blocks [0, n_part * n_split) the weight-gradient partials - a 64-sample chunk's
+// d/16 x k/16 output tiles shared by n_split workgroups, each taking every n_split-th row tile (it stages those columns
+// of x only: 60 instead of 112 KB, and a quarter of the MFMAs; the chunk's staging round trip and its MFMA loop were
+// 9 + 8 us of a 22-us launch that 74 of 256 CUs took part in) -, the last block the loss
 __global__ __launch_bounds__(256) void transr_wgrad_step_kernel(
-    int n_part, int scatter_blocks, int32_t batch, int d, int k, int n_rel, const int32_t* __restrict__ seg,
+    int n_part, int n_split, int32_t batch, int d, int k, int n_rel, const int32_t* __restrict__ seg,
     const float* __restrict__ XS, const float* __restrict__ GA, const float* __restrict__ GR,
     const int32_t* __restrict__ chunk_ptr, const int2* __restrict__ chunks, float* __restrict__ part,
-    const float* __restrict__ losses, float* __restrict__ loss, TrStageGeom geom, TrScatterArgs sc) {
+    const float* __restrict__ losses, float* __restrict__ loss, TrStageGeom geom) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   const int bx = (int)blockIdx.x;
-  if (bx < n_part) {
-    if (d % 16 == 0 && k % 16 == 0) transr_wgrad_mfma_body(s_dyn, geom, bx, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
+  if (bx < n_part * n_split) {
+    if (d % 16 == 0 && k % 16 == 0)
+      transr_wgrad_mfma_body(s_dyn, geom, bx / n_split, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part, bx % n_split,
+                             n_split);
     else transr_wgrad_partial_body(s_dyn, geom, bx, d, k, n_rel, seg, XS, GA, GR, chunk_ptr, chunks, part);
-  } else if (bx < n_part + scatter_blocks) {
-    transr_scatter_body(bx - n_part, sc.n_rows, d, sc.sorted_ids, sc.row_order, sc.DX, sc.grad_ent, nullptr, sc.row_slot, sc.tag);
   } else {
     transr_reduce_body(n_rel, 0, 1, batch, d, k, n_rel, chunk_ptr, part, losses, nullptr, nullptr, loss, nullptr);
   }
@@ -911,7 +979,8 @@ struct TrAdamArgs {
   int d, k, dk;
   const unsigned long long* row_slot;
   unsigned long long tag;
-  const float* Gc;
+  const float* DXs;          // the samples' gradient rows at their sorted positions
+  const int32_t* run_len;    // run_len[p]: rows of the run that starts at sorted position p
   const float* part;
   const int32_t* chunk_ptr;
 };
@@ -934,8 +1003,19 @@ __global__ __launch_bounds__(256) void transr_adam_kernel(TrAdamArgs a, float w1
       const int64_t row = i / a.d;
       const unsigned long long slot = a.row_slot[row];
       if ((slot >> kTrSlotBits) == a.tag) {
+        // the row's gradient: its run of the sorted gradient rows, added in sorted order from 0 (transr_scatter_body's
+        // order), four rows requested per look (a hub entity heads dozens of samples of an edge-uniform batch)
         const int64_t pr = (int64_t)(slot & ((1ull << kTrSlotBits) - 1ull)) - 1;
-        gg = *reinterpret_cast<const float4*>(a.Gc + pr * a.d + (i - row * a.d));
+        const int len = a.run_len[pr];
+        const float* src = a.DXs + pr * a.d + (i - row * a.d);
+        for (int q = 0; q < len; q += 4) {
+          float4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(src + (size_t)(q + u < len ? q + u : len - 1) * a.d);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q + u < len) { gg.x += x[u].x; gg.y += x[u].y; gg.z += x[u].z; gg.w += x[u].w; }
+        }
       }
     } else {
       const int width = t == 1 ? a.dk : a.k;
@@ -977,7 +1057,7 @@ static size_t transr_step_workspace_bytes(int64_t batch, int d, int k, int n_rel
   w += align_up(b * 4, 256);                             // losses
   w += align_up(3 * b * (size_t)k * 4, 256);             // GA
   w += align_up(b * (size_t)k * 4, 256);                 // GR
-  w += 3 * align_up(3 * b * (size_t)d * 4, 256);         // DX, XS, compact entity-gradient rows
+  w += 2 * align_up(3 * b * (size_t)d * 4, 256);         // DX (rows at their sorted positions), XS
   w += align_up(n_part * ((size_t)d * k + k) * 4, 256);  // W / relation gradient partials
   return w;
 }
@@ -1055,8 +1135,8 @@ static int transr_run(int stage, int64_t n_nodes, int n_rel, int d, int k, int64
   const bool fwd = (stage & kTrForward) != 0, bwd = (stage & kTrBackward) != 0 && want_grad;
   const SortJob rel_job = {B, rel_bits, r, nullptr, nullptr, order, nullptr, (int32_t)n_rel, seg, chunk_ptr, chunks};
   const SortJob id_job = {3 * B, id_bits, h, pos_t, neg_t, row_order, sorted_ids, 0, nullptr, nullptr, nullptr};
-  const TrScatterArgs sc = {3 * B, sorted_ids, row_order, DX, grad_ent, grad_scale, nullptr, 0ull};
-  const TrScatterArgs no_sc = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0ull};
+  const TrScatterArgs sc = {3 * B, sorted_ids, row_order, DX, grad_ent, grad_scale};
+  const TrScatterArgs no_sc = {0, nullptr, nullptr, nullptr, nullptr, nullptr};
   const unsigned scatter_blocks = (unsigned)((3 * B + 15) / 16);
   const int64_t n_zero = (int64_t)n_nodes * d;
   // first launch: the sort(s) this call needs + the zero fill of the dense entity gradient
@@ -1228,23 +1308,27 @@ int kgat_transr_adam_step_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   const int32_t* chunk_ptr = reinterpret_cast<const int32_t*>(blk + lay.chunk_ptr);
   const int2* chunks = reinterpret_cast<const int2*>(blk + lay.chunks);
   const int32_t* sorted_ids = reinterpret_cast<const int32_t*>(blk + lay.sorted_ids);
-  const int32_t* row_order = reinterpret_cast<const int32_t*>(blk + lay.row_order);
+  const int32_t* inv_pos = reinterpret_cast<const int32_t*>(blk + lay.inv_pos);
+  const int32_t* run_len = reinterpret_cast<const int32_t*>(blk + lay.run_len);
   Carver cv(workspace);
   float* losses = cv.take<float>((size_t)B);
   float* GA = cv.take<float>((size_t)3 * B * k);
   float* GR = cv.take<float>((size_t)B * k);
   float* DX = cv.take<float>((size_t)3 * B * d);
   float* XS = cv.take<float>((size_t)3 * B * d);
-  float* Gc = cv.take<float>((size_t)3 * B * d);
   float* part = cv.take<float>((size_t)n_part * ((size_t)d * k + k));
 
-  const unsigned sb = (unsigned)((B + 3) / 4);
+  const unsigned sb = (unsigned)((B + 3) / 4), mark_blocks = (unsigned)((3 * B + 255) / 256);
+  const TrStepMarks mk = {inv_pos, sorted_ids, run_len, reinterpret_cast<unsigned long long*>(row_slot),
+                          (unsigned long long)tag, (int)sb};
   if (d <= kTrWLds && k <= kTrWLds)
-    hipLaunchKernelGGL((transr_sample_kernel<true, true>), dim3(sb), dim3(256), 0, st, B, d, k, order, h, r, pos_t, neg_t,
-                       (const float*)ent, (const float*)W_R, (const float*)rel, reg_lambda, losses, GA, GR, DX, XS);
+    hipLaunchKernelGGL((transr_sample_kernel<true, true>), dim3(sb + mark_blocks), dim3(256), 0, st, B, d, k, order, h, r,
+                       pos_t, neg_t, (const float*)ent, (const float*)W_R, (const float*)rel, reg_lambda, losses, GA, GR, DX,
+                       XS, mk);
   else
-    hipLaunchKernelGGL((transr_sample_kernel<true, false>), dim3(sb), dim3(256), 0, st, B, d, k, order, h, r, pos_t, neg_t,
-                       (const float*)ent, (const float*)W_R, (const float*)rel, reg_lambda, losses, GA, GR, DX, XS);
+    hipLaunchKernelGGL((transr_sample_kernel<true, false>), dim3(sb + mark_blocks), dim3(256), 0, st, B, d, k, order, h, r,
+                       pos_t, neg_t, (const float*)ent, (const float*)W_R, (const float*)rel, reg_lambda, losses, GA, GR, DX,
+                       XS, mk);
   KGAT_CHECK_LAUNCH("transr_sample");
   const size_t lds = transr_stage_bytes(d, k);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(transr_wgrad_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1252,12 +1336,10 @@ int kgat_transr_adam_step_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
     set_error("transr_adam_step: cannot reserve %zu bytes of LDS", lds);
     return KGAT_E_HIP;
   }
-  const int scatter_blocks = (3 * B + 15) / 16;
-  const TrScatterArgs sc = {3 * B, sorted_ids, row_order, DX, Gc, nullptr, reinterpret_cast<unsigned long long*>(row_slot),
-                            (unsigned long long)tag};
-  hipLaunchKernelGGL(transr_wgrad_step_kernel, dim3((unsigned)(n_part + scatter_blocks + 1)), dim3(256), lds, st, n_part,
-                     scatter_blocks, B, d, k, n_rel, seg, (const float*)XS, (const float*)GA, (const float*)GR, chunk_ptr, chunks,
-                     part, (const float*)losses, loss, transr_stage_geom(d, k), sc);
+  const int n_split = (d % 16 == 0 && k % 16 == 0) ? (d / 16 < 4 ? d / 16 : 4) : 1;
+  hipLaunchKernelGGL(transr_wgrad_step_kernel, dim3((unsigned)(n_part * n_split + 1)), dim3(256), lds, st, n_part, n_split, B,
+                     d, k, n_rel, seg, (const float*)XS, (const float*)GA, (const float*)GR, chunk_ptr, chunks, part,
+                     (const float*)losses, loss, transr_stage_geom(d, k));
   KGAT_CHECK_LAUNCH("transr_wgrad_step");
   TrAdamArgs a;
   const int64_t sizes[3] = {(int64_t)n_nodes * d, (int64_t)n_rel * d * k, (int64_t)n_rel * k};
@@ -1277,7 +1359,7 @@ int kgat_transr_adam_step_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t 
   a.d = d; a.k = k; a.dk = d * k;
   a.row_slot = reinterpret_cast<const unsigned long long*>(row_slot);
   a.tag = (unsigned long long)tag;
-  a.Gc = Gc; a.part = part; a.chunk_ptr = chunk_ptr;
+  a.DXs = DX; a.run_len = run_len; a.part = part; a.chunk_ptr = chunk_ptr;
   hipLaunchKernelGGL(transr_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)eps);
   KGAT_CHECK_LAUNCH("transr_adam");

@@ -500,13 +500,15 @@ int kgat_transr_backward_f32(int64_t n_nodes, int n_rel, int d, int k, int64_t b
  * block: the loss (1 float at `loss`) and the step of torch.optim.Adam on the three parameters the loss reaches -
  * ent (n_nodes x d), W_R (n_rel x d x k), rel (n_rel x k), updated IN PLACE with their moments (`exp_avg_host`,
  * `exp_avg_sq_host`: HOST arrays of three device pointers in that order; `steps_host`: the three step counts AFTER
- * this step).  Dense semantics as kgat_adam_step_f32 (every row of the table moves), without a dense gradient: the
- * <= 3 x batch summed gradient rows go to a compact buffer and are found again through `row_slot`, n_nodes 64-bit
- * words owned by the caller - zero before the first call, never to be cleared - in which a word is valid for the call
- * whose `tag` it carries: pass a tag in [1, 2^50) that differs from every earlier call's on the same row_slot (a
- * counter).  The bits of kgat_transr_loss_grad_f32 followed by kgat_adam_step_f32, i.e. of the reference's
- * loss.backward(); optimizer.step().  All pointers 16-byte aligned.  Launches: per-sample kernel, weight-gradient
- * partials + gradient rows + loss, Adam. */
+ * this step).  Dense semantics as kgat_adam_step_f32 (every row of the table moves), without a dense gradient and
+ * without a scatter launch: the per-sample kernel writes its three gradient rows at their SORTED positions (the presort
+ * also emits the inverse permutation and the run lengths), workgroups in the same launch tag the batch's entities in
+ * `row_slot`, n_nodes 64-bit words owned by the caller - zero before the first call, never to be cleared - in which a
+ * word is valid for the call whose `tag` it carries (pass a tag in [1, 2^50) that differs from every earlier call's on
+ * the same row_slot: a counter), and the Adam launch takes g = 0 for an untagged row and the sum of the row's run, in
+ * sorted order, for a tagged one.  The bits of kgat_transr_loss_grad_f32 followed by kgat_adam_step_f32, i.e. of the
+ * reference's loss.backward(); optimizer.step().  All pointers 16-byte aligned.  Launches: per-sample kernel (+ tags),
+ * weight-gradient partials (a chunk's output tiles shared by up to four workgroups) + loss, Adam. */
 size_t kgat_transr_sorted_bytes(int64_t batch, int n_rel);
 int kgat_transr_presort_f32(int64_t n_nodes, int n_rel, int64_t n_batches, int64_t batch, const int32_t* h,
                             const int32_t* r, const int32_t* pos_t, const int32_t* neg_t, void* sorted,

@@ -268,7 +268,7 @@ def test_planted_structure_recall_rises(dev, capsys):
     a user's held-out items share a KG attribute with its training items).  If the gradients (fused BPR / TransR /
     aggregation backward), the optimiser (one-launch Adam) and the attention refresh compose, recall@20 on the held-out
     interactions must leave the 20 / n_items = 0.02 of a random ranking within three short epochs; a sign error, a
-    dropped gradient or a stale attention leaves it there (measured round 6: 0.022 -> 0.06 / 0.16 / 0.26)."""
+    dropped gradient or a stale attention leaves it there (measured round 6: 0.022 -> 0.040 / 0.076 / 0.130)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
