@@ -12,7 +12,7 @@ host clock between two synchronisations (``--log_json`` keeps the per-epoch reco
 in eval mode (the reference never leaves training mode, so its evaluation passes through dropout).
 
   python examples/train_kgat.py --data_dir datasets/amazon-book/data      # reference file format
-  python examples/train_kgat.py --synthetic 1.0 --epochs 3               # amazon-book shape: 0.19 s per epoch
+  python examples/train_kgat.py --synthetic 1.0 --epochs 3               # amazon-book shape: 0.17 s per epoch
   python examples/train_kgat.py --planted --epochs 12 --lr 0.03 --batch_size 512 --batch_size_kg 512 --eval_before
                                                                           # planted structure: recall@20 must rise
   python examples/train_kgat.py --synthetic 0.01 --gpus 2                # CF phase on destination shards
