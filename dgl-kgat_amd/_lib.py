@@ -78,6 +78,7 @@ SIGNATURES = {
     "kgat_bi_interaction_train_f32": (_i32, [_i64, _i32, _i32, _p, _p, _p, C.c_float, C.c_float, C.c_uint64, _i64, _p,
                                              _p, _i64, _p, _i64, _p]),
     "kgat_add3_rows_f32": (_i32, [_i64, _i32, _p, _i64, _p, _p, _p, _p]),
+    "kgat_sum_partials_f32": (_i32, [_i32, _p, _p, _p, _p, _p]),
     "kgat_bi_interaction_bwd_pre_f32": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_uint64, _i64,
                                                _p, _p]),
     "kgat_mul2_f32": (_i32, [_i64, _p, _p, _p, _p, _p, _p]),

@@ -208,12 +208,14 @@ class _GNNTrain(torch.autograd.Function):
             offs.append(offs[-1] + wd)
         g_a = g_b = None  # the two addends of the gradient arriving at hs[li + 1] from the layer above
         grad_w = [None] * n_l
+        pending = []
         for li in range(n_l - 1, -1, -1):
             gz = ops.bi_interaction_bwd_pre(hs[li + 1], g_a, g_b, grad_out[:, offs[li + 1]:offs[li + 2]], ctx.slope,
                                             ctx.drop_p, ctx.seed + li)
             if ctx.needs_input_grad[5 + li]:
                 if ops.bi_interaction_bwd_input_supported(hs[li].shape[1], gz.shape[1]):
-                    grad_w[li] = ops.bi_interaction_bwd_weight(gz, hs[li], hns[li])   # grad_z^T (h * h_N)
+                    # grad_z^T (h * h_N) as per-workgroup partials; every layer's set is summed by ONE launch at the end
+                    pending.append((li, ops.bi_interaction_bwd_weight(gz, hs[li], hns[li], want_partials=True)))
                 else:
                     grad_w[li] = tall_weight_grad(gz, hs[li] * hns[li])
             w_l = weights[li].detach().contiguous()
@@ -223,6 +225,9 @@ class _GNNTrain(torch.autograd.Function):
             else:
                 t, g_b = ops.mul2(gz @ w_l, hs[li], hns[li])
             g_a = ops.spmm(rev.indptr, rev.col, rev.row_of, t, w_rev)
+        if pending:
+            for (li, _), summed in zip(pending, ops.sum_partials([p_ for _, p_ in pending])):
+                grad_w[li] = summed
         grad_h0 = None
         if ctx.needs_input_grad[4]:
             g0 = grad_out[:, :ctx.widths[0]]

@@ -1051,6 +1051,75 @@ int kgat_bi_interaction_bwd_weight_f32(int64_t n_rows, int d_in, int d_out, cons
   return KGAT_E_UNSUPPORTED;
 }
 
+// out[s][e] = sum over the partials of set s, for up to four sets in ONE launch (the weight gradients of a stack's
+// layers: three torch reductions of 11 us each before).  Sixteen lanes share an output float4: lane j adds partials
+// j, j + 16, ... (eight loads in flight), then the sixteen sums are added in lane order by a fixed shuffle tree -
+// a fixed order of additions: bitwise reproducible.
+struct SumSets {
+  const float4* part[4];
+  float4* out[4];
+  int32_t n_part[4], n4[4];     // partials per set, float4 elements per partial
+  int32_t first_group[5];       // 16-lane groups of set s: [first_group[s], first_group[s + 1])
+  int n_sets;
+};
+__global__ __launch_bounds__(256) void sum_partials_kernel(SumSets a) {
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int j = threadIdx.x & 15;
+  if (grp >= a.first_group[a.n_sets]) return;
+  int s = 0;
+  while (s + 1 < a.n_sets && grp >= a.first_group[s + 1]) ++s;
+  const int32_t e = (int32_t)(grp - a.first_group[s]);
+  const float4* __restrict__ p = a.part[s] + e;
+  const int32_t np = a.n_part[s], n4 = a.n4[s];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t q0 = j; q0 < np; q0 += 16 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int32_t q = q0 + 16 * u;
+      v[u] = q < np ? p[(size_t)q * n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    acc.x += __shfl_down(acc.x, off, 16); acc.y += __shfl_down(acc.y, off, 16);
+    acc.z += __shfl_down(acc.z, off, 16); acc.w += __shfl_down(acc.w, off, 16);
+  }
+  if (j == 0) a.out[s][e] = acc;
+}
+
+int kgat_sum_partials_f32(int n_sets, const float* const* partials_host, float* const* out_host,
+                          const int64_t* n_partials_host, const int64_t* n_elems_host, kgat_stream_t stream) {
+  KGAT_CHECK_ARG(n_sets >= 0 && n_sets <= 4, "sum_partials: at most four sets per call");
+  if (n_sets == 0) return KGAT_OK;
+  KGAT_CHECK_ARG(partials_host && out_host && n_partials_host && n_elems_host, "sum_partials: null pointer");
+  SumSets a;
+  a.n_sets = 0;
+  int64_t groups = 0;
+  for (int s = 0; s < n_sets; ++s) {
+    KGAT_CHECK_ARG(n_partials_host[s] >= 1 && n_partials_host[s] < INT32_MAX && n_elems_host[s] >= 0 &&
+                       n_elems_host[s] % 4 == 0 && n_elems_host[s] / 4 < INT32_MAX, "sum_partials: set %d: bad sizes", s);
+    if (n_elems_host[s] == 0) continue;
+    KGAT_CHECK_ARG(partials_host[s] && out_host[s] &&
+                       ((reinterpret_cast<uintptr_t>(partials_host[s]) | reinterpret_cast<uintptr_t>(out_host[s])) & 15u) == 0,
+                   "sum_partials: set %d: null or misaligned pointer", s);
+    const int c = a.n_sets++;
+    a.part[c] = reinterpret_cast<const float4*>(partials_host[s]);
+    a.out[c] = reinterpret_cast<float4*>(out_host[s]);
+    a.n_part[c] = (int32_t)n_partials_host[s];
+    a.n4[c] = (int32_t)(n_elems_host[s] / 4);
+    a.first_group[c] = (int32_t)groups;
+    groups += n_elems_host[s] / 4;
+  }
+  if (a.n_sets == 0) return KGAT_OK;
+  a.first_group[a.n_sets] = (int32_t)groups;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+  KGAT_CHECK_LAUNCH("sum_partials");
+  return KGAT_OK;
+}
+
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
                   kgat_stream_t stream) {
   KGAT_CHECK_ARG(n >= 0 && n % 4 == 0, "mul2: length must be a multiple of 4");

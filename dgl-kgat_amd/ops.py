@@ -812,9 +812,30 @@ def bi_interaction_bwd_input(grad_z, W2, H, HN):
     return t, gb
 
 
-def bi_interaction_bwd_weight(grad_z, H, HN):
+def sum_partials(partial_sets):
+    """[(n_partials, ...) tensor, ...] -> [sum over dim 0, ...] for up to four sets in one launch
+    (kgat_sum_partials_f32; a fixed order of additions)."""
+    import ctypes as C
+    outs = []
+    for lo in range(0, len(partial_sets), 4):
+        sets = [_need(t, torch.float32, "partials") for t in partial_sets[lo:lo + 4]]
+        res = [torch.empty(t.shape[1:], dtype=torch.float32, device=t.device) for t in sets]
+        n = len(sets)
+        if any(t[0].numel() % 4 for t in sets):
+            raise ValueError("sum_partials: partial sizes must be multiples of 4 floats")
+        check(_lib.load().kgat_sum_partials_f32(n, (C.c_void_p * n)(*[t.data_ptr() for t in sets]),
+                                                (C.c_void_p * n)(*[r.data_ptr() for r in res]),
+                                                (C.c_int64 * n)(*[t.shape[0] for t in sets]),
+                                                (C.c_int64 * n)(*[t[0].numel() for t in sets]), _stream(sets[0])),
+              "kgat_sum_partials_f32")
+        outs += res
+    return outs
+
+
+def bi_interaction_bwd_weight(grad_z, H, HN, want_partials=False):
     """grad_W2 = grad_z^T (H * HN) (kgat_bi_interaction_bwd_weight_f32: per-workgroup partials over 64-row slabs, the
-    product formed on the way; the partials are added here in index order)."""
+    product formed on the way; the partials are added here in index order - or, want_partials=True, handed back for
+    ops.sum_partials, which sums several layers' sets in one launch)."""
     grad_z = _need(grad_z, torch.float32, "grad_z")
     n, d_out = grad_z.shape
     H = _need(H, torch.float32, "H")
@@ -827,7 +848,7 @@ def bi_interaction_bwd_weight(grad_z, H, HN):
     partials = torch.empty((nb, d_out, d_in), dtype=torch.float32, device=H.device)
     check(lib.kgat_bi_interaction_bwd_weight_f32(n, d_in, d_out, _ptr(grad_z), _ptr(H), _ptr(HN), _ptr(partials), nb,
                                                  _stream(H)), "kgat_bi_interaction_bwd_weight_f32")
-    return partials.sum(0)
+    return partials if want_partials else partials.sum(0)
 
 
 def mul2(a, b, c):
@@ -917,7 +938,7 @@ def sddmm_dot(src, dst, X, G):
 
 
 __all__ = ["csr_from_coo", "group_by_relation", "invert_permutation", "row_order_by_degree", "gather",
-           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "add3_rows", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "transr_presort", "transr_adam_step", "TransRAdamState", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
+           "att_score", "att_score_split", "att_score_split_supported", "att_score_folded_supported", "att_score_fused", "att_pack_records", "att_score_fused_supported", "fold_tiles", "fold_tile_cost", "bi_interaction_train", "add3_rows", "bi_interaction_bwd_pre", "bi_interaction_bwd_input", "bi_interaction_bwd_input_supported", "bi_interaction_bwd_weight", "sum_partials", "mul2", "dropout_keep_mask", "transr_loss_grad", "transr_supported", "transr_presort", "transr_adam_step", "TransRAdamState", "head_groups", "edge_softmax", "edge_softmax_bwd", "spmm", "spmm_workspace", "sddmm_dot",
            "bi_interaction", "bi_interaction_supported", "l2_normalize_rows", "readout_concat",
            "KGATLibraryError"]
 

@@ -451,6 +451,12 @@ int kgat_bi_interaction_bwd_input_f32(int64_t n_rows, int d_in, int d_out, const
 int64_t kgat_bi_interaction_bwd_weight_partials(int64_t n_rows);
 int kgat_bi_interaction_bwd_weight_f32(int64_t n_rows, int d_in, int d_out, const float* grad_z, const float* H,
                                        const float* HN, float* partials, int64_t n_partials, kgat_stream_t stream);
+/* out_s = the sum of set s's n_partials_s partials (each n_elems_s floats, a multiple of 4, back to back) for up to four
+ * sets in ONE launch - the weight gradients of a propagation stack's layers, whose partials
+ * kgat_bi_interaction_bwd_weight_f32 leaves to the caller.  HOST arrays of n_sets entries.  A fixed order of additions
+ * (sixteen strided lane sums, then a shuffle tree): bitwise reproducible; not the order of a sequential sum. */
+int kgat_sum_partials_f32(int n_sets, const float* const* partials_host, float* const* out_host,
+                          const int64_t* n_partials_host, const int64_t* n_elems_host, kgat_stream_t stream);
 /* ab = a * b and ac = a * c elementwise in one pass (n a multiple of 4). */
 int kgat_mul2_f32(int64_t n, const float* a, const float* b, const float* c, float* ab, float* ac,
                   kgat_stream_t stream);

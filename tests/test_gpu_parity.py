@@ -1632,3 +1632,44 @@ def test_gnn_train_fused_dropout(K, dev):
     a2 = m.gnn(g).detach()
     a3 = m.gnn(g).detach()
     assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+
+
+@pytest.mark.parametrize("n,d,wide", [(1000, 64, 176), (77, 16, 48), (4099, 128, 304), (5, 8, 8)])
+def test_add3_rows_and_training_ego_block(K, dev, n, d, wide):
+    """Round 6's two CF-step helpers: kgat_add3_rows_f32 = (a + b) + c with `a` a column slice of a wider matrix, equal
+    bit for bit to the two torch adds it replaces; and the ego block written by the TRAINING dense kernel (self_out of
+    kgat_bi_interaction_train_f32) = the layer's input rows, bit for bit, with the layer's other outputs unchanged."""
+    from dgl_kgat_amd import ops
+    gen = torch.Generator().manual_seed(n + d)
+    big = torch.randn(n, wide, generator=gen).to(dev)
+    b, c = torch.randn(n, d, generator=gen).to(dev), torch.randn(n, d, generator=gen).to(dev)
+    got = ops.add3_rows(big[:, :d], b, c)
+    ref = big[:, :d] + b
+    ref += c
+    assert torch.equal(got, ref)
+    if d in (16, 64, 128):
+        H, HN = torch.randn(n, d, generator=gen).to(dev), torch.randn(n, d, generator=gen).to(dev)
+        W2 = (torch.randn(d // 2 if d > 16 else 16, d, generator=gen) * 0.1).to(dev)
+        out_a = torch.full((n, wide), float("nan"), device=dev)
+        out_b = torch.full((n, wide), float("nan"), device=dev)
+        do = W2.shape[0]
+        h_a = ops.bi_interaction_train(H, HN, W2, 0.01, 0.2, 77, norm_out=out_a[:, d:d + do], self_out=out_a[:, :d])
+        h_b = ops.bi_interaction_train(H, HN, W2, 0.01, 0.2, 77, norm_out=out_b[:, d:d + do])
+        assert torch.equal(out_a[:, :d], H) and torch.isnan(out_b[:, :d]).all()
+        assert torch.equal(h_a, h_b) and torch.equal(out_a[:, d:d + do], out_b[:, d:d + do])
+
+
+def test_sum_partials_one_launch(K, dev):
+    """kgat_sum_partials_f32: several partial sets (the weight gradients of a stack's layers) summed by one launch -
+    against a float64 sum, bit for bit the same on a second call, set sizes off every grouping (1 ... 768 partials)."""
+    from dgl_kgat_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    sets = [torch.randn(768, 64, 64, generator=gen).to(dev), torch.randn(768, 32, 64, generator=gen).to(dev),
+            torch.randn(129, 16, 32, generator=gen).to(dev), torch.randn(1, 4, 4, generator=gen).to(dev),
+            torch.randn(17, 128, 128, generator=gen).to(dev)]
+    got = ops.sum_partials(sets)
+    again = ops.sum_partials(sets)
+    for t, g_, a_ in zip(sets, got, again):
+        ref = t.double().sum(0)
+        assert g_.shape == t.shape[1:] and torch.equal(g_, a_)
+        assert float((g_.double() - ref).abs().max()) <= 1e-6 * float(t.abs().sum(0).max())
