@@ -512,15 +512,12 @@ def train_leg(args, dev, g, n, n_rel, E, host_triplets):
         t["epoch_s"] = t["kg_s"] + t["attention_s"] + t["cf_s"] + t["eval_s"]
         return t
 
-    from dgl_kgat_amd import lazy as _lazy
-    lazy_before = _lazy._enabled
-    K.enable_lazy_edge_weights()   # (as examples/train_kgat.py: nothing in the loop reads the edge-id-ordered copy)
+    lazy_before = K.enable_lazy_edge_weights()   # (as examples/train_kgat.py: nothing in the loop reads the edge-id-ordered copy)
     try:
         one_epoch()                     # warm: buffers, the phase's workspaces
         epochs = [one_epoch() for _ in range(2)]
     finally:
-        K.enable_lazy_edge_weights(bool(lazy_before))
-        _lazy._enabled = lazy_before
+        K.enable_lazy_edge_weights(lazy_before)
     measured = min(epochs, key=lambda t: t["epoch_s"])
     kg_phase_ms = measured["kg_s"] / n_kg * 1e3
     model.train()

@@ -143,11 +143,14 @@ def _guard_legacy_to_dlpack(install=True):
 
 def enable(flag=True):
     """Turn the deferred edge-id-ordered attention on (or off) for this process; turning it on wraps the legacy
-    torch.utils.dlpack.to_dlpack so that a pending tensor is filled before it is exported."""
+    torch.utils.dlpack.to_dlpack so that a pending tensor is filled before it is exported.  ``flag=None`` returns to
+    "not decided by the process" (the environment's KGAT_LAZY_EDGE_WEIGHTS decides again).  Returns the PREVIOUS
+    setting (True / False / None), so a caller can restore it: ``prev = enable(True); ...; enable(prev)``."""
     global _enabled
-    _enabled = bool(flag)
-    _guard_legacy_to_dlpack(install=_enabled)
-    return _enabled
+    prev = _enabled
+    _enabled = None if flag is None else bool(flag)
+    _guard_legacy_to_dlpack(install=bool(_enabled))
+    return prev
 
 
 def enabled():
