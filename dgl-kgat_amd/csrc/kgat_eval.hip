@@ -37,19 +37,33 @@ __global__ __launch_bounds__(256) void eval_items_kmajor_kernel(int64_t n_items,
                                                                 const float* __restrict__ emb, int64_t emb_stride,
                                                                 const int32_t* __restrict__ item_ids,
                                                                 float* __restrict__ itemT) {
-  // one thread per (tile, k pair, lane): coalesced stores, gathered 4-byte loads (a 17 MB one-off per call)
+  // one thread per element of itemT: coalesced stores, gathered 4-byte loads (a 17 MB one-off per call).
+  // Layout (round 6): [tile][group of 8 k pairs][half of the group][lane][4 k pairs] - a lane's A operands of FOUR
+  // consecutive MFMAs are one 16-byte load, a wavefront's one contiguous KB (it was [tile][k pair][lane]: one 4-byte
+  // load per MFMA, and on this chip a vector-memory instruction costs the fp32 MFMA stream about as much issue time as
+  // an MFMA does - NOTEBOOK 3.2)
   const int64_t total = n_tiles * FP2 * 64;
   for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (int64_t)gridDim.x * 256) {
-    const int lane = (int)(x & 63);
-    const int64_t ts = x >> 6;
-    const int s = (int)(ts % FP2);
-    const int64_t tile = ts / FP2;
+    const int u4 = (int)(x & 3);
+    const int lane = (int)(x >> 2 & 63);
+    const int64_t tq = x >> 8;                       // (tile, group, half) = tile * (FP2 / 4) + quad of k pairs
+    const int s = (int)(tq % (FP2 / 4)) * 4 + u4;
+    const int64_t tile = tq / (FP2 / 4);
     const int64_t it = tile * kEvalTile + (lane & 31);
     const int k = 2 * s + (lane >> 5);
     float v = 0.f;
     if (it < n_items && k < F) v = emb[(size_t)item_ids[it] * emb_stride + k];
     itemT[x] = v;
   }
+}
+
+// A float as an unsigned integer with the same order (for atomicMax on a shared threshold) and back.
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
 }
 
 // "a ranks before b": score descending, position ascending
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t tile_lo,
     int64_t tile_hi, int n_lists, int list0, int use_tau0, const float* __restrict__ emb, int64_t emb_stride,
     const float* __restrict__ itemT, const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items,
-    int K, float* __restrict__ part_s, int32_t* __restrict__ part_i) {
+    int K, float* __restrict__ part_s, int32_t* __restrict__ part_i, unsigned* __restrict__ tau_shared) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ul = lane & 31, half = lane >> 5;
@@ -161,6 +175,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     tau_i = part_i[((size_t)up_c * n_lists) * K + K - 1];
   }
   int c_mine = 0;         // entries in the user's buffer (the same value in both lanes of the user)
+  // Round 6: the segments of a user's item range run side by side (one wavefront each), every one warming up its own
+  // K-th best: they now SHARE it.  tau_shared[user] holds the best K-th score any segment has published (atomicMax on
+  // order-preserving bits; zero-filled = below every float): K entries of some segment rank at or before it, so
+  // nothing that scores below it can be among the user's K best - a valid bound whenever it is read, however stale.
+  // A wavefront takes it over when it beats its own (ties on the score stay candidates: position "pad"), reads it
+  // once per tile group - requested at the end of a check, used by the next - and publishes after every prune.  The
+  // result is the exact top K either way; fewer candidates are appended and pruned on the way.
+  float sh_next = kNegInf;
+  auto adopt_shared = [&]() {
+    if (sh_next > tau_s) { tau_s = sh_next; tau_i = kIdxPad; }
+  };
 
   // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.  An entry's
   // place is the number of entries that rank before it (the order is total): n broadcast compares per lane instead
@@ -188,20 +213,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     const float ts = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), lk));
     const int ti = __builtin_amdgcn_readlane(i, lk);
     if (ul == v) {  // both lanes of the user
-      tau_s = keep == K ? ts : kNegInf;
-      tau_i = keep == K ? ti : kIdxPad;
+      // (never below what is already known: a shared bound may be ahead of this segment's own K-th best)
+      if (keep == K && (ts > tau_s || (ts == tau_s && ti < tau_i))) { tau_s = ts; tau_i = ti; }
       c_mine = keep;
     }
-    if (lane == 0) kept[v] = keep;
+    if (lane == 0) {
+      kept[v] = keep;
+      if (keep == K && tau_shared != nullptr) atomicMax(tau_shared + (u0 + v), ordered_bits(ts));
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
 
-  // A fragments: one coalesced 4-byte load per lane per MFMA.  The sweep is a flat sequence of steps (tile group,
-  // group of U k pairs); a step's loads are issued while the previous step's MFMAs run (two register buffers,
-  // the loop unrolled by two so that no buffer is copied).
+  // A fragments: one coalesced 16-byte load per lane per FOUR MFMAs (itemT's layout, above).  The sweep is a flat
+  // sequence of steps (tile group, group of U k pairs); a step's loads are issued while the previous step's MFMAs run
+  // (two register buffers, the loop unrolled by two so that no buffer is copied).
   constexpr int U = 8;
-  const float* a_base = itemT + lane;
+  typedef float floatx4 __attribute__((ext_vector_type(4)));
+  const floatx4* a_base = reinterpret_cast<const floatx4*>(itemT) + lane;
   const int KGR = FP2 / U;                                     // k groups per tile group (FP2 is a multiple of U)
   struct Pos { int64_t t0; int g; };
   auto advance = [&](Pos& p) { if (++p.g == KGR) { p.g = 0; p.t0 += kEvalNT; } };
@@ -211,9 +240,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
 #pragma unroll
     for (int t = 0; t < kEvalNT; ++t) {
       const int64_t tt = p.t0 + t < t_hi ? p.t0 + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
-      const float* ap = a_base + ((size_t)tt * FP2 + p.g * U) * 64;
+      const floatx4* ap = a_base + ((size_t)tt * KGR + p.g) * (U / 4) * 64;
 #pragma unroll
-      for (int u = 0; u < U; ++u) a[u][t] = ap[u * 64];
+      for (int q = 0; q < U / 4; ++q) {
+        const floatx4 v = ap[q * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[4 * q + c][t] = v[c];
+      }
     }
   };
   floatx16 acc[kEvalNT];
@@ -223,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   // acc[t][r]: user ul, item position 32 (t0 + t) + (r & 3) + 8 (r >> 2) + 4 half
   auto check = [&](int64_t t0) {
+    adopt_shared();
 #pragma unroll
     for (int t = 0; t < kEvalNT; ++t) {
       if (t0 + t >= t_hi) break;  // wave-uniform
@@ -277,6 +311,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
         __builtin_amdgcn_wave_barrier();
       }
     }
+    if (tau_shared != nullptr)   // for the next tile group's check (an L2 round trip behind that group's MFMAs)
+      sh_next = from_ordered_bits(__hip_atomic_load(tau_shared + up_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (past the L1)
   };
   auto compute = [&](const float (&a)[U][kEvalNT], const Pos& p) {
     if (p.t0 >= t_hi) return;
@@ -315,10 +351,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
       constexpr int j = J, g = j % KG, gn = (j + 1) % KG;                                                 \
       const int64_t tt = t0 + (j / KG) * kEvalNT, tn = t0 + ((j + 1) / KG) * kEvalNT;                     \
       issue(NXT, Pos{tn, gn});                                                                            \
+      /* the next step's sixteen loads go out HERE, ahead of this step's MFMAs: left to itself the scheduler sinks */ \
+      /* them between the MFMAs and waits for each a few instructions after issuing it (vmcnt 7-13: the latency of */ \
+      /* an L2 round trip per MFMA instead of per step)                                                            */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
       if (tt < t_hi) { /* wave-uniform */                                                                 \
         _Pragma("unroll") for (int u = 0; u < U; ++u)                                                     \
           _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[u][t], breg[g * U + u], acc[t], 0, 0, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         if (g == KG - 1) {                                                                                \
           check(tt);                                                                                      \
           _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
@@ -475,7 +516,7 @@ int kgat_eval_items_kmajor_f32(int64_t n_items, int F, const float* emb, int64_t
 size_t kgat_eval_workspace_bytes(int64_t n_users, int64_t n_items, int F, int K) {
   if (n_users <= 0 || n_items <= 0 || !kgat_eval_supported(F, K)) return 256;
   const EvalPlanH pl = eval_plan(n_users, n_items, F);
-  return 2 * align_up((size_t)n_users * pl.n_lists * K * 4, 256) + 256;
+  return 2 * align_up((size_t)n_users * pl.n_lists * K * 4, 256) + align_up((size_t)n_users * 4, 256) + 256;
 }
 
 int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t n_items, int F, const float* emb,
@@ -504,6 +545,7 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   Carver cv(workspace);
   float* part_s = cv.take<float>((size_t)n_users * pl.n_lists * K);
   int32_t* part_i = cv.take<int32_t>((size_t)n_users * pl.n_lists * K);
+  unsigned* tau_shared = cv.take<unsigned>((size_t)n_users);   // shared K-th best per user (order-preserving bits)
   const bool reg = eval_rows_in_registers(FP2);
   const size_t lds = EvalLds::per_wave_bytes(FP2, reg) * nw;
   const unsigned gx = (unsigned)((n_users + 32 * nw - 1) / (32 * nw));
@@ -517,7 +559,7 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
     }                                                                                                                 \
     hipLaunchKernelGGL((eval_topk_kernel<NW, KG_>), dim3(gx, (unsigned)(GY)), dim3(NW * 64), lds, st, n_users,        \
                        user_ids, n_items, FP2, F, (int64_t)(TLO), (int64_t)(THI), pl.n_lists, LIST0, TAU0, emb,      \
-                       emb_stride, itemT, train_ptr, train_items, K, part_s, part_i);                                \
+                       emb_stride, itemT, train_ptr, train_items, K, part_s, part_i, (GY) > 1 ? tau_shared : nullptr); \
   } while (0)
 #define KGAT_EVAL_LAUNCH_NW(GY, TLO, THI, LIST0, TAU0)                     \
   do {                                                                     \
@@ -526,6 +568,10 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
     else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0, GY, TLO, THI, LIST0, TAU0);   \
     else KGAT_EVAL_LAUNCH(1, 0, GY, TLO, THI, LIST0, TAU0);                \
   } while (0)
+  if (pl.seg > 1 && hipMemsetAsync(tau_shared, 0, (size_t)n_users * 4, st) != hipSuccess) {
+    set_error("eval_recall_ndcg: cannot clear the shared thresholds");
+    return KGAT_E_HIP;
+  }
   if (pl.sample_tiles) {
     KGAT_EVAL_LAUNCH_NW(1, 0, pl.sample_tiles, 0, 0);
     KGAT_CHECK_LAUNCH("eval_topk (sample)");
