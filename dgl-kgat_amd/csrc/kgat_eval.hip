@@ -20,6 +20,9 @@
 //
 // The order is total - (score descending, position ascending) - so the result does not depend on how
 // items were cut into tiles and segments: bitwise reproducible, equal to a stable descending sort.
+#include <functional>
+#include <queue>
+#include <vector>
 #include "kgat_common.h"
 
 namespace kgat {
@@ -101,6 +104,10 @@ __device__ __forceinline__ bool in_sorted(const int32_t* __restrict__ a, int32_t
   return false;
 }
 
+// tile boundaries of the grid's segments (a kernel argument): segment y sweeps tiles [b[y], b[y + 1])
+constexpr int kEvalMaxLists = 66;
+struct EvalBounds { int32_t b[kEvalMaxLists + 1]; };
+
 struct EvalLds {
   // per wavefront: cand_s / cand_i [32 users][kEvalCap], kept [32]; then (LDS form only) the users' rows [FP2][64]
   static __host__ __device__ size_t per_wave_bytes(int FP2, bool rows_in_registers = false) {
@@ -121,8 +128,8 @@ constexpr int kEvalRegKG = 11;    // F in (160, 176]: the 64 + 64 + 32 + 16 read
 // left to its default budget it kept 150 and spilled the users' rows to scratch)
 template <int NW, int KG>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(248))) void eval_topk_kernel(
-    int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, int64_t tile_lo,
-    int64_t tile_hi, int n_lists, int list0, int use_tau0, const float* __restrict__ emb, int64_t emb_stride,
+    int64_t n_users, const int32_t* __restrict__ user_ids, int64_t n_items, int FP2, int F, EvalBounds bounds,
+    const float* __restrict__ emb, int64_t emb_stride,
     const float* __restrict__ itemT, const int32_t* __restrict__ train_ptr, const int32_t* __restrict__ train_items,
     int K, float* __restrict__ part_s, int32_t* __restrict__ part_i, unsigned* __restrict__ tau_shared) {
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -163,17 +170,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // the segment's tiles: an even split of this launch's tile range over gridDim.y
-  const int n_seg = gridDim.y;
-  const int64_t t_lo = tile_lo + (tile_hi - tile_lo) * seg / n_seg, t_hi = tile_lo + (tile_hi - tile_lo) * (seg + 1) / n_seg;
+  // The segment's tiles (bounds, from the host's plan).  With a sample, segment 0 is the first few tiles - a short sweep
+  // whose K-th best, published through tau_shared, spares every other segment most of its warm-up (about
+  // K ln(1 + n_seg_items / sample) candidates per user and segment instead of K ln(n_seg_items / K)) - and the other
+  // segments split the rest.  Workgroups are dispatched x-fastest, so the sample segments of all users go out FIRST; a
+  // later segment that starts before its users' sample has finished just starts from what has been published so far
+  // (any published K-th best is a valid bound).  Round 6: this was a launch of its own - 0.9 ms of candidate handling
+  // with almost no MFMAs, 553 workgroups on 512 slots; as part of one grid it runs beside the other segments' MFMAs
+  // and nobody waits for its tail.
+  const int n_lists = gridDim.y;
+  const int64_t t_lo = bounds.b[seg], t_hi = bounds.b[seg + 1];
   float tau_s = kNegInf;  // the user's K-th best so far (score, position); -inf while fewer than K are held
   int tau_i = kIdxPad;
-  if (use_tau0) {
-    // the K-th best of the sample launch's list (list 0; (-inf, pad) if it found fewer than K): at least K
-    // entries rank at or before it, so nothing that ranks after it can be among the user's K best
-    tau_s = part_s[((size_t)up_c * n_lists) * K + K - 1];
-    tau_i = part_i[((size_t)up_c * n_lists) * K + K - 1];
-  }
   int c_mine = 0;         // entries in the user's buffer (the same value in both lanes of the user)
   // Round 6: the segments of a user's item range run side by side (one wavefront each), every one warming up its own
   // K-th best: they now SHARE it.  tau_shared[user] holds the best K-th score any segment has published (atomicMax on
@@ -183,6 +191,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   // once per tile group - requested at the end of a check, used by the next - and publishes after every prune.  The
   // result is the exact top K either way; fewer candidates are appended and pruned on the way.
   float sh_next = kNegInf;
+  if (tau_shared != nullptr)
+    sh_next = from_ordered_bits(__hip_atomic_load(tau_shared + up_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   auto adopt_shared = [&]() {
     if (sh_next > tau_s) { tau_s = sh_next; tau_i = kIdxPad; }
   };
@@ -197,11 +207,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     if (lane < n) { s = cand_s[v * kEvalCap + lane]; i = cand_i[v * kEvalCap + lane]; }
     const int32_t lo = __builtin_amdgcn_readlane(tr_lo, v), hi = __builtin_amdgcn_readlane(tr_hi, v);
     if (lane >= kp && lane < n && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
+    // (one 64-bit key per entry - the score's order-preserving bits above the complemented position: "ranks before"
+    //  is key > key, ONE compare per broadcast entry instead of three and their combination; the fp32 MFMA and the
+    //  vector ALU do not overlap on a SIMD, so every instruction here is taken from the other wavefront's sweep.
+    //  s + 0 maps -0 to +0, which the float compares treated as equal.)
+    const unsigned long long key = ((unsigned long long)ordered_bits(s + 0.f) << 32) | (unsigned)~i;
+    const unsigned key_lo = (unsigned)key, key_hi = (unsigned)(key >> 32);
     int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), j));
-      const int ij = __builtin_amdgcn_readlane(i, j);
-      rank += ranks_before(sj, ij, s, i) ? 1 : 0;
+    for (int j = 0; j < n; j += 4) {   // (lanes [n, 64) hold (-inf, pad): behind every real entry, so reading them is harmless)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)key_hi, j + jj) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)key_lo, j + jj);
+        rank += kj > key ? 1 : 0;
+      }
     }
     const int valid = __popcll(__ballot(i != kIdxPad));
     const int keep = valid < K ? valid : K;
@@ -333,47 +352,55 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     }
   };
   if constexpr (REG) {
-    // Two tile groups per loop iteration: 2 KG steps (tile group, k group) with compile-time k groups - the register
-    // index of the B operand - and compile-time buffer parity (KG is odd: the parity flips from one tile group to the
-    // next).  Step j's loads were issued during step j - 1; a group past the end re-reads the clamped last tile and
-    // is skipped by compute_r.
-    static_assert(KG == 11, "the step list below is written out for 2 x 11 steps");
-    // Two tile groups per loop iteration = 22 steps (tile group, k group) with compile-time k groups - the register
-    // index of the B operand - and compile-time buffer parity (KG is odd: the parity flips from one tile group to the
-    // next).  Step j's loads are issued during step j - 1 (a ring of three buffers, two steps ahead, measured the same:
-    // 9.51 vs 9.40 ms); a group past the end re-reads the clamped last tile and is skipped.
+    // Two tile groups per loop iteration = 44 half steps (tile group, k group, half of the k group) with compile-time
+    // k groups - the register index of the B operand.  A half step is two 16-byte loads per lane (four k pairs of both
+    // tiles) and eight MFMAs; its loads are issued THREE half steps ahead into a ring of four buffers (the registers of
+    // two whole-step buffers: one step ahead was 1,024 MFMA cycles, about the L2's latency under this load; three half
+    // steps are 1,536).  44 is a multiple of 4: the ring position of a half step is a compile-time constant.  A group
+    // past the end re-reads the clamped last tile and is skipped.
     // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
     //  per step - the index as an integral_constant - sent every captured array to scratch)
-    float a0[U][kEvalNT], a1[U][kEvalNT];
-    issue(a0, Pos{t_lo, 0});
-#define KGAT_EVAL_STEP(J, CUR, NXT)                                                                       \
+    static_assert(KG == 11 && U == 8, "the step list below is written out for 2 x 11 steps of 2 halves");
+    float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
+    auto issue_half = [&](float (&a)[4][kEvalNT], int64_t tg, int g, int q) {
+#pragma unroll
+      for (int t = 0; t < kEvalNT; ++t) {
+        const int64_t tt = tg + t < t_hi ? tg + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
+        const floatx4 v = a_base[(((size_t)tt * KG + g) * 2 + q) * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c][t] = v[c];
+      }
+    };
+    issue_half(h0, t_lo, 0, 0);
+    issue_half(h1, t_lo, 0, 1);
+    issue_half(h2, t_lo, 1, 0);
+#define KGAT_EVAL_HALF(J, CUR, NXT)                                                                       \
     {                                                                                                     \
-      constexpr int j = J, g = j % KG, gn = (j + 1) % KG;                                                 \
-      const int64_t tt = t0 + (j / KG) * kEvalNT, tn = t0 + ((j + 1) / KG) * kEvalNT;                     \
-      issue(NXT, Pos{tn, gn});                                                                            \
-      /* the next step's sixteen loads go out HERE, ahead of this step's MFMAs: left to itself the scheduler sinks */ \
-      /* them between the MFMAs and waits for each a few instructions after issuing it (vmcnt 7-13: the latency of */ \
-      /* an L2 round trip per MFMA instead of per step)                                                            */ \
+      constexpr int j = J, g = (j / 2) % KG, q = j % 2, jn = j + 3, gn = (jn / 2) % KG, qn = jn % 2;      \
+      const int64_t tt = t0 + (j / 2 / KG) * kEvalNT, tn = t0 + (jn / 2 / KG) * kEvalNT;                  \
+      issue_half(NXT, tn, gn, qn);                                                                        \
+      /* the loads go out HERE, ahead of this half step's MFMAs: left to itself the scheduler sinks them between */ \
+      /* the MFMAs and waits for each a few instructions after issuing it                                         */ \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
       if (tt < t_hi) { /* wave-uniform */                                                                 \
-        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                     \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                     \
           _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[u][t], breg[g * U + u], acc[t], 0, 0, 0);   \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[c][t], breg[g * U + 4 * q + c], acc[t], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        if (g == KG - 1) {                                                                                \
+        if (g == KG - 1 && q == 1) {                                                                      \
           check(tt);                                                                                      \
           _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                               \
         }                                                                                                 \
       }                                                                                                   \
     }
-#define KGAT_EVAL_STEP2(J) KGAT_EVAL_STEP(J, a0, a1) KGAT_EVAL_STEP(J + 1, a1, a0)
+#define KGAT_EVAL_HALF4(J) KGAT_EVAL_HALF(J, h0, h3) KGAT_EVAL_HALF(J + 1, h1, h0) KGAT_EVAL_HALF(J + 2, h2, h1) KGAT_EVAL_HALF(J + 3, h3, h2)
     for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * kEvalNT) {
-      KGAT_EVAL_STEP2(0) KGAT_EVAL_STEP2(2) KGAT_EVAL_STEP2(4) KGAT_EVAL_STEP2(6) KGAT_EVAL_STEP2(8) KGAT_EVAL_STEP2(10)
-      KGAT_EVAL_STEP2(12) KGAT_EVAL_STEP2(14) KGAT_EVAL_STEP2(16) KGAT_EVAL_STEP2(18) KGAT_EVAL_STEP2(20)
+      KGAT_EVAL_HALF4(0) KGAT_EVAL_HALF4(4) KGAT_EVAL_HALF4(8) KGAT_EVAL_HALF4(12) KGAT_EVAL_HALF4(16) KGAT_EVAL_HALF4(20)
+      KGAT_EVAL_HALF4(24) KGAT_EVAL_HALF4(28) KGAT_EVAL_HALF4(32) KGAT_EVAL_HALF4(36) KGAT_EVAL_HALF4(40)
     }
-#undef KGAT_EVAL_STEP2
-#undef KGAT_EVAL_STEP
+#undef KGAT_EVAL_HALF4
+#undef KGAT_EVAL_HALF
   } else {
     float a0[U][kEvalNT], a1[U][kEvalNT];
     Pos p0{t_lo, 0}, p1{t_lo, 0};
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     prune(v);
     const int n = __builtin_amdgcn_readlane(c_mine, v);
     if (lane < K) {
-      const size_t o = ((size_t)(u0 + v) * n_lists + list0 + seg) * K + lane;
+      const size_t o = ((size_t)(u0 + v) * n_lists + seg) * K + lane;
       part_s[o] = lane < n ? cand_s[v * kEvalCap + lane] : kNegInf;
       part_i[o] = lane < n ? cand_i[v * kEvalCap + lane] : kIdxPad;
     }
@@ -453,13 +480,39 @@ static int eval_waves_per_block(int FP2) {
   return 0;
 }
 
-// Launch plan.  A first launch sweeps a SAMPLE of the items (the first kEvalSampleTiles tiles) for every user; the
-// K-th best of that list is a valid lower bound of the user's final K-th best, and every segment of the main launch
-// starts from it instead of warming its own threshold up from -inf (about K ln(1 + n_seg_items / sample) candidates
-// per user and segment instead of K ln(n_seg_items / K)).  The main launch splits the remaining tiles into segments
-// so that the grid has a few workgroups per CU.
+// Launch plan.  One grid: segment 0 sweeps a SAMPLE of the items (the first kEvalSampleTiles tiles) for every user -
+// the K-th best of that list is a valid lower bound of the user's final K-th best, published to the other segments
+// through tau_shared (see the kernel) - and the remaining tiles are split into segments so that the grid has a few
+// workgroups per CU.
+//
+// Segment sizes (round 6).  A CU holds `slots` workgroups at a time and the hardware hands the grid out in order, one
+// segment row (all user blocks) after the other: with equal segments the reference's shape is 2,212 workgroups on
+// 512 slots - 4.3 rounds, the fifth a third full (14 % of the launch spent waiting for it).  The plan therefore also
+// considers rows whose LAST segments are shorter (the stragglers of the last round are short ones) and one or two
+// more rows than the minimum, simulates the in-order hand-out of each candidate (a workgroup costs its tiles plus a
+// fixed share for its prologue, closing prunes and list) and keeps the shortest.
 constexpr int kEvalSampleTiles = 16;  // 512 items
-struct EvalPlanH { int nw, sample_tiles, seg, n_lists; };
+constexpr double kEvalFixedCost = 0.02;   // a workgroup's fixed work, in units of one user block's whole sweep
+struct EvalPlanH { int nw, sample_tiles, seg, n_lists; EvalBounds bounds; };
+
+static double eval_makespan(int64_t blocks, int64_t slots, double sample, const double* frac, int n) {
+  // in-order list scheduling on `slots` identical slots: a min-heap of the slots' finishing times
+  std::priority_queue<double, std::vector<double>, std::greater<double>> h;
+  for (int64_t i = 0; i < slots; ++i) h.push(0.0);
+  double last = 0.0;
+  for (int r = -1; r < n; ++r) {
+    if (r < 0 && sample <= 0.0) continue;
+    const double cost = (r < 0 ? sample : frac[r]) + kEvalFixedCost;
+    for (int64_t x = 0; x < blocks; ++x) {
+      const double t = h.top() + cost;
+      h.pop();
+      h.push(t);
+      if (t > last) last = t;
+    }
+  }
+  return last;
+}
+
 static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   EvalPlanH p;
   p.nw = eval_waves_per_block(eval_fp2(F));
@@ -468,15 +521,46 @@ static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   const int64_t rest = n_tiles - p.sample_tiles;
   const int nw = p.nw > 0 ? p.nw : 1;
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
+  const bool reg = eval_rows_in_registers(eval_fp2(F));
+  const int64_t slots = (int64_t)device_cu_count() * (reg ? 2 : 1);   // resident workgroups (LDS bound)
   // ~4 workgroups per CU (8 with the users' rows in registers: two are resident per CU there)
-  const int64_t want = (int64_t)device_cu_count() * (eval_rows_in_registers(eval_fp2(F)) ? 8 : 4);
+  const int64_t want = slots * 4;
   int64_t seg = (want + blocks - 1) / (blocks > 0 ? blocks : 1);
   const int64_t max_seg = rest / 16 > 0 ? rest / 16 : 1;     // at least 16 tiles (512 items) per segment
   if (seg > max_seg) seg = max_seg;
   if (seg > 64) seg = 64;
   if (seg < 1) seg = 1;
-  p.seg = (int)seg;
+  // candidates: seg .. seg + 2 rows, equal or with a short tail (weights 1, .., 1, 1/2, 1/4)
+  double best = -1.0, best_frac[kEvalMaxLists];
+  int best_n = (int)seg;
+  for (int i = 0; i < best_n; ++i) best_frac[i] = 1.0 / best_n;
+  if (seg > 1 && blocks <= 16 * slots) {   // (one row, or a grid of many rounds: nothing to gain)
+    for (int n = (int)seg; n <= (int)seg + 2 && n <= max_seg && n <= 64; ++n)
+      for (int tail = 0; tail <= 1; ++tail) {
+        if (tail && n < 3) continue;
+        double w[kEvalMaxLists], sum = 0.0;
+        for (int i = 0; i < n; ++i) { w[i] = !tail || i < n - 2 ? 1.0 : (i == n - 2 ? 0.5 : 0.25); sum += w[i]; }
+        bool ok = true;
+        for (int i = 0; i < n; ++i) { w[i] /= sum; ok = ok && w[i] * rest >= 8.0; }
+        if (!ok) continue;
+        const double mk = eval_makespan(blocks, slots, (double)p.sample_tiles / (double)n_tiles, w, n);
+        if (best < 0.0 || mk < best) { best = mk; best_n = n; for (int i = 0; i < n; ++i) best_frac[i] = w[i]; }
+      }
+  }
+  p.seg = best_n;
   p.n_lists = p.seg + (p.sample_tiles ? 1 : 0);
+  int y = 0;
+  p.bounds.b[0] = 0;
+  if (p.sample_tiles) p.bounds.b[++y] = p.sample_tiles;
+  double acc = 0.0;
+  for (int i = 0; i < p.seg; ++i) {
+    acc += best_frac[i];
+    int64_t e = i == p.seg - 1 ? n_tiles : p.sample_tiles + (int64_t)(acc * (double)rest + 0.5);
+    if (e <= p.bounds.b[y]) e = p.bounds.b[y] + 1;                      // (never empty; rest >= seg)
+    if (e > n_tiles - (p.seg - 1 - i)) e = n_tiles - (p.seg - 1 - i);
+    p.bounds.b[++y] = (int32_t)e;
+  }
+  for (int i = y + 1; i <= kEvalMaxLists; ++i) p.bounds.b[i] = (int32_t)n_tiles;
   return p;
 }
 
@@ -550,36 +634,26 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   const size_t lds = EvalLds::per_wave_bytes(FP2, reg) * nw;
   const unsigned gx = (unsigned)((n_users + 32 * nw - 1) / (32 * nw));
   hipStream_t st = as_stream(stream);
-#define KGAT_EVAL_LAUNCH(NW, KG_, GY, TLO, THI, LIST0, TAU0)                                                          \
+#define KGAT_EVAL_LAUNCH(NW, KG_)                                                                                     \
   do {                                                                                                                \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(eval_topk_kernel<NW, KG_>),                                 \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                    \
       set_error("eval_recall_ndcg: cannot reserve %zu bytes of LDS", lds);                                            \
       return KGAT_E_HIP;                                                                                              \
     }                                                                                                                 \
-    hipLaunchKernelGGL((eval_topk_kernel<NW, KG_>), dim3(gx, (unsigned)(GY)), dim3(NW * 64), lds, st, n_users,        \
-                       user_ids, n_items, FP2, F, (int64_t)(TLO), (int64_t)(THI), pl.n_lists, LIST0, TAU0, emb,      \
-                       emb_stride, itemT, train_ptr, train_items, K, part_s, part_i, (GY) > 1 ? tau_shared : nullptr); \
+    hipLaunchKernelGGL((eval_topk_kernel<NW, KG_>), dim3(gx, (unsigned)pl.n_lists), dim3(NW * 64), lds, st, n_users,  \
+                       user_ids, n_items, FP2, F, pl.bounds, emb, emb_stride, itemT,                                  \
+                       train_ptr, train_items, K, part_s, part_i, pl.n_lists > 1 ? tau_shared : nullptr);             \
   } while (0)
-#define KGAT_EVAL_LAUNCH_NW(GY, TLO, THI, LIST0, TAU0)                     \
-  do {                                                                     \
-    if (reg) KGAT_EVAL_LAUNCH(4, kEvalRegKG, GY, TLO, THI, LIST0, TAU0);   \
-    else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0, GY, TLO, THI, LIST0, TAU0);   \
-    else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0, GY, TLO, THI, LIST0, TAU0);   \
-    else KGAT_EVAL_LAUNCH(1, 0, GY, TLO, THI, LIST0, TAU0);                \
-  } while (0)
-  if (pl.seg > 1 && hipMemsetAsync(tau_shared, 0, (size_t)n_users * 4, st) != hipSuccess) {
+  if (pl.n_lists > 1 && hipMemsetAsync(tau_shared, 0, (size_t)n_users * 4, st) != hipSuccess) {
     set_error("eval_recall_ndcg: cannot clear the shared thresholds");
     return KGAT_E_HIP;
   }
-  if (pl.sample_tiles) {
-    KGAT_EVAL_LAUNCH_NW(1, 0, pl.sample_tiles, 0, 0);
-    KGAT_CHECK_LAUNCH("eval_topk (sample)");
-    KGAT_EVAL_LAUNCH_NW(pl.seg, pl.sample_tiles, n_tiles, 1, 1);
-  } else {
-    KGAT_EVAL_LAUNCH_NW(pl.seg, 0, n_tiles, 0, 0);
-  }
-#undef KGAT_EVAL_LAUNCH_NW
+  // ONE launch: the sample sweep is segment 0 of the grid (dispatched first), the segments of the rest follow
+  if (reg) KGAT_EVAL_LAUNCH(4, kEvalRegKG);
+  else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0);
+  else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0);
+  else KGAT_EVAL_LAUNCH(1, 0);
 #undef KGAT_EVAL_LAUNCH
   KGAT_CHECK_LAUNCH("eval_topk");
   hipLaunchKernelGGL(eval_merge_kernel, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, st, n_users, pl.n_lists, K,
