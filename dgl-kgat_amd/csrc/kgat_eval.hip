@@ -4,16 +4,16 @@
 // (:5-7) and ndcg@K against the user's OWN sorted hit list (:23-34).  SURVEY.md 8f #4.
 //
 // Three launches, no (users x items) score matrix in memory:
-//  1. eval_items_kmajor_kernel: the item rows as MFMA A fragments, [32-item tile][k pair][lane] - one
-//     coalesced 256-byte load per v_mfma_f32_32x32x2_f32 later.
-//  2. eval_topk_kernel: a wavefront owns 32 users (the B operand: their rows, kept in LDS for the whole
-//     launch) and a contiguous segment of item tiles; scores come out of the fp32 MFMA (an exact
-//     k-ordered fmaf chain, 157 TF peak: 620 GFLOP on the amazon-book shape) with the USER on the lane,
-//     so a lane compares its 16 scores of a tile with its user's current K-th best and only the rare
-//     survivors (about K ln(n / K) per user over the whole sweep) are appended to the user's candidate
-//     buffer in LDS.  A full buffer is pruned by the whole wavefront: entries that are training items
-//     are dropped (binary search in the user's sorted list), a 64-lane bitonic sort on (score
-//     descending, position ascending) keeps the K best and renews the threshold.
+//  1. eval_items_kmajor_kernel: the item rows as MFMA A fragments, [32-item tile][group of 8 k pairs][half][lane][4] -
+//     one coalesced 16-byte load per lane per FOUR v_mfma_f32_32x32x2_f32 later.
+//  2. eval_topk_kernel: a wavefront owns 32 users (the B operand: their rows, in registers at the reference's readout
+//     width, in LDS otherwise) and a contiguous segment of item tiles; scores come out of the fp32 MFMA (an exact
+//     k-ordered fmaf chain, 157 TF peak: 620 GFLOP on the amazon-book shape) with the USER on the lane, so a lane
+//     compares its 16 scores of a tile with its user's current K-th best and only the rare survivors (about
+//     K ln(n / K) per user over the whole sweep) are appended to the user's candidate buffer in LDS.  A full buffer is
+//     pruned by the whole wavefront: entries that are training items are dropped (binary search in the user's sorted
+//     list), every entry's place is counted on (score descending, position ascending), the K best stay and renew the
+//     threshold.  One grid: segment 0 is a short sample sweep whose K-th best the other segments start from.
 //  3. eval_merge_kernel: one wavefront per user merges the segments' partial lists with the masked
 //     training items - min(K, |train_u|) entries (0.0, lowest positions), which is all of them that can
 //     rank - marks the hits (binary search in the sorted test list) and writes recall and ndcg in fp64.
@@ -180,9 +180,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   // and nobody waits for its tail.
   const int n_lists = gridDim.y;
   const int64_t t_lo = bounds.b[seg], t_hi = bounds.b[seg + 1];
-  float tau_s = kNegInf;  // the user's K-th best so far (score, position); -inf while fewer than K are held
-  int tau_i = kIdxPad;
-  int c_mine = 0;         // entries in the user's buffer (the same value in both lanes of the user)
+  // the user's K-th best score so far: -inf while fewer than K are held (+inf on a lane without a user: nothing passes)
+  float tau_s = u_ok ? kNegInf : __builtin_inff();
+  // A user's buffer of kEvalCap entries is filled from BOTH ends: the lane of half 0 appends upwards from position 0,
+  // the lane of half 1 downwards from kEvalCap - 1 - no coordination between the two per append (round 6: it was one
+  // counter per user, a ballot per register and 64-bit shifts to order the two lanes behind each other: about twenty
+  // vector instructions per register of a tile, all of them taken from the other wavefront's MFMAs).  wp = the lane's
+  // next free entry (index into cand_s / cand_i).
+  int wp = ul * kEvalCap + (half ? kEvalCap - 1 : 0);
+  const int dir = half ? -1 : 1;
   // Round 6: the segments of a user's item range run side by side (one wavefront each), every one warming up its own
   // K-th best: they now SHARE it.  tau_shared[user] holds the best K-th score any segment has published (atomicMax on
   // order-preserving bits; zero-filled = below every float): K entries of some segment rank at or before it, so
@@ -194,19 +200,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   if (tau_shared != nullptr)
     sh_next = from_ordered_bits(__hip_atomic_load(tau_shared + up_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   auto adopt_shared = [&]() {
-    if (sh_next > tau_s) { tau_s = sh_next; tau_i = kIdxPad; }
+    if (sh_next > tau_s) tau_s = sh_next;   // (ties on the score stay candidates: the filter is >=)
   };
 
   // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.  An entry's
   // place is the number of entries that rank before it (the order is total): n broadcast compares per lane instead
   // of a sorting network's 42 dependent cross-lane exchanges.
   auto prune = [&](int v) {
-    const int n = __builtin_amdgcn_readlane(c_mine, v), kp = kept[v];
+    const int base = v * kEvalCap, kp = kept[v];
+    // entries [0, p_lo) and (p_hi, kEvalCap) of the buffer are in use (p_lo <= p_hi + 1)
+    const int p_lo = __builtin_amdgcn_readlane(wp, v) - base, p_hi = __builtin_amdgcn_readlane(wp, v + 32) - base;
+    const bool have = lane < p_lo || lane > p_hi;
     float s = kNegInf;
     int i = kIdxPad;
-    if (lane < n) { s = cand_s[v * kEvalCap + lane]; i = cand_i[v * kEvalCap + lane]; }
+    if (have) { s = cand_s[base + lane]; i = cand_i[base + lane]; }
     const int32_t lo = __builtin_amdgcn_readlane(tr_lo, v), hi = __builtin_amdgcn_readlane(tr_hi, v);
-    if (lane >= kp && lane < n && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
+    if (lane >= kp && have && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
     // (one 64-bit key per entry - the score's order-preserving bits above the complemented position: "ranks before"
     //  is key > key, ONE compare per broadcast entry instead of three and their combination; the fp32 MFMA and the
     //  vector ALU do not overlap on a SIMD, so every instruction here is taken from the other wavefront's sweep.
@@ -214,7 +223,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     const unsigned long long key = ((unsigned long long)ordered_bits(s + 0.f) << 32) | (unsigned)~i;
     const unsigned key_lo = (unsigned)key, key_hi = (unsigned)(key >> 32);
     int rank = 0;
-    for (int j = 0; j < n; j += 4) {   // (lanes [n, 64) hold (-inf, pad): behind every real entry, so reading them is harmless)
+    const unsigned long long used = __ballot(have);
+    for (int j = 0; j < 64; j += 4) {   // (a lane without an entry holds (-inf, pad): behind every real entry, harmless)
+      if ((used >> j & 15ull) == 0ull) continue;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)key_hi, j + jj) << 32) |
@@ -230,11 +241,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     const unsigned long long kth = __ballot(i != kIdxPad && rank == K - 1);
     const int lk = kth ? __builtin_ctzll(kth) : 0;
     const float ts = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), lk));
-    const int ti = __builtin_amdgcn_readlane(i, lk);
     if (ul == v) {  // both lanes of the user
       // (never below what is already known: a shared bound may be ahead of this segment's own K-th best)
-      if (keep == K && (ts > tau_s || (ts == tau_s && ti < tau_i))) { tau_s = ts; tau_i = ti; }
-      c_mine = keep;
+      if (keep == K && ts > tau_s) tau_s = ts;
+      wp = base + (half ? kEvalCap - 1 : keep);
     }
     if (lane == 0) {
       kept[v] = keep;
@@ -279,44 +289,37 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
 #pragma unroll
     for (int t = 0; t < kEvalNT; ++t) {
       if (t0 + t >= t_hi) break;  // wave-uniform
+      const int ib = (int)((t0 + t) * kEvalTile) + 4 * half;
+      if ((t0 + t + 1) * kEvalTile > n_items) {   // the padded end of the last tile (wave-uniform): never a candidate
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ib + (r & 3) + 8 * (r >> 2) >= n_items) acc[t][r] = __builtin_nanf("");
+      }
       float m = acc[t][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
-      if (__ballot(u_ok && m >= tau_s) != 0ull) {
-        // which of the 16 registers hold a candidate in ANY lane: one bit per register, OR-ed over the wavefront
-        // (vector instructions only), then a scalar walk over the set bits - instead of 16 ballots, each a
-        // vector-compare -> scalar-branch round trip
-        unsigned bits = 0;
+      if (__ballot(m >= tau_s) != 0ull) {
+        // every score at or above the user's K-th best so far is appended (a tie on the score with a later position is
+        // sorted out by the prune: the order there is total); after every four registers - at most four entries from
+        // either end - a buffer with fewer than eight free entries is pruned
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bits |= (u_ok && acc[t][r] >= tau_s) ? (1u << r) : 0u;
-        bits |= __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-        bits |= __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-        bits |= __builtin_amdgcn_mov_dpp(bits, 0x141, 0xF, 0xF, true);   // row_half_mirror
-        bits |= __builtin_amdgcn_mov_dpp(bits, 0x140, 0xF, 0xF, true);   // row_mirror: every lane has its row's OR
-        unsigned any = 0;
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int rw = 0; rw < 4; ++rw) any |= (unsigned)__builtin_amdgcn_readlane((int)bits, 16 * rw);
-        const int ib = (int)((t0 + t) * kEvalTile) + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (!(any >> r & 1u)) continue;  // scalar test
-          const float sc = acc[t][r];
-          const int it = ib + (r & 3) + 8 * (r >> 2);
-          const bool c = u_ok && sc >= tau_s && it < n_items && (sc > tau_s || it < tau_i);
-          const unsigned long long mk = __ballot(c);
-          if (mk == 0ull) continue;  // wave-uniform
-          // a user's two lanes (halves) append behind each other: no atomics, the count stays in registers
-          const int lo_c = (int)(mk >> ul) & 1, hi_c = (int)(mk >> (ul + 32)) & 1;
-          if (c) {
-            const int slot = c_mine + (half ? lo_c : 0);  // < kEvalCap: c_mine <= kEvalCap - 2 here
-            cand_s[ul * kEvalCap + slot] = sc;
-            cand_i[ul * kEvalCap + slot] = it;
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * q + rr;
+            const float sc = acc[t][r];
+            if (sc >= tau_s) {
+              cand_s[wp] = sc;
+              cand_i[wp] = ib + (r & 3) + 8 * (r >> 2);
+              wp += dir;
+            }
           }
-          c_mine += lo_c + hi_c;
-          // a buffer that could not take the next register's two entries is pruned now (not "room for a whole
-          // tile": with K = 20 kept of 64 that left 12 appends between prunes - one prune per tile and wavefront)
-          unsigned long long need = __ballot(half == 0 && c_mine > kEvalCap - 2);
+          // both lanes of a user see both write positions: v_permlane32_swap hands every lane the lower half's value
+          // and the upper half's
+          const auto both = __builtin_amdgcn_permlane32_swap((unsigned)wp, (unsigned)wp, false, false);
+          unsigned long long need = __ballot((int)both[1] - (int)both[0] + 1 < 8);
           if (need) {
+            need &= 0xffffffffull;   // (one bit per user)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             do {
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   for (int v = 0; v < 32; ++v) {
     if (u0 + v >= n_users) break;
     prune(v);
-    const int n = __builtin_amdgcn_readlane(c_mine, v);
+    const int n = __builtin_amdgcn_readlane(wp, v) - v * kEvalCap;   // (the kept entries, at the low end)
     if (lane < K) {
       const size_t o = ((size_t)(u0 + v) * n_lists + seg) * K + lane;
       part_s[o] = lane < n ? cand_s[v * kEvalCap + lane] : kNegInf;
