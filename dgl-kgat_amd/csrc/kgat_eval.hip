@@ -295,15 +295,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
         for (int r = 0; r < 16; ++r)
           if (ib + (r & 3) + 8 * (r >> 2) >= n_items) acc[t][r] = __builtin_nanf("");
       }
-      float m = acc[t][0];
+      // the maximum of every four registers, then of all sixteen: a tile without a candidate costs the ten maxima and one
+      // compare, a tile with one walks only the quads that hold it
+      float mq[4];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
+      for (int q = 0; q < 4; ++q)
+        mq[q] = fmaxf(fmaxf(acc[t][4 * q], acc[t][4 * q + 1]), fmaxf(acc[t][4 * q + 2], acc[t][4 * q + 3]));
+      const float m = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
       if (__ballot(m >= tau_s) != 0ull) {
         // every score at or above the user's K-th best so far is appended (a tie on the score with a later position is
         // sorted out by the prune: the order there is total); after every four registers - at most four entries from
         // either end - a buffer with fewer than eight free entries is pruned
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (__ballot(mq[q] >= tau_s) == 0ull) continue;   // wave-uniform
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * q + rr;
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
     //  per step - the index as an integral_constant - sent every captured array to scratch)
     static_assert(KG == 11 && U == 8, "the step list below is written out for 2 x 11 steps of 2 halves");
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
     auto issue_half = [&](float (&a)[4][kEvalNT], int64_t tg, int g, int q) {
 #pragma unroll
@@ -388,13 +394,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
       if (tt < t_hi) { /* wave-uniform */                                                                 \
         _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                     \
           _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[c][t], breg[g * U + 4 * q + c], acc[t], 0, 0, 0); \
+            /* (a tile group's first MFMA adds to the constant 0: no clearing of 32 registers per group) */ \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[c][t], breg[g * U + 4 * q + c],             \
+                                                          (g == 0 && q == 0 && c == 0) ? zero16 : acc[t], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        if (g == KG - 1 && q == 1) {                                                                      \
-          check(tt);                                                                                      \
-          _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                               \
-        }                                                                                                 \
+        if (g == KG - 1 && q == 1) check(tt);                                                             \
       }                                                                                                   \
     }
 #define KGAT_EVAL_HALF4(J) KGAT_EVAL_HALF(J, h0, h3) KGAT_EVAL_HALF(J + 1, h1, h0) KGAT_EVAL_HALF(J + 2, h2, h1) KGAT_EVAL_HALF(J + 3, h3, h2)
