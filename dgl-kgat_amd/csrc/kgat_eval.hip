@@ -371,11 +371,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     static_assert(KG == 11 && U == 8, "the step list below is written out for 2 x 11 steps of 2 halves");
     const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const size_t seg_bytes = (size_t)(t_hi - t_lo) * KG * 2048;
+    const __amdgpu_buffer_rsrc_t seg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(itemT) + (size_t)t_lo * KG * 512, 0, (int)(unsigned)seg_bytes, 0x00020000);
     auto issue_half = [&](float (&a)[4][kEvalNT], int64_t tg, int g, int q) {
 #pragma unroll
       for (int t = 0; t < kEvalNT; ++t) {
         const int64_t tt = tg + t < t_hi ? tg + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
-        const floatx4 v = a_base[(((size_t)tt * KG + g) * 2 + q) * 64];
+        // (a buffer load: the segment's fragments as a resource, the wave-uniform offset in a scalar register, the lane's
+        //  16 bytes the only vector operand - as a global load every address was two 64-bit vector adds, six vector
+        //  instructions per half step; the host checks that a segment's fragments stay below 4 GB)
+        const unsigned soff = (unsigned)(((tt - t_lo) * KG + g) * 2 + q) * 1024u;
+        const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(seg_rsrc, lane * 16, (int)soff, 0));
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c][t] = v[c];
       }
@@ -633,6 +641,9 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
   const EvalPlanH pl = eval_plan(n_users, n_items, F);
   const int nw = pl.nw;
+  for (int y = 0; y < pl.n_lists; ++y)   // (the kernel addresses a segment's fragments with 32-bit offsets)
+    KGAT_CHECK_ARG((int64_t)(pl.bounds.b[y + 1] - pl.bounds.b[y]) * FP2 * 256 < ((int64_t)1 << 32),
+                   "eval_recall_ndcg: a segment of %d tiles is beyond 4 GB of fragments", pl.bounds.b[y + 1] - pl.bounds.b[y]);
   Carver cv(workspace);
   float* part_s = cv.take<float>((size_t)n_users * pl.n_lists * K);
   int32_t* part_i = cv.take<int32_t>((size_t)n_users * pl.n_lists * K);
