@@ -255,11 +255,23 @@ __global__ __launch_bounds__(SpmmGeom<LPR>::THREADS) void spmm_merge_kernel(
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 
+typedef unsigned long long u64x2v __attribute__((ext_vector_type(2)));
 struct alignas(16) EdgeRec {
-  int32_t c;  // source row
-  int32_t r;  // destination row
-  float w;
-  int32_t pad;
+  // One 16-byte record per edge, moved as ONE vector (ds_write_b128 / ds_read_b128).  v[0]: the source row's position
+  // in X in 16-byte units (row * LPR) as a 64-bit value - after the read it sits in an aligned register pair and the
+  // gather's address is ONE v_lshl_add_u64 ((cq << 4) + the lane's pointer; round 6: the record held the 32-bit row and
+  // every gather paid a sign extension, a copy, a 64-bit shift and a 64-bit add, four vector instructions beside the
+  // two packed FMAs of an edge).  v[1]: destination row (low word), weight (high word).
+  u64x2v v;
+  __device__ __forceinline__ uint64_t cq() const { return v[0]; }
+  __device__ __forceinline__ int32_t r() const { return (int32_t)(uint32_t)v[1]; }
+  __device__ __forceinline__ float w() const { return __uint_as_float((uint32_t)(v[1] >> 32)); }
+  static __device__ __forceinline__ EdgeRec make(uint64_t cq, int32_t r, float w) {
+    EdgeRec e;
+    e.v[0] = cq;
+    e.v[1] = ((uint64_t)__float_as_uint(w) << 32) | (uint32_t)r;
+    return e;
+  }
 };
 
 template <int LPR, int C, bool MUL_SELF, bool COPY_SELF = false, int DO = 0>
@@ -303,21 +315,15 @@ constexpr int kSpmmXcdRemap = 0;
   const int64_t tile1 = (tile0 + TE < e1) ? tile0 + TE : e1;
   const int n_tile = (int)(tile1 - tile0);
   for (int k = tid; k < TE; k += SpmmGeom<LPR>::THREADS) {
-    EdgeRec rec;
+    EdgeRec rec = EdgeRec::make(0, -1, 0.f);
     if (k < n_tile) {
       const int64_t p = tile0 + k;
-                      // launches gain 3 % (D = 64) / 7 % (D = 32) - profiles/r04_spmm_cache_policy_ab.txt -, the step
-                      // 6.6 us (0.4244 -> 0.4178 ms, profiles/r04_step_ab_cache_policy.txt; the first step-level
-                      // comparison, on per-kernel averages of separate runs, had not resolved it)
-      rec.c = __builtin_nontemporal_load(col + p);
-      rec.r = __builtin_nontemporal_load(row_of + p);
-      rec.w = __builtin_nontemporal_load(w + p);
-    } else {
-      rec.c = 0;
-      rec.r = -1;
-      rec.w = 0.f;
+      // (non-temporal: col / row_of / w are read once and should not push source rows out of the caches - the launches
+      //  gain 3 % (D = 64) / 7 % (D = 32), profiles/r04_spmm_cache_policy_ab.txt, the step 6.6 us: 0.4244 -> 0.4178 ms,
+      //  profiles/r04_step_ab_cache_policy.txt)
+      rec = EdgeRec::make((uint64_t)(uint32_t)__builtin_nontemporal_load(col + p) * LPR,
+                          __builtin_nontemporal_load(row_of + p), __builtin_nontemporal_load(w + p));
     }
-    rec.pad = 0;
     s_rec[k] = rec;
   }
   if (FUSED) {  // rows of the tile's range without in-edges are never written: they must read as zero
@@ -325,8 +331,8 @@ constexpr int kSpmmXcdRemap = 0;
   }
   __syncthreads();
   // (wave-uniform values read from LDS: pinned in SGPRs, the edge loop is at its VGPR limit)
-  const int32_t first_row = __builtin_amdgcn_readfirstlane(s_rec[0].r);
-  const int32_t last_row = __builtin_amdgcn_readfirstlane(s_rec[n_tile - 1].r);
+  const int32_t first_row = __builtin_amdgcn_readfirstlane(s_rec[0].r());
+  const int32_t last_row = __builtin_amdgcn_readfirstlane(s_rec[n_tile - 1].r());
   if constexpr (FUSED) {
     // interior rows beyond the row buffer's capacity that have no in-edges: nobody writes their P row, the dense
     // tail reads it from the scratch - zero it here (one lane per row tests the row offsets; such rows are rare)
@@ -348,11 +354,12 @@ constexpr int kSpmmXcdRemap = 0;
   };
 
   const EdgeRec* run = s_rec + sub * C;
+  const float4* const Xl = X + sl;   // the lane's column of every source row
   int n_run = n_tile - sub * C;
   n_run = n_run < 0 ? 0 : (n_run > C ? C : n_run);
   const int ng = n_run / G;
 
-  int32_t cur_row = n_run > 0 ? run[0].r : -1;
+  int32_t cur_row = n_run > 0 ? run[0].r() : -1;
   bool head_done = false;
   float2v a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
   // KGAT_SPMM_MUL_SELF loads X[row] when a row ENDS: a dependent round trip inside the edge loop - the wavefront's
@@ -394,21 +401,21 @@ constexpr int kSpmmSelfPrefetch = 0;  // measured SLOWER (100.7 vs 91.4 us at D 
 #pragma unroll
     for (int i = 0; i < G; ++i) rec[i] = run[g * G + i];
 #pragma unroll
-    for (int i = 0; i < G; ++i) x[i] = X[(size_t)rec[i].c * LPR + sl];
+    for (int i = 0; i < G; ++i) x[i] = Xl[rec[i].cq()];
   };
   auto consume = [&](const EdgeRec (&rec)[G], const float4 (&x)[G]) {
     // rows are sorted: the group stays inside the open row iff its last edge does
-    if (__ballot(rec[G - 1].r != cur_row) == 0ull) {
+    if (__ballot(rec[G - 1].r() != cur_row) == 0ull) {
 #pragma unroll
-      for (int i = 0; i < G; ++i) accum(rec[i].w, x[i]);
+      for (int i = 0; i < G; ++i) accum(rec[i].w(), x[i]);
     } else {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
-        if (rec[i].r != cur_row) {
+        if (rec[i].r() != cur_row) {
           flush();
-          open_row(rec[i].r);
+          open_row(rec[i].r());
         }
-        accum(rec[i].w, x[i]);
+        accum(rec[i].w(), x[i]);
       }
     }
   };
@@ -425,12 +432,12 @@ constexpr int kSpmmSelfPrefetch = 0;  // measured SLOWER (100.7 vs 91.4 us at D 
   }
   for (int j = ng * G; j < n_run; ++j) {  // only the last run of the edge range is ragged
     const EdgeRec rec = run[j];
-    const float4 x = X[(size_t)rec.c * LPR + sl];
-    if (rec.r != cur_row) {
+    const float4 x = Xl[rec.cq()];
+    if (rec.r() != cur_row) {
       flush();
-      open_row(rec.r);
+      open_row(rec.r());
     }
-    accum(rec.w, x);
+    accum(rec.w(), x);
   }
   // the run's last open row: head slot if the run never changed row, else tail slot
   {
