@@ -117,6 +117,51 @@ def test_eval_ties_and_masked_zeros_exact(dev, n_u, n_i, F, K):
     assert np.array_equal(rec, rec2) and np.array_equal(ndcg, ndcg2) and np.array_equal(topk, topk2)
 
 
+@pytest.mark.parametrize("n_u,n_i,F,K", [(1100, 6000, 176, 20), (400, 9001, 176, 7), (500, 4000, 64, 20)])
+def test_eval_real_valued_scores_and_racing_thresholds(dev, n_u, n_i, F, K):
+    """Real-valued embeddings (fp32 scores, no exact ties) at sizes with a sample segment and several item segments per
+    user block: the kernel's K best against an fp64 ranking of the same fp32 inputs - equal, or different only where two
+    fp64 scores are closer than the fp32 rounding of a 176-term dot product -, and the same bits from call to call: the
+    segments of a user race each other through the shared K-th best (tau_shared), which may change the work, never the
+    result."""
+    from dgl_kgat_amd import metrics, ops
+    rng = np.random.default_rng(7 * n_u + n_i)
+    emb = rng.standard_normal((n_u + n_i, F)).astype(np.float32)
+    item_range = np.arange(n_u, n_u + n_i)
+    train = {u: np.unique(rng.integers(0, n_i, int(rng.integers(0, 60)))) for u in range(n_u)}
+    test = {u: np.unique(rng.integers(0, n_i, 1 + u % 7)) for u in range(n_u)}
+    # a few users whose best items are all training items
+    e64 = emb.astype(np.float64)
+    for u in range(0, n_u, 97):
+        train[u] = np.unique(np.argsort(-(e64[item_range] @ e64[u]))[:45])
+    plan = metrics.EvalPlan(train, test, item_range, dev)
+    e = torch.as_tensor(emb, device=dev)
+    runs = [ops.eval_recall_ndcg(e, plan.user_ids, plan.item_ids, plan.train_ptr, plan.train_items, plan.test_ptr,
+                                 plan.test_items, K, want_topk=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+    rec, ndcg, topk = (x.cpu().numpy() for x in runs[0])
+    users = list(test.keys())
+    tol = 2e-4
+    n_exact = 0
+    for r, u in enumerate(users):
+        score = e64[item_range] @ e64[u]
+        score[train[u]] = 0.0
+        order = np.argsort(-score, kind="stable")
+        if np.array_equal(topk[r], order[:K]):
+            n_exact += 1
+            continue
+        # not the fp64 order: every selected item within rounding of the K-th best, in descending order up to rounding
+        got = score[topk[r]]
+        assert np.all(got >= score[order[K - 1]] - tol), (u, got, score[order[:K]])
+        assert np.all(np.diff(got) <= tol), (u, got)
+        assert len(set(topk[r].tolist())) == K
+    assert n_exact >= 0.995 * n_u, (n_exact, n_u)
+    ref = orc.recall_ndcg_per_user(e64, train, test, item_range, K)
+    assert abs(rec.mean() - ref[0]) < 2e-3 and abs(ndcg.mean() - ref[1]) < 2e-3, (rec.mean(), ndcg.mean(), ref)
+
+
 def test_eval_rejects_what_the_reference_cannot_do(dev):
     from dgl_kgat_amd import metrics, ops
     from dgl_kgat_amd.ops import KGATLibraryError
