@@ -203,9 +203,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     if (sh_next > tau_s) tau_s = sh_next;   // (ties on the score stay candidates: the filter is >=)
   };
 
-  // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.  An entry's
-  // place is the number of entries that rank before it (the order is total): n broadcast compares per lane instead
-  // of a sorting network's 42 dependent cross-lane exchanges.
+  // Keep the K best entries of user `v` (wave-uniform), dropping training items among the new ones.  The K-th best
+  // key is SELECTED, not ranked: a bisection over the 32 bits of the scores' order-preserving form - per bit one vector
+  // compare against a scalar and a scalar population count - instead of one broadcast + compare + add per entry and
+  // lane (round 6: the rank count was three quarters of a prune's vector instructions, and on this chip every vector
+  // instruction of this wavefront is taken from the other wavefront's fp32 MFMAs; scalar instructions are not).  Entries
+  // that tie with the K-th score are taken in position order (a second bisection over the positions, only when the tie
+  // straddles the cut).  The survivors are compacted to the low end of the buffer in lane order - not sorted: the order
+  // is total, so the SET is what matters; the merge launch sorts.
   auto prune = [&](int v) {
     const int base = v * kEvalCap, kp = kept[v];
     // entries [0, p_lo) and (p_hi, kEvalCap) of the buffer are in use (p_lo <= p_hi + 1)
@@ -216,31 +221,38 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     if (have) { s = cand_s[base + lane]; i = cand_i[base + lane]; }
     const int32_t lo = __builtin_amdgcn_readlane(tr_lo, v), hi = __builtin_amdgcn_readlane(tr_hi, v);
     if (lane >= kp && have && in_sorted(train_items, lo, hi, i)) { s = kNegInf; i = kIdxPad; }
-    // (one 64-bit key per entry - the score's order-preserving bits above the complemented position: "ranks before"
-    //  is key > key, ONE compare per broadcast entry instead of three and their combination; the fp32 MFMA and the
-    //  vector ALU do not overlap on a SIMD, so every instruction here is taken from the other wavefront's sweep.
-    //  s + 0 maps -0 to +0, which the float compares treated as equal.)
-    const unsigned long long key = ((unsigned long long)ordered_bits(s + 0.f) << 32) | (unsigned)~i;
-    const unsigned key_lo = (unsigned)key, key_hi = (unsigned)(key >> 32);
-    int rank = 0;
-    const unsigned long long used = __ballot(have);
-    for (int j = 0; j < 64; j += 4) {   // (a lane without an entry holds (-inf, pad): behind every real entry, harmless)
-      if ((used >> j & 15ull) == 0ull) continue;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)key_hi, j + jj) << 32) |
-                                      (unsigned)__builtin_amdgcn_readlane((int)key_lo, j + jj);
-        rank += kj > key ? 1 : 0;
+    const bool valid = i != kIdxPad;
+    // the score as an unsigned key of the same order (s + 0 maps -0 to +0, equal for the reference's compare); 0 - below
+    // the key of every float - for a lane without an entry
+    const unsigned key = valid ? ordered_bits(s + 0.f) : 0u;
+    const int n_valid = __popcll(__ballot(valid));
+    const int keep = n_valid < K ? n_valid : K;
+    unsigned T = 0u;   // the keep-th largest key: the largest T with at least `keep` keys >= T
+    if (keep > 0) {
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned c = T | (1u << bit);
+        if (__popcll(__ballot(key >= c)) >= keep) T = c;
       }
     }
-    const int valid = __popcll(__ballot(i != kIdxPad));
-    const int keep = valid < K ? valid : K;
+    const bool above = keep > 0 && key > T, tied = keep > 0 && key == T;   // (T > 0: an empty lane is neither)
+    const int need_tied = keep - __popcll(__ballot(above));                // >= 1 when keep > 0
+    bool sel = above || tied;
+    if (__popcll(__ballot(tied)) > need_tied) {
+      // the need_tied lowest positions among the tied entries: I = the need_tied-th smallest of them (positions are
+      // distinct), found as the largest I with fewer than need_tied tied positions below it
+      int I = 0;
+      for (int bit = 30; bit >= 0; --bit) {
+        const int c = I | (1 << bit);
+        if (__popcll(__ballot(tied && i < c)) < need_tied) I = c;
+      }
+      sel = above || (tied && i <= I);
+    }
+    const unsigned long long sel_mask = __ballot(sel);
+    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(sel_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel_mask, 0u));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();                        // every lane has read its entry
-    if (i != kIdxPad && rank < keep) { cand_s[v * kEvalCap + rank] = s; cand_i[v * kEvalCap + rank] = i; }
-    const unsigned long long kth = __ballot(i != kIdxPad && rank == K - 1);
-    const int lk = kth ? __builtin_ctzll(kth) : 0;
-    const float ts = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), lk));
+    if (sel) { cand_s[base + pos] = s; cand_i[base + pos] = i; }
+    const float ts = from_ordered_bits(T);                  // the K-th best score when keep == K
     if (ul == v) {  // both lanes of the user
       // (never below what is already known: a shared bound may be ahead of this segment's own K-th best)
       if (keep == K && ts > tau_s) tau_s = ts;
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     }
     if (lane == 0) {
       kept[v] = keep;
-      if (keep == K && tau_shared != nullptr) atomicMax(tau_shared + (u0 + v), ordered_bits(ts));
+      if (keep == K && tau_shared != nullptr) atomicMax(tau_shared + (u0 + v), T);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
