@@ -231,19 +231,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     if (keep > 0) {
       for (int bit = 31; bit >= 0; --bit) {
         const unsigned c = T | (1u << bit);
-        if (__popcll(__ballot(key >= c)) >= keep) T = c;
+        if ((int)__popcll(__ballot(key >= c)) >= keep) T = c;
       }
     }
     const bool above = keep > 0 && key > T, tied = keep > 0 && key == T;   // (T > 0: an empty lane is neither)
-    const int need_tied = keep - __popcll(__ballot(above));                // >= 1 when keep > 0
+    const int need_tied = keep - (int)__popcll(__ballot(above));                // >= 1 when keep > 0
     bool sel = above || tied;
-    if (__popcll(__ballot(tied)) > need_tied) {
+    if ((int)__popcll(__ballot(tied)) > need_tied) {
       // the need_tied lowest positions among the tied entries: I = the need_tied-th smallest of them (positions are
       // distinct), found as the largest I with fewer than need_tied tied positions below it
       int I = 0;
       for (int bit = 30; bit >= 0; --bit) {
         const int c = I | (1 << bit);
-        if (__popcll(__ballot(tied && i < c)) < need_tied) I = c;
+        if ((int)__popcll(__ballot(tied && i < c)) < need_tied) I = c;
       }
       sel = above || (tied && i <= I);
     }
@@ -383,7 +383,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     static_assert(KG == 11 && U == 8, "the step list below is written out for 2 x 11 steps of 2 halves");
     const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
-    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
     const size_t seg_bytes = (size_t)(t_hi - t_lo) * KG * 2048;
     const __amdgpu_buffer_rsrc_t seg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(itemT) + (size_t)t_lo * KG * 512, 0, (int)(unsigned)seg_bytes, 0x00020000);
@@ -650,7 +649,6 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
     return KGAT_E_WORKSPACE;
   }
   const int FP2 = eval_fp2(F);
-  const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
   const EvalPlanH pl = eval_plan(n_users, n_items, F);
   const int nw = pl.nw;
   for (int y = 0; y < pl.n_lists; ++y)   // (the kernel addresses a segment's fragments with 32-bit offsets)
