@@ -117,7 +117,7 @@ def test_eval_ties_and_masked_zeros_exact(dev, n_u, n_i, F, K):
     assert np.array_equal(rec, rec2) and np.array_equal(ndcg, ndcg2) and np.array_equal(topk, topk2)
 
 
-@pytest.mark.parametrize("n_u,n_i,F,K", [(1100, 6000, 176, 20), (400, 9001, 176, 7), (500, 4000, 64, 20)])
+@pytest.mark.parametrize("n_u,n_i,F,K", [(1100, 6000, 176, 20), (400, 9001, 176, 7), (500, 4000, 64, 20), (40, 30000, 176, 20)])
 def test_eval_real_valued_scores_and_racing_thresholds(dev, n_u, n_i, F, K):
     """Real-valued embeddings (fp32 scores, no exact ties) at sizes with a sample segment and several item segments per
     user block: the kernel's K best against an fp64 ranking of the same fp32 inputs - equal, or different only where two
