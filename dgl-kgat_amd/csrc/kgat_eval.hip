@@ -13,7 +13,7 @@
 //     K ln(n / K) per user over the whole sweep) are appended to the user's candidate buffer in LDS.  A full buffer is
 //     pruned by the whole wavefront: entries that are training items are dropped (binary search in the user's sorted
 //     list), every entry's place is counted on (score descending, position ascending), the K best stay and renew the
-//     threshold.  One grid: segment 0 is a short sample sweep whose K-th best the other segments start from.
+//     threshold.  One grid; the segments of a user block share their K-th best as they go.
 //  3. eval_merge_kernel: one wavefront per user merges the segments' partial lists with the masked
 //     training items - min(K, |train_u|) entries (0.0, lowest positions), which is all of them that can
 //     rank - marks the hits (binary search in the sorted test list) and writes recall and ndcg in fp64.
@@ -170,14 +170,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // The segment's tiles (bounds, from the host's plan).  With a sample, segment 0 is the first few tiles - a short sweep
-  // whose K-th best, published through tau_shared, spares every other segment most of its warm-up (about
-  // K ln(1 + n_seg_items / sample) candidates per user and segment instead of K ln(n_seg_items / K)) - and the other
-  // segments split the rest.  Workgroups are dispatched x-fastest, so the sample segments of all users go out FIRST; a
-  // later segment that starts before its users' sample has finished just starts from what has been published so far
-  // (any published K-th best is a valid bound).  Round 6: this was a launch of its own - 0.9 ms of candidate handling
-  // with almost no MFMAs, 553 workgroups on 512 slots; as part of one grid it runs beside the other segments' MFMAs
-  // and nobody waits for its tail.
+  // The segment's tiles (bounds, from the host's plan).  Workgroups are dispatched x-fastest: one segment row (all user
+  // blocks) after the other, so the segments of a user block mostly run one after the other and a later one starts
+  // from the K-th best the earlier ones have published (tau_shared below; any published value is a valid bound).
+  // (Rounds 5-6 seeded the thresholds with a sample sweep over the first 512 items - first a launch of its own, 0.9 ms of
+  // candidate handling with almost no MFMAs, then segment 0 of this grid; with the shared threshold it measures the same
+  // with and without, 500 ... 300,000 users: profiles/r06_eval_scan.txt - and it is gone.)
   const int n_lists = gridDim.y;
   const int64_t t_lo = bounds.b[seg], t_hi = bounds.b[seg + 1];
   // the user's K-th best score so far: -inf while fewer than K are held (+inf on a lane without a user: nothing passes)
@@ -506,29 +504,25 @@ static int eval_waves_per_block(int FP2) {
   return 0;
 }
 
-// Launch plan.  One grid: segment 0 sweeps a SAMPLE of the items (the first kEvalSampleTiles tiles) for every user -
-// the K-th best of that list is a valid lower bound of the user's final K-th best, published to the other segments
-// through tau_shared (see the kernel) - and the remaining tiles are split into segments so that the grid has a few
-// workgroups per CU.
+// Launch plan.  One grid: the item tiles are split into segments so that the grid has a few workgroups per CU.
 //
 // Segment sizes (round 6).  A CU holds `slots` workgroups at a time and the hardware hands the grid out in order, one
 // segment row (all user blocks) after the other: with equal segments the reference's shape is 2,212 workgroups on
-// 512 slots - 4.3 rounds, the fifth a third full (14 % of the launch spent waiting for it).  The plan therefore also
-// considers rows whose LAST segments are shorter (the stragglers of the last round are short ones) and one or two
-// more rows than the minimum, simulates the in-order hand-out of each candidate (a workgroup costs its tiles plus a
-// fixed share for its prologue, closing prunes and list) and keeps the shortest.
-constexpr int kEvalSampleTiles = 16;  // 512 items
+// 512 slots - 4.3 rounds, the fifth a third full.  The plan therefore also considers rows whose LAST segments are
+// shorter (the stragglers of the last round are short ones) and one or two more rows than the minimum, simulates the
+// in-order hand-out of each candidate (a workgroup costs its tiles plus a fixed share for its prologue, closing prunes
+// and list) and keeps the shortest.  (Worth 2 % on the chip, not the 11 % of the simulation: a CU left with one
+// workgroup runs it faster.)
 constexpr double kEvalFixedCost = 0.02;   // a workgroup's fixed work, in units of one user block's whole sweep
-struct EvalPlanH { int nw, sample_tiles, seg, n_lists; EvalBounds bounds; };
+struct EvalPlanH { int nw, seg, n_lists; EvalBounds bounds; };
 
-static double eval_makespan(int64_t blocks, int64_t slots, double sample, const double* frac, int n) {
+static double eval_makespan(int64_t blocks, int64_t slots, const double* frac, int n) {
   // in-order list scheduling on `slots` identical slots: a min-heap of the slots' finishing times
   std::priority_queue<double, std::vector<double>, std::greater<double>> h;
   for (int64_t i = 0; i < slots; ++i) h.push(0.0);
   double last = 0.0;
-  for (int r = -1; r < n; ++r) {
-    if (r < 0 && sample <= 0.0) continue;
-    const double cost = (r < 0 ? sample : frac[r]) + kEvalFixedCost;
+  for (int r = 0; r < n; ++r) {
+    const double cost = frac[r] + kEvalFixedCost;
     for (int64_t x = 0; x < blocks; ++x) {
       const double t = h.top() + cost;
       h.pop();
@@ -543,8 +537,7 @@ static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   EvalPlanH p;
   p.nw = eval_waves_per_block(eval_fp2(F));
   const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
-  p.sample_tiles = n_tiles >= 4 * kEvalSampleTiles ? kEvalSampleTiles : 0;
-  const int64_t rest = n_tiles - p.sample_tiles;
+  const int64_t rest = n_tiles;
   const int nw = p.nw > 0 ? p.nw : 1;
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
   const bool reg = eval_rows_in_registers(eval_fp2(F));
@@ -569,19 +562,18 @@ static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
         bool ok = true;
         for (int i = 0; i < n; ++i) { w[i] /= sum; ok = ok && w[i] * rest >= 8.0; }
         if (!ok) continue;
-        const double mk = eval_makespan(blocks, slots, (double)p.sample_tiles / (double)n_tiles, w, n);
+        const double mk = eval_makespan(blocks, slots, w, n);
         if (best < 0.0 || mk < best) { best = mk; best_n = n; for (int i = 0; i < n; ++i) best_frac[i] = w[i]; }
       }
   }
   p.seg = best_n;
-  p.n_lists = p.seg + (p.sample_tiles ? 1 : 0);
+  p.n_lists = p.seg;
   int y = 0;
   p.bounds.b[0] = 0;
-  if (p.sample_tiles) p.bounds.b[++y] = p.sample_tiles;
   double acc = 0.0;
   for (int i = 0; i < p.seg; ++i) {
     acc += best_frac[i];
-    int64_t e = i == p.seg - 1 ? n_tiles : p.sample_tiles + (int64_t)(acc * (double)rest + 0.5);
+    int64_t e = i == p.seg - 1 ? n_tiles : (int64_t)(acc * (double)rest + 0.5);
     if (e <= p.bounds.b[y]) e = p.bounds.b[y] + 1;                      // (never empty; rest >= seg)
     if (e > n_tiles - (p.seg - 1 - i)) e = n_tiles - (p.seg - 1 - i);
     p.bounds.b[++y] = (int32_t)e;
@@ -677,7 +669,7 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
     set_error("eval_recall_ndcg: cannot clear the shared thresholds");
     return KGAT_E_HIP;
   }
-  // ONE launch: the sample sweep is segment 0 of the grid (dispatched first), the segments of the rest follow
+  // ONE launch over (user blocks) x (item segments)
   if (reg) KGAT_EVAL_LAUNCH(4, kEvalRegKG);
   else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0);
   else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0);
