@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the threshold sample (kEvalSampleTiles) was removed from kgat_eval.hip after these scans (profiles/r06_eval_scan.txt);
+# the script applies to the sources up to commit 'Evaluation: the prune selects the K-th best key by bisection'.
 # Developer probe (round 6): evaluation kernel - tiles of the sample segment (kEvalSampleTiles), rebuilt per variant
 # on the GPU box; prints the full-size time.
 cd $GRAFT_REPO_ROOT

@@ -1,3 +1,7 @@
+#!/bin/bash
+# Developer probe (round 6): evaluation with and without the threshold sample over user / item counts.
+# HISTORICAL: the threshold sample (kEvalSampleTiles) was removed from kgat_eval.hip after these scans (profiles/r06_eval_scan.txt);
+# the script applies to the sources up to commit 'Evaluation: the prune selects the K-th best key by bisection'.
 cd $GRAFT_REPO_ROOT
 F=dgl-kgat_amd/csrc/kgat_eval.hip
 cp $F /tmp/eval.orig
