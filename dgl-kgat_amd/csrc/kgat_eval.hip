@@ -542,8 +542,10 @@ static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
   const bool reg = eval_rows_in_registers(eval_fp2(F));
   const int64_t slots = (int64_t)device_cu_count() * (reg ? 2 : 1);   // resident workgroups (LDS bound)
-  // ~4 workgroups per CU (8 with the users' rows in registers: two are resident per CU there)
-  const int64_t want = slots * 4;
+  // about two rounds of resident workgroups (measured against one and four at the shapes of the reference's three
+  // datasets and at 8,000 users: profiles/r06_eval_scan.txt - every row more is another prologue, warm-up and list
+  // per user, one round leaves the last workgroups of an uneven grid alone on the chip)
+  const int64_t want = slots * 2;
   int64_t seg = (want + blocks - 1) / (blocks > 0 ? blocks : 1);
   const int64_t max_seg = rest / 16 > 0 ? rest / 16 : 1;     // at least 16 tiles (512 items) per segment
   if (seg > max_seg) seg = max_seg;
