@@ -358,6 +358,8 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
 }
 
 // the place of every id among all ids (see above); thread t = position t of the concatenated sorted slices
+// (NL: the slices the search is unrolled over - 8 at the CF step's batch, 30,720 ids in eight slices)
+template <int NL>
 __global__ __launch_bounds__(256) void bpr_merge_kernel(int32_t total, int32_t n_lists, const uint64_t* __restrict__ lists,
                                                         int32_t* __restrict__ order, int32_t* __restrict__ sorted) {
   const int32_t t = (int32_t)blockIdx.x * 256 + threadIdx.x;
@@ -370,24 +372,24 @@ __global__ __launch_bounds__(256) void bpr_merge_kernel(int32_t total, int32_t n
   // (lower bound) - all of them advanced TOGETHER, one probe of every slice per round: the probes of a round are
   // independent loads (round 6: slice after slice it was a chain of up to 15 x 12 dependent L2 round trips, 19.7 us
   // for the CF step's 30,720 ids).  Same positions.
-  int32_t lo[kSliceSortMaxLists], hi[kSliceSortMaxLists];
+  int32_t lo[NL], hi[NL];
 #pragma unroll
-  for (int L = 0; L < kSliceSortMaxLists; ++L) {
+  for (int L = 0; L < NL; ++L) {
     const int32_t g0 = L * kSliceSort;
     lo[L] = 0;
     hi[L] = (L < n_lists && L != mine) ? (total - g0 < kSliceSort ? total - g0 : kSliceSort) : 0;
   }
   for (int step = 0; step < 13; ++step) {   // 2^12 = kSliceSort entries: 13 halvings empty every range
-    uint64_t probe[kSliceSortMaxLists];
+    uint64_t probe[NL];
 #pragma unroll
-    for (int L = 0; L < kSliceSortMaxLists; ++L) {
+    for (int L = 0; L < NL; ++L) {
       // (unconditional: a load under a lane mask is waited for on the spot - sixteen round trips per round again; an
       //  empty range probes entry 0 of its slice, or of slice 0 if the slice does not exist, and ignores it)
       const int32_t mid = lo[L] < hi[L] ? (lo[L] + hi[L]) >> 1 : 0;
       probe[L] = lists[(L < n_lists ? L * kSliceSort : 0) + mid] >> 17;
     }
 #pragma unroll
-    for (int L = 0; L < kSliceSortMaxLists; ++L) {
+    for (int L = 0; L < NL; ++L) {
       const int32_t mid = (lo[L] + hi[L]) >> 1;
       const uint64_t bound = L < mine ? key + 1 : key;
       if (lo[L] < hi[L]) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void bpr_merge_kernel(int32_t total, int32_t n
     }
   }
 #pragma unroll
-  for (int L = 0; L < kSliceSortMaxLists; ++L) pos += lo[L];
+  for (int L = 0; L < NL; ++L) pos += lo[L];
   order[pos] = (int32_t)(v & 0x1FFFFull);
   sorted[pos] = (int32_t)key;
 }
@@ -478,8 +480,12 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
     hipLaunchKernelGGL(bpr_sort_zero_kernel, dim3((unsigned)n_lists + zero_blocks), dim3(1024), 0, st, (int32_t)batch, n_lists,
                        n_nodes, bits_for_id(n_nodes), u, p, n, lists, grad, (int64_t)n_nodes * F);
     KGAT_CHECK_LAUNCH("bpr_sort_zero");
-    hipLaunchKernelGGL(bpr_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, n_lists,
-                       (const uint64_t*)lists, order, sorted_w);
+    if (n_lists <= 8)
+      hipLaunchKernelGGL(bpr_merge_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, n_lists,
+                         (const uint64_t*)lists, order, sorted_w);
+    else
+      hipLaunchKernelGGL(bpr_merge_kernel<kSliceSortMaxLists>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
+                         n_lists, (const uint64_t*)lists, order, sorted_w);
     KGAT_CHECK_LAUNCH("bpr_merge");
     sorted = sorted_w;
   } else {
