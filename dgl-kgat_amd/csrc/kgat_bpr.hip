@@ -269,6 +269,8 @@ __global__ __launch_bounds__(256) void bpr_carry_kernel(int64_t batch, int64_t n
 constexpr int kSliceSort = 4096;
 constexpr int kSliceSortMaxLists = 16;
 constexpr int kSliceWaves = 16;
+constexpr int kSliceDigitBits = 9;   // 18-bit ids (the CKGs of the reference's datasets) in TWO passes; eight bits took three
+constexpr int kSliceDigits = 1 << kSliceDigitBits;
 
 __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int32_t n_lists, int64_t n_nodes, int key_bits,
                                                              const int32_t* __restrict__ u, const int32_t* __restrict__ p,
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
     return;
   }
   __shared__ uint64_t s_buf[2][kSliceSort];
-  __shared__ int32_t s_cnt[256 * kSliceWaves];
+  __shared__ int32_t s_cnt[kSliceDigits * kSliceWaves];
   __shared__ int32_t s_wsum[kSliceWaves];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t total = 3 * batch;
@@ -298,19 +300,21 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
   const int32_t slice = ((cnt + kSliceWaves * 64 - 1) / (kSliceWaves * 64)) * 64;  // per wavefront, a multiple of 64
   const int32_t lo = w * slice, hi = lo + slice < cnt ? lo + slice : cnt;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int passes = (key_bits + 7) / 8;
+  const int passes = (key_bits + kSliceDigitBits - 1) / kSliceDigitBits;
   int cur = 0;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = 17 + 8 * pass;
-    for (int i = tid; i < 256 * kSliceWaves; i += 1024) s_cnt[i] = 0;
+    const int shift = 17 + kSliceDigitBits * pass;
+    constexpr int CPT = kSliceDigits * kSliceWaves / 1024;   // counters per thread
+    for (int i = tid; i < kSliceDigits * kSliceWaves; i += 1024) s_cnt[i] = 0;
     __syncthreads();
-    for (int32_t i = lo + lane; i < hi; i += 64) atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & 255u) * kSliceWaves + w], 1);
+    for (int32_t i = lo + lane; i < hi; i += 64)
+      atomicAdd(&s_cnt[(uint32_t)((s_buf[cur][i] >> shift) & (uint32_t)(kSliceDigits - 1)) * kSliceWaves + w], 1);
     __syncthreads();
-    {  // exclusive scan of the 4096 counters in (digit, wavefront) order, 4 per thread
-      int32_t c[4];
+    {  // exclusive scan of the counters in (digit, wavefront) order, CPT per thread
+      int32_t c[CPT];
+      int32_t mine = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] = s_cnt[4 * tid + q];
-      const int32_t mine = c[0] + c[1] + c[2] + c[3];
+      for (int q = 0; q < CPT; ++q) { c[q] = s_cnt[CPT * tid + q]; mine += c[q]; }
       int32_t inc = mine;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -322,8 +326,8 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
       int32_t base = inc - mine;
       for (int q = 0; q < w; ++q) base += s_wsum[q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s_cnt[4 * tid + q] = base;
+      for (int q = 0; q < CPT; ++q) {
+        s_cnt[CPT * tid + q] = base;
         base += c[q];
       }
     }
@@ -332,10 +336,10 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
       const int32_t i = i0 + lane;
       const bool valid = i < hi;
       const uint64_t v = valid ? s_buf[cur][i] : 0ull;
-      const uint32_t dgt = (uint32_t)((v >> shift) & 255u);
+      const uint32_t dgt = (uint32_t)((v >> shift) & (uint32_t)(kSliceDigits - 1));
       uint64_t peers = __ballot(valid);
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
+      for (int bit = 0; bit < kSliceDigitBits; ++bit) {
         const bool on = (dgt >> bit) & 1u;
         const uint64_t bal = __ballot(on);
         peers &= on ? bal : ~bal;
@@ -361,7 +365,17 @@ __global__ __launch_bounds__(1024) void bpr_sort_zero_kernel(int32_t batch, int3
 // (NL: the slices the search is unrolled over - 8 at the CF step's batch, 30,720 ids in eight slices)
 template <int NL>
 __global__ __launch_bounds__(256) void bpr_merge_kernel(int32_t total, int32_t n_lists, const uint64_t* __restrict__ lists,
-                                                        int32_t* __restrict__ order, int32_t* __restrict__ sorted) {
+                                                        int32_t* __restrict__ order, int32_t* __restrict__ sorted,
+                                                        float* __restrict__ zero, int64_t n_zero) {
+  // the blocks behind the merge's own: the second part of the gradient's zero fill (see kgat_bpr_grad_f32)
+  const int32_t merge_blocks = (total + 255) / 256;
+  if ((int32_t)blockIdx.x >= merge_blocks) {
+    const int64_t n4 = n_zero / 4, stride = (int64_t)(gridDim.x - merge_blocks) * 256;
+    float4* z = reinterpret_cast<float4*>(zero);
+    for (int64_t i = (int64_t)(blockIdx.x - merge_blocks) * 256 + threadIdx.x; i < n4; i += stride)
+      z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int32_t t = (int32_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
   const uint64_t v = lists[t];
@@ -476,16 +490,23 @@ int kgat_bpr_grad_f32(int64_t n_nodes, int F, const float* emb, int64_t emb_stri
     uint64_t* lists = cs.take<uint64_t>((size_t)batch * 3);
     int32_t* sorted_w = cs.take<int32_t>((size_t)batch * 3);
     const int32_t total = (int32_t)(3 * batch), n_lists = (total + kSliceSort - 1) / kSliceSort;
+    // The zero fill of the N x F gradient (112 MB at the amazon-book size: 25 us of stores) rides beside the two
+    // launches in front of the scatter, both of them chains of round trips on a few workgroups: the sort's launch
+    // (~17 us with two radix passes) takes the first 75 %, the merge's (12 us) the rest.  F is a multiple of 4, so both
+    // parts are whole float4s.
     const unsigned zero_blocks = 2u * (unsigned)device_cu_count();
+    const int64_t n_all = (int64_t)n_nodes * F;
+    const int64_t n_first = (n_all * 75 / 100) / 4 * 4;
     hipLaunchKernelGGL(bpr_sort_zero_kernel, dim3((unsigned)n_lists + zero_blocks), dim3(1024), 0, st, (int32_t)batch, n_lists,
-                       n_nodes, bits_for_id(n_nodes), u, p, n, lists, grad, (int64_t)n_nodes * F);
+                       n_nodes, bits_for_id(n_nodes), u, p, n, lists, grad, n_first);
     KGAT_CHECK_LAUNCH("bpr_sort_zero");
+    const unsigned merge_blocks = (unsigned)((total + 255) / 256), zero_blocks2 = 8u * (unsigned)device_cu_count();
     if (n_lists <= 8)
-      hipLaunchKernelGGL(bpr_merge_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, n_lists,
-                         (const uint64_t*)lists, order, sorted_w);
+      hipLaunchKernelGGL(bpr_merge_kernel<8>, dim3(merge_blocks + zero_blocks2), dim3(256), 0, st, total, n_lists,
+                         (const uint64_t*)lists, order, sorted_w, grad + n_first, n_all - n_first);
     else
-      hipLaunchKernelGGL(bpr_merge_kernel<kSliceSortMaxLists>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
-                         n_lists, (const uint64_t*)lists, order, sorted_w);
+      hipLaunchKernelGGL(bpr_merge_kernel<kSliceSortMaxLists>, dim3(merge_blocks + zero_blocks2), dim3(256), 0, st, total,
+                         n_lists, (const uint64_t*)lists, order, sorted_w, grad + n_first, n_all - n_first);
     KGAT_CHECK_LAUNCH("bpr_merge");
     sorted = sorted_w;
   } else {
