@@ -3,9 +3,10 @@
 // (gathers, batched dot products, logsigmoid, three regularisers, an index_put with a device sort): 75 launches of
 // a few microseconds each, 0.7 ms of the 1.6 ms CF step, all of it launch latency.  Here:
 //   forward   bpr_sample_kernel (one wavefront per sample: the three rows, five dot products) + bpr_reduce_kernel
-//   backward  four launches of bounded work: bpr_sort_zero_kernel (slices of 4,096 row ids sorted in LDS beside the
-//             zero fill of the N x F gradient) + bpr_merge_kernel (every id's place among all ids: a stable merge by
-//             binary searches; up to 65,536 ids - beyond: the device radix sort of kgat_graph.hip + a memset) +
+//   backward  four launches of bounded work: bpr_sort_zero_kernel (slices of 4,096 row ids sorted in LDS beside
+//             three quarters of the zero fill of the N x F gradient) + bpr_merge_kernel (every id's place among all
+//             ids: a stable merge by binary searches advanced together, beside the rest of the fill; up to 65,536 ids -
+//             beyond: the device radix sort of kgat_graph.hip + a memset) +
 //             bpr_window_kernel (a wavefront per 32 sorted positions adds their contributions in order; rows inside
 //             the window are written, pieces of rows that cross its edges left as partials) + bpr_carry_kernel (the
 //             crossing rows' pieces in window order): fixed order of additions, no float atomics, bitwise
