@@ -122,7 +122,12 @@ struct EvalLds {
 // With the rows in registers a wavefront needs 16.6 KB, two workgroups of four fit a CU, and a second wavefront per
 // SIMD issues MFMAs while the first one filters; no ds_read per MFMA either.  The arithmetic is the same fmaf chain
 // in the same k order: same score bits.  KG = 0: the LDS form (any width).
-constexpr int kEvalRegKG = 11;    // F in (160, 176]: the 64 + 64 + 32 + 16 readout of the reference's default model
+// Instantiated for KG = 11 (the 64 + 64 + 32 + 16 = 176-column readout of the reference's default model), 6 and 16: a
+// width in (40, 96] / (96, 176] / (176, 256] is padded with zero columns to 96 / 176 / 256 and takes the register form
+// of that size (70,679 x 24,915, K = 20: 160 columns 9.1 ms in the LDS form, 5.7 padded to 176; 88 columns 6.4 vs 3.1;
+// 192 columns 17.1 ms in the LDS form).  Narrower rows are cheaper in the LDS form (16 columns: 2.2 ms), wider ones do
+// not fit the registers.
+__host__ __device__ constexpr int eval_reg_kg(int F) { return F <= 40 ? 0 : (F <= 96 ? 6 : (F <= 176 ? 11 : (F <= 256 ? 16 : 0))); }
 
 // (two wavefronts per SIMD at most - the LDS allows no more in either form - so the allocator may use 256 registers:
 // left to its default budget it kept 150 and spilled the users' rows to scratch)
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     // past the end re-reads the clamped last tile and is skipped.
     // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
     //  per step - the index as an integral_constant - sent every captured array to scratch)
-    static_assert(KG == 11 && U == 8, "the step list below is written out for 2 x 11 steps of 2 halves");
+    static_assert(KG <= 16 && U == 8, "the step list below is written out for up to 2 x 16 steps of 2 halves");
     const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
     const size_t seg_bytes = (size_t)(t_hi - t_lo) * KG * 2048;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     issue_half(h1, t_lo, 0, 1);
     issue_half(h2, t_lo, 1, 0);
 #define KGAT_EVAL_HALF(J, CUR, NXT)                                                                       \
-    {                                                                                                     \
+    if constexpr (J < 4 * KG) {                                                                           \
       constexpr int j = J, g = (j / 2) % KG, q = j % 2, jn = j + 3, gn = (jn / 2) % KG, qn = jn % 2;      \
       const int64_t tt = t0 + (j / 2 / KG) * kEvalNT, tn = t0 + (jn / 2 / KG) * kEvalNT;                  \
       issue_half(NXT, tn, gn, qn);                                                                        \
@@ -421,7 +426,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
 #define KGAT_EVAL_HALF4(J) KGAT_EVAL_HALF(J, h0, h3) KGAT_EVAL_HALF(J + 1, h1, h0) KGAT_EVAL_HALF(J + 2, h2, h1) KGAT_EVAL_HALF(J + 3, h3, h2)
     for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * kEvalNT) {
       KGAT_EVAL_HALF4(0) KGAT_EVAL_HALF4(4) KGAT_EVAL_HALF4(8) KGAT_EVAL_HALF4(12) KGAT_EVAL_HALF4(16) KGAT_EVAL_HALF4(20)
-      KGAT_EVAL_HALF4(24) KGAT_EVAL_HALF4(28) KGAT_EVAL_HALF4(32) KGAT_EVAL_HALF4(36) KGAT_EVAL_HALF4(40)
+      KGAT_EVAL_HALF4(24) KGAT_EVAL_HALF4(28) KGAT_EVAL_HALF4(32) KGAT_EVAL_HALF4(36) KGAT_EVAL_HALF4(40) KGAT_EVAL_HALF4(44)
+      KGAT_EVAL_HALF4(48) KGAT_EVAL_HALF4(52) KGAT_EVAL_HALF4(56) KGAT_EVAL_HALF4(60)   // (beyond 4 KG: compiled out)
     }
 #undef KGAT_EVAL_HALF4
 #undef KGAT_EVAL_HALF
@@ -491,13 +497,12 @@ __global__ __launch_bounds__(256) void eval_merge_kernel(
   }
 }
 
-// k pairs of a row, padded with zeros to the unroll of the MFMA loop
-static int eval_fp2(int F) { return ((F + 1) / 2 + 7) / 8 * 8; }
+// k pairs of a row, padded with zeros: to the register form's size where there is one, else to the unroll of the MFMA loop
+static int eval_fp2(int F) { return eval_reg_kg(F) > 0 ? eval_reg_kg(F) * 8 : ((F + 1) / 2 + 7) / 8 * 8; }
 
-static bool eval_rows_in_registers(int FP2) { return FP2 == kEvalRegKG * 8; }
-
-static int eval_waves_per_block(int FP2) {
-  if (eval_rows_in_registers(FP2)) return 4;
+static int eval_waves_per_block(int F) {
+  const int FP2 = eval_fp2(F);
+  if (eval_reg_kg(F) > 0) return 4;
   // the largest workgroup whose wavefronts' LDS (candidates + the users' rows) fits a CU
   for (int nw = 4; nw >= 1; nw >>= 1)
     if (EvalLds::per_wave_bytes(FP2) * nw <= (size_t)160 * 1024) return nw;
@@ -535,12 +540,12 @@ static double eval_makespan(int64_t blocks, int64_t slots, const double* frac, i
 
 static EvalPlanH eval_plan(int64_t n_users, int64_t n_items, int F) {
   EvalPlanH p;
-  p.nw = eval_waves_per_block(eval_fp2(F));
+  p.nw = eval_waves_per_block(F);
   const int64_t n_tiles = (n_items + kEvalTile - 1) / kEvalTile;
   const int64_t rest = n_tiles;
   const int nw = p.nw > 0 ? p.nw : 1;
   const int64_t blocks = (n_users + 32 * nw - 1) / (32 * nw);
-  const bool reg = eval_rows_in_registers(eval_fp2(F));
+  const bool reg = eval_reg_kg(F) > 0;
   const int64_t slots = (int64_t)device_cu_count() * (reg ? 2 : 1);   // resident workgroups (LDS bound)
   // about two rounds of resident workgroups (measured against one and four at the shapes of the reference's three
   // datasets and at 8,000 users: profiles/r06_eval_scan.txt - every row more is another prologue, warm-up and list
@@ -591,8 +596,7 @@ using namespace kgat;
 extern "C" {
 
 int kgat_eval_supported(int F, int K) {
-  const int FP2 = eval_fp2(F);
-  return F >= 1 && K >= 1 && K <= kEvalMaxK && eval_waves_per_block(FP2) > 0;
+  return F >= 1 && K >= 1 && K <= kEvalMaxK && eval_waves_per_block(F) > 0;
 }
 
 int64_t kgat_eval_items_elems(int64_t n_items, int F) {
@@ -652,7 +656,8 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   float* part_s = cv.take<float>((size_t)n_users * pl.n_lists * K);
   int32_t* part_i = cv.take<int32_t>((size_t)n_users * pl.n_lists * K);
   unsigned* tau_shared = cv.take<unsigned>((size_t)n_users);   // shared K-th best per user (order-preserving bits)
-  const bool reg = eval_rows_in_registers(FP2);
+  const int kg = eval_reg_kg(F);
+  const bool reg = kg > 0;
   const size_t lds = EvalLds::per_wave_bytes(FP2, reg) * nw;
   const unsigned gx = (unsigned)((n_users + 32 * nw - 1) / (32 * nw));
   hipStream_t st = as_stream(stream);
@@ -672,7 +677,9 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
     return KGAT_E_HIP;
   }
   // ONE launch over (user blocks) x (item segments)
-  if (reg) KGAT_EVAL_LAUNCH(4, kEvalRegKG);
+  if (kg == 6) KGAT_EVAL_LAUNCH(4, 6);
+  else if (kg == 11) KGAT_EVAL_LAUNCH(4, 11);
+  else if (kg == 16) KGAT_EVAL_LAUNCH(4, 16);
   else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0);
   else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0);
   else KGAT_EVAL_LAUNCH(1, 0);

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dgl_kgat_amd import metrics, ops
 dev = torch.device("cuda:0")
-n_u, n_i, F, K = int(os.environ.get("EVAL_PROBE_USERS", 70679)), int(os.environ.get("EVAL_PROBE_ITEMS", 24915)), 176, 20
+n_u, n_i, F, K = int(os.environ.get("EVAL_PROBE_USERS", 70679)), int(os.environ.get("EVAL_PROBE_ITEMS", 24915)), int(os.environ.get("EVAL_PROBE_F", 176)), 20
 g = torch.Generator(device="cpu").manual_seed(5)
 emb = torch.randn((n_u + n_i, F), generator=g).to(dev)
 rng = np.random.default_rng(6)
