@@ -375,12 +375,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     }
   };
   if constexpr (REG) {
-    // Two tile groups per loop iteration = 44 half steps (tile group, k group, half of the k group) with compile-time
-    // k groups - the register index of the B operand.  A half step is two 16-byte loads per lane (four k pairs of both
-    // tiles) and eight MFMAs; its loads are issued THREE half steps ahead into a ring of four buffers (the registers of
-    // two whole-step buffers: one step ahead was 1,024 MFMA cycles, about the L2's latency under this load; three half
-    // steps are 1,536).  44 is a multiple of 4: the ring position of a half step is a compile-time constant.  A group
-    // past the end re-reads the clamped last tile and is skipped.
+    // Two tile groups per loop iteration = 4 KG half steps (tile group, k group, half of the k group; 44 at KG = 11) with
+    // compile-time k groups - the register index of the B operand.  A half step is two 16-byte loads per lane (four k
+    // pairs of both tiles) and eight MFMAs; its loads are issued THREE half steps ahead into a ring of four buffers (the
+    // registers of two whole-step buffers: one step ahead was 1,024 MFMA cycles, about the L2's latency under this
+    // load; three half steps are 1,536).  4 KG is a multiple of 4: the ring position of a half step is a compile-time
+    // constant.  A group past the end re-reads the clamped last tile and is skipped.
     // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
     //  per step - the index as an integral_constant - sent every captured array to scratch)
     static_assert(KG <= 16 && U == 8, "the step list below is written out for up to 2 x 16 steps of 2 halves");
