@@ -32,7 +32,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kEvalCap = 64;      // candidate entries per user (one per lane of the pruning wavefront)
 constexpr int kEvalMaxK = 32;
 constexpr int kEvalTile = 32;     // items per MFMA tile
-constexpr int kEvalNT = 2;        // item tiles in flight per wavefront
+// (item tiles in flight per wavefront: two, one in the widest register form - NT in the kernel)
 constexpr float kNegInf = -__builtin_inff();
 constexpr int kIdxPad = 0x7fffffff;
 
@@ -127,7 +127,11 @@ struct EvalLds {
 // of that size (70,679 x 24,915, K = 20: 160 columns 9.1 ms in the LDS form, 5.7 padded to 176; 88 columns 6.4 vs 3.1;
 // 192 columns 17.1 ms in the LDS form).  Narrower rows are cheaper in the LDS form (16 columns: 2.2 ms), wider ones do
 // not fit the registers.
-__host__ __device__ constexpr int eval_reg_kg(int F) { return F <= 40 ? 0 : (F <= 96 ? 6 : (F <= 176 ? 11 : (F <= 256 ? 16 : 0))); }
+// KG = 22 (352 columns: the 128 + 128 + 64 + 32 readout of the d = 128 model) keeps 176 row values per lane and ONE item
+// tile in flight instead of two (a single accumulator chain per wavefront; the second wavefront of the SIMD fills in).
+__host__ __device__ constexpr int eval_reg_kg(int F) {
+  return F <= 40 ? 0 : (F <= 96 ? 6 : (F <= 176 ? 11 : (F <= 256 ? 16 : (F <= 352 ? 22 : 0))));
+}
 
 // (two wavefronts per SIMD at most - the LDS allows no more in either form - so the allocator may use 256 registers:
 // left to its default budget it kept 150 and spilled the users' rows to scratch)
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ul = lane & 31, half = lane >> 5;
   constexpr bool REG = KG > 0;
+  constexpr int NT = KG > 16 ? 1 : 2;   // item tiles in flight: one where the users' rows leave no registers for two
   char* base = s_raw + (size_t)w * EvalLds::per_wave_bytes(FP2, REG);
   float* cand_s = reinterpret_cast<float*>(base);
   int32_t* cand_i = reinterpret_cast<int32_t*>(base + 32 * kEvalCap * 4);
@@ -277,12 +282,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
   const floatx4* a_base = reinterpret_cast<const floatx4*>(itemT) + lane;
   const int KGR = FP2 / U;                                     // k groups per tile group (FP2 is a multiple of U)
   struct Pos { int64_t t0; int g; };
-  auto advance = [&](Pos& p) { if (++p.g == KGR) { p.g = 0; p.t0 += kEvalNT; } };
-  auto issue = [&](float (&a)[U][kEvalNT], const Pos& p) {
+  auto advance = [&](Pos& p) { if (++p.g == KGR) { p.g = 0; p.t0 += NT; } };
+  auto issue = [&](float (&a)[U][NT], const Pos& p) {
     // (unconditional: a load under a branch makes the compiler's counted vmcnt waits conservative - it then waited
     // for the NEXT step's loads before this step's MFMAs; past the end the clamped tile is loaded again, unused)
 #pragma unroll
-    for (int t = 0; t < kEvalNT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int64_t tt = p.t0 + t < t_hi ? p.t0 + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
       const floatx4* ap = a_base + ((size_t)tt * KGR + p.g) * (U / 4) * 64;
 #pragma unroll
@@ -293,16 +298,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
       }
     }
   };
-  floatx16 acc[kEvalNT];
+  floatx16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < kEvalNT; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   // acc[t][r]: user ul, item position 32 (t0 + t) + (r & 3) + 8 (r >> 2) + 4 half
   auto check = [&](int64_t t0) {
     adopt_shared();
 #pragma unroll
-    for (int t = 0; t < kEvalNT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       if (t0 + t >= t_hi) break;  // wave-uniform
       const int ib = (int)((t0 + t) * kEvalTile) + 4 * half;
       if ((t0 + t + 1) * kEvalTile > n_items) {   // the padded end of the last tile (wave-uniform): never a candidate
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     if (tau_shared != nullptr)   // for the next tile group's check (an L2 round trip behind that group's MFMAs)
       sh_next = from_ordered_bits(__hip_atomic_load(tau_shared + up_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (past the L1)
   };
-  auto compute = [&](const float (&a)[U][kEvalNT], const Pos& p) {
+  auto compute = [&](const float (&a)[U][NT], const Pos& p) {
     if (p.t0 >= t_hi) return;
     float b[U];
 #pragma unroll
@@ -364,12 +369,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < kEvalNT; ++t)
+      for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u], acc[t], 0, 0, 0);
     if (p.g == KGR - 1) {
       check(p.t0);
 #pragma unroll
-      for (int t = 0; t < kEvalNT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;   // (here, behind the check's branch: not a select per step)
     }
@@ -383,15 +388,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
     // constant.  A group past the end re-reads the clamped last tile and is skipped.
     // (written out, not a loop: `#pragma unroll` over the steps was declined by the optimiser, and a generic lambda
     //  per step - the index as an integral_constant - sent every captured array to scratch)
-    static_assert(KG <= 16 && U == 8, "the step list below is written out for up to 2 x 16 steps of 2 halves");
+    static_assert(KG <= 22 && U == 8, "the step list below is written out for up to 2 x 22 steps of 2 halves");
     const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float h0[4][kEvalNT], h1[4][kEvalNT], h2[4][kEvalNT], h3[4][kEvalNT];
+    float h0[4][NT], h1[4][NT], h2[4][NT], h3[4][NT];
     const size_t seg_bytes = (size_t)(t_hi - t_lo) * KG * 2048;
     const __amdgpu_buffer_rsrc_t seg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(itemT) + (size_t)t_lo * KG * 512, 0, (int)(unsigned)seg_bytes, 0x00020000);
-    auto issue_half = [&](float (&a)[4][kEvalNT], int64_t tg, int g, int q) {
+    auto issue_half = [&](float (&a)[4][NT], int64_t tg, int g, int q) {
 #pragma unroll
-      for (int t = 0; t < kEvalNT; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int64_t tt = tg + t < t_hi ? tg + t : t_hi - 1;   // (a clamped duplicate tile is ignored below)
         // (a buffer load: the segment's fragments as a resource, the wave-uniform offset in a scalar register, the lane's
         //  16 bytes the only vector operand - as a global load every address was two 64-bit vector adds, six vector
@@ -408,14 +413,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
 #define KGAT_EVAL_HALF(J, CUR, NXT)                                                                       \
     if constexpr (J < 4 * KG) {                                                                           \
       constexpr int j = J, g = (j / 2) % KG, q = j % 2, jn = j + 3, gn = (jn / 2) % KG, qn = jn % 2;      \
-      const int64_t tt = t0 + (j / 2 / KG) * kEvalNT, tn = t0 + (jn / 2 / KG) * kEvalNT;                  \
+      const int64_t tt = t0 + (j / 2 / KG) * NT, tn = t0 + (jn / 2 / KG) * NT;                  \
       issue_half(NXT, tn, gn, qn);                                                                        \
       /* the loads go out HERE, ahead of this half step's MFMAs: left to itself the scheduler sinks them between */ \
       /* the MFMAs and waits for each a few instructions after issuing it                                         */ \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
       if (tt < t_hi) { /* wave-uniform */                                                                 \
         _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                     \
-          _Pragma("unroll") for (int t = 0; t < kEvalNT; ++t)                                             \
+          _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
             /* (a tile group's first MFMA adds to the constant 0: no clearing of 32 registers per group) */ \
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[c][t], breg[g * U + 4 * q + c],             \
                                                           (g == 0 && q == 0 && c == 0) ? zero16 : acc[t], 0, 0, 0); \
@@ -424,15 +429,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2), 
       }                                                                                                   \
     }
 #define KGAT_EVAL_HALF4(J) KGAT_EVAL_HALF(J, h0, h3) KGAT_EVAL_HALF(J + 1, h1, h0) KGAT_EVAL_HALF(J + 2, h2, h1) KGAT_EVAL_HALF(J + 3, h3, h2)
-    for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * kEvalNT) {
+    for (int64_t t0 = t_lo; t0 < t_hi; t0 += 2 * NT) {
       KGAT_EVAL_HALF4(0) KGAT_EVAL_HALF4(4) KGAT_EVAL_HALF4(8) KGAT_EVAL_HALF4(12) KGAT_EVAL_HALF4(16) KGAT_EVAL_HALF4(20)
       KGAT_EVAL_HALF4(24) KGAT_EVAL_HALF4(28) KGAT_EVAL_HALF4(32) KGAT_EVAL_HALF4(36) KGAT_EVAL_HALF4(40) KGAT_EVAL_HALF4(44)
-      KGAT_EVAL_HALF4(48) KGAT_EVAL_HALF4(52) KGAT_EVAL_HALF4(56) KGAT_EVAL_HALF4(60)   // (beyond 4 KG: compiled out)
+      KGAT_EVAL_HALF4(48) KGAT_EVAL_HALF4(52) KGAT_EVAL_HALF4(56) KGAT_EVAL_HALF4(60) KGAT_EVAL_HALF4(64) KGAT_EVAL_HALF4(68)
+      KGAT_EVAL_HALF4(72) KGAT_EVAL_HALF4(76) KGAT_EVAL_HALF4(80) KGAT_EVAL_HALF4(84)   // (beyond 4 KG: compiled out)
     }
 #undef KGAT_EVAL_HALF4
 #undef KGAT_EVAL_HALF
   } else {
-    float a0[U][kEvalNT], a1[U][kEvalNT];
+    float a0[U][NT], a1[U][NT];
     Pos p0{t_lo, 0}, p1{t_lo, 0};
     advance(p1);
     issue(a0, p0);
@@ -680,6 +686,7 @@ int kgat_eval_recall_ndcg_f32(int64_t n_users, const int32_t* user_ids, int64_t 
   if (kg == 6) KGAT_EVAL_LAUNCH(4, 6);
   else if (kg == 11) KGAT_EVAL_LAUNCH(4, 11);
   else if (kg == 16) KGAT_EVAL_LAUNCH(4, 16);
+  else if (kg == 22) KGAT_EVAL_LAUNCH(4, 22);
   else if (nw == 4) KGAT_EVAL_LAUNCH(4, 0);
   else if (nw == 2) KGAT_EVAL_LAUNCH(2, 0);
   else KGAT_EVAL_LAUNCH(1, 0);

@@ -83,7 +83,7 @@ def test_eval_vs_oracle_masked_items_and_empty_lists(dev):
 @pytest.mark.parametrize("n_u,n_i,F,K", [(70, 45, 13, 5), (33, 32, 8, 32), (5, 64, 7, 1), (260, 1500, 24, 20),
                                          (129, 2100, 176, 20), (64, 40, 200, 8), (40, 300, 360, 20),
                                          (150, 1900, 41, 20), (97, 2300, 96, 20), (200, 1500, 161, 9), (77, 2500, 256, 20),
-                                         (60, 700, 257, 5)])
+                                         (60, 700, 257, 5), (70, 1800, 352, 20), (45, 2600, 300, 7)])
 def test_eval_ties_and_masked_zeros_exact(dev, n_u, n_i, F, K):
     """Small-integer embeddings: every fp32 score is exact, so the ranking is decided by the rule alone - many equal
     scores (lower position first), negative K-th scores (the masked 0.0 of training items ranks), all-zero rows
@@ -120,7 +120,7 @@ def test_eval_ties_and_masked_zeros_exact(dev, n_u, n_i, F, K):
 
 
 @pytest.mark.parametrize("n_u,n_i,F,K", [(1100, 6000, 176, 20), (400, 9001, 176, 7), (500, 4000, 64, 20), (40, 30000, 176, 20),
-                                         (600, 5000, 208, 20), (300, 7000, 120, 20)])
+                                         (600, 5000, 208, 20), (300, 7000, 120, 20), (300, 5000, 352, 20)])
 def test_eval_real_valued_scores_and_racing_thresholds(dev, n_u, n_i, F, K):
     """Real-valued embeddings (fp32 scores, no exact ties) at sizes with a sample segment and several item segments per
     user block: the kernel's K best against an fp64 ranking of the same fp32 inputs - equal, or different only where two
