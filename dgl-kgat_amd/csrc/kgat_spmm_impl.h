@@ -422,13 +422,17 @@ constexpr int kSpmmSelfPrefetch = 0;  // measured SLOWER (100.7 vs 91.4 us at D 
 
   EdgeRec ra[G], rb[G];
   float4 xa[G], xb[G];
+  // The next group's records and rows are requested UNCONDITIONALLY (past the run's end: its last group again, rows the
+  // L1 has just seen, never consumed).  Round 6: they were requested under `if (g + 1 < ng)`, and a load under a branch
+  // makes the compiler's counted waits conservative - it cannot assume the four new loads are pending, so the current
+  // group's first row was waited for with vmcnt(3) instead of vmcnt(7): the wavefront sat out most of the round trip
+  // of the loads it had just issued, and the double buffering bought nothing.
   if (ng > 0) load_group(0, ra, xa);
   for (int g = 0; g < ng; g += 2) {
-    if (g + 1 < ng) load_group(g + 1, rb, xb);
+    load_group(g + 1 < ng ? g + 1 : ng - 1, rb, xb);
     consume(ra, xa);
-    if (g + 1 >= ng) break;
-    if (g + 2 < ng) load_group(g + 2, ra, xa);
-    consume(rb, xb);
+    load_group(g + 2 < ng ? g + 2 : ng - 1, ra, xa);
+    if (g + 1 < ng) consume(rb, xb);
   }
   for (int j = ng * G; j < n_run; ++j) {  // only the last run of the edge range is ragged
     const EdgeRec rec = run[j];
